@@ -1,0 +1,499 @@
+/*
+ * oracle/tfhe_oracle.c -- TEST INFRASTRUCTURE ONLY (CPU oracle).
+ *
+ * CPU restatement of the TFHE programmable-bootstrap path that the reference
+ * (MakisChristou/fhestring) reaches through `tfhe 0.5.2` (Cargo.lock:416-433)
+ * from src/ciphertext/fheasciichar.rs:23-102 and src/client_key.rs:31-99 with
+ * PARAM_MESSAGE_2_CARRY_2_KS_PBS (src/main.rs:3,43).  The arithmetic crate is
+ * NOT on disk, so this file restates its published algorithm (SURVEY.md
+ * Appendix A): LWE keyswitch -> modulus switch -> blind rotation (CMUX chain of
+ * GGSW x GLWE external products over Z_{2^64}[X]/(X^2048+1)) -> sample extract.
+ *
+ * PARITY STATUS: ciphertext-level parity with tfhe-rs is UNPINNED (the
+ * reference holds no ciphertext-level known-answer vectors, draws keys from OS
+ * entropy and multiplies polynomials with an f64 FFT).  What IS pinned:
+ *   - decrypt-level results against the reference's own test literals
+ *     (tests/golden/ref_tests.json, from src/main.rs:138-1153);
+ *   - the exact negacyclic product used here (Goldilocks NTT, 2 x 29-bit key
+ *     limbs) is checked bit-for-bit against a schoolbook product mod 2^64.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product path (fhestring_amd/) never does.
+ *
+ * Everything here is exact integer arithmetic (wrapping u64 torus).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef uint64_t u64;
+typedef int64_t i64;
+typedef uint32_t u32;
+typedef __uint128_t u128;
+
+/* ---- PARAM_MESSAGE_2_CARRY_2_KS_PBS -------------- */
+#define LWE_N 742       /* small LWE dimension                               */
+#define POLY_N 2048     /* GLWE polynomial size, k = 1                        */
+#define BIG_N 2048      /* big LWE dimension k*N                              */
+#define PBS_BASE_LOG 23 /* 1 level                                            */
+#define KS_BASE_LOG 3
+#define KS_LEVEL 5
+#define DELTA_LOG 59    /* 2 msg + 2 carry + 1 padding bit                    */
+#define LWE_NOISE 7.069849454709433e-6
+#define GLWE_NOISE 2.9403601535432533e-16
+#define BSK_QUANT_BITS 6 /* BSK coefficients are multiples of 2^6 (58-bit torus) */
+
+#define BSK_POLYS (LWE_N * 4)            /* [i][row][col] polys of POLY_N    */
+#define BSK_WORDS ((size_t)BSK_POLYS * POLY_N)
+#define KSK_WORDS ((size_t)BIG_N * KS_LEVEL * (LWE_N + 1))
+#define BIG_CT (BIG_N + 1)
+#define SMALL_CT (LWE_N + 1)
+
+/* ---- deterministic RNG (SplitMix64 + Box-Muller) ------------------------ */
+typedef struct { u64 s; } orc_rng;
+
+static inline u64 rng_u64(orc_rng *r) {
+    u64 z = (r->s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static inline double rng_unit(orc_rng *r) { /* (0,1] */
+    return ((double)(rng_u64(r) >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+}
+static inline u64 rng_noise(orc_rng *r, double std_frac) {
+    double u1 = rng_unit(r), u2 = rng_unit(r);
+    double g = sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925 * u2);
+    double v = g * std_frac * 18446744073709551616.0;
+    return (u64)(i64)llround(v);
+}
+
+/* ---- Goldilocks field p = 2^64 - 2^32 + 1 ------------------------------- */
+#define GP 0xFFFFFFFF00000001ull
+#define GEPS 0xFFFFFFFFull
+
+static inline u64 g_reduce128(u128 x) {
+    u64 lo = (u64)x, hi = (u64)(x >> 64);
+    u64 hh = hi >> 32, hl = hi & GEPS;
+    u64 t0 = lo - hh;
+    t0 -= GEPS & (0 - (u64)(lo < hh)); /* borrow: add p == subtract eps (mod 2^64) */
+    u64 t1 = hl * GEPS;
+    u64 res = t0 + t1;
+    res += GEPS & (0 - (u64)(res < t1));
+    u64 c = res - GP;
+    return res >= GP ? c : res;
+}
+static inline u64 g_mul(u64 a, u64 b) { return g_reduce128((u128)a * b); }
+static inline u64 g_add(u64 a, u64 b) { /* a,b < p */
+    u64 s = a + b;
+    u64 t = s - GP;
+    return ((s < a) | (s >= GP)) ? t : s;
+}
+static inline u64 g_sub(u64 a, u64 b) { return a - b + (GP & (0 - (u64)(a < b))); }
+static u64 g_pow(u64 b, u64 e) {
+    u64 r = 1;
+    while (e) { if (e & 1) r = g_mul(r, b); b = g_mul(b, b); e >>= 1; }
+    return r;
+}
+static u64 g_inv(u64 a) { return g_pow(a, GP - 2); }
+
+/* negacyclic NTT tables (Cooley-Tukey forward with merged psi powers,
+ * Gentleman-Sande inverse; bit-reversed twiddle order) */
+static u64 g_psi_br[POLY_N], g_ipsi_br[POLY_N], g_ninv;
+static int g_tables_ready = 0;
+static pthread_mutex_t g_tab_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static unsigned bitrev11(unsigned x) {
+    unsigned r = 0;
+    for (int i = 0; i < 11; i++) r |= ((x >> i) & 1u) << (10 - i);
+    return r;
+}
+static void g_init_tables(void) {
+    pthread_mutex_lock(&g_tab_mu);
+    if (!g_tables_ready) {
+        u64 psi = g_pow(7, (GP - 1) / (2 * POLY_N)); /* primitive 4096-th root */
+        u64 ipsi = g_inv(psi);
+        u64 a = 1, b = 1;
+        for (unsigned i = 0; i < POLY_N; i++) {
+            g_psi_br[bitrev11(i)] = a;
+            g_ipsi_br[bitrev11(i)] = b;
+            a = g_mul(a, psi);
+            b = g_mul(b, ipsi);
+        }
+        g_ninv = g_inv(POLY_N);
+        g_tables_ready = 1;
+    }
+    pthread_mutex_unlock(&g_tab_mu);
+}
+static void g_ntt_fwd(u64 *a) {
+    unsigned t = POLY_N;
+    for (unsigned m = 1; m < POLY_N; m <<= 1) {
+        t >>= 1;
+        for (unsigned i = 0; i < m; i++) {
+            u64 w = g_psi_br[m + i];
+            u64 *x = a + 2 * i * t, *y = x + t;
+            for (unsigned j = 0; j < t; j++) {
+                u64 u = x[j], v = g_mul(y[j], w);
+                x[j] = g_add(u, v);
+                y[j] = g_sub(u, v);
+            }
+        }
+    }
+}
+static void g_ntt_inv(u64 *a) {
+    unsigned t = 1;
+    for (unsigned m = POLY_N; m > 1; m >>= 1) {
+        unsigned h = m >> 1;
+        for (unsigned i = 0; i < h; i++) {
+            u64 w = g_ipsi_br[h + i];
+            u64 *x = a + 2 * i * t, *y = x + t;
+            for (unsigned j = 0; j < t; j++) {
+                u64 u = x[j], v = y[j];
+                x[j] = g_add(u, v);
+                y[j] = g_mul(g_sub(u, v), w);
+            }
+        }
+        t <<= 1;
+    }
+    for (unsigned j = 0; j < POLY_N; j++) a[j] = g_mul(a[j], g_ninv);
+}
+
+/* ---- server key --------------------------------------------------------- */
+typedef struct {
+    u64 *bsk;      /* [742][2 rows][2 cols][2048] std domain, quantised to 2^6 */
+    u64 *ksk;      /* [2048][5][743]                                          */
+    u64 *bsk_ntt;  /* [742][2 rows][2 cols][2 limbs][2048] Goldilocks NTT     */
+} orc_server_key;
+
+u64 orc_bsk_words(void) { return BSK_WORDS; }
+u64 orc_ksk_words(void) { return KSK_WORDS; }
+
+/* Round every BSK coefficient to the nearest multiple of 2^6.  The on-device
+ * key format is a 58-bit torus (see DESIGN.md "BSK precision"); keys generated
+ * by orc_keygen are already on that grid so this is then the identity. */
+void orc_bsk_quantize(u64 *bsk, u64 n) {
+    const u64 half = 1ull << (BSK_QUANT_BITS - 1);
+    const u64 mask = ~((1ull << BSK_QUANT_BITS) - 1);
+    for (u64 i = 0; i < n; i++) bsk[i] = (bsk[i] + half) & mask;
+}
+
+/* negacyclic a (*) S for binary S, wrapping u64 */
+static void negacyclic_mul_binary(const u64 *a, const u64 *s_bits, u64 *out) {
+    memset(out, 0, POLY_N * sizeof(u64));
+    for (unsigned j = 0; j < POLY_N; j++) {
+        if (!s_bits[j]) continue;
+        for (unsigned k = 0; k < j; k++) out[k] -= a[k + POLY_N - j];
+        for (unsigned k = j; k < POLY_N; k++) out[k] += a[k - j];
+    }
+}
+
+/* Key generation (restates what tfhe::integer::gen_keys_radix produces for the
+ * reference at src/client_key.rs:31; own seeded RNG).
+ *   lwe_sk[742], glwe_sk[2048]: binary secret keys (one u64 per bit)
+ *   bsk: GGSW_i encrypts lwe_sk[i]; row 0 = GLWE(-s_i*S(X)*2^41), row 1 = GLWE(s_i*2^41)
+ *   ksk[i][l] = LWE_small(glwe_sk[i] * 2^(64-3(l+1)))                      */
+void orc_keygen(u64 seed, u64 *lwe_sk, u64 *glwe_sk, u64 *bsk, u64 *ksk) {
+    orc_rng r = { seed };
+    for (int i = 0; i < LWE_N; i++) lwe_sk[i] = rng_u64(&r) >> 63;
+    for (int i = 0; i < POLY_N; i++) glwe_sk[i] = rng_u64(&r) >> 63;
+    const u64 qmask = ~((1ull << BSK_QUANT_BITS) - 1);
+    const u64 qhalf = 1ull << (BSK_QUANT_BITS - 1);
+    u64 *prod = (u64 *)malloc(POLY_N * sizeof(u64));
+    for (int i = 0; i < LWE_N; i++) {
+        for (int row = 0; row < 2; row++) {
+            u64 *mask = bsk + (((size_t)i * 2 + row) * 2 + 0) * POLY_N;
+            u64 *body = bsk + (((size_t)i * 2 + row) * 2 + 1) * POLY_N;
+            for (int n = 0; n < POLY_N; n++) mask[n] = rng_u64(&r) & qmask;
+            negacyclic_mul_binary(mask, glwe_sk, prod);
+            for (int n = 0; n < POLY_N; n++) {
+                u64 m;
+                if (row == 0) m = (u64)0 - (lwe_sk[i] * glwe_sk[n] << (64 - PBS_BASE_LOG));
+                else m = (n == 0) ? (lwe_sk[i] << (64 - PBS_BASE_LOG)) : 0;
+                u64 e = rng_noise(&r, GLWE_NOISE);
+                body[n] = (prod[n] + e + m + qhalf) & qmask;
+            }
+        }
+    }
+    free(prod);
+    for (int i = 0; i < BIG_N; i++) {
+        for (int l = 0; l < KS_LEVEL; l++) {
+            u64 *ct = ksk + ((size_t)i * KS_LEVEL + l) * SMALL_CT;
+            u64 acc = 0;
+            for (int j = 0; j < LWE_N; j++) {
+                ct[j] = rng_u64(&r);
+                acc += ct[j] * lwe_sk[j];
+            }
+            ct[LWE_N] = acc + rng_noise(&r, LWE_NOISE) +
+                        (glwe_sk[i] << (64 - KS_BASE_LOG * (l + 1)));
+        }
+    }
+}
+
+orc_server_key *orc_server_key_new(const u64 *bsk, const u64 *ksk) {
+    g_init_tables();
+    orc_server_key *k = (orc_server_key *)calloc(1, sizeof(*k));
+    k->bsk = (u64 *)malloc(BSK_WORDS * sizeof(u64));
+    k->ksk = (u64 *)malloc(KSK_WORDS * sizeof(u64));
+    k->bsk_ntt = (u64 *)malloc(2 * BSK_WORDS * sizeof(u64));
+    memcpy(k->bsk, bsk, BSK_WORDS * sizeof(u64));
+    memcpy(k->ksk, ksk, KSK_WORDS * sizeof(u64));
+    orc_bsk_quantize(k->bsk, BSK_WORDS);
+    const u64 lm = (1ull << 29) - 1;
+    for (size_t p = 0; p < BSK_POLYS; p++) {
+        const u64 *src = k->bsk + p * POLY_N;
+        u64 *l0 = k->bsk_ntt + (2 * p) * POLY_N, *l1 = l0 + POLY_N;
+        for (int n = 0; n < POLY_N; n++) {
+            u64 v = src[n] >> BSK_QUANT_BITS;
+            l0[n] = v & lm;
+            l1[n] = v >> 29;
+        }
+        g_ntt_fwd(l0);
+        g_ntt_fwd(l1);
+    }
+    return k;
+}
+void orc_server_key_free(orc_server_key *k) {
+    if (!k) return;
+    free(k->bsk); free(k->ksk); free(k->bsk_ntt); free(k);
+}
+
+/* ---- client side (src/client_key.rs:85-106 via RadixClientKey) ---------- */
+/* encrypt one shortint block value m in [0,32) (padding bit included) under
+ * the big key */
+void orc_encrypt_block(const u64 *glwe_sk, u64 m, u64 *rng_state, u64 *ct) {
+    orc_rng r = { *rng_state };
+    u64 acc = 0;
+    for (int j = 0; j < BIG_N; j++) {
+        ct[j] = rng_u64(&r);
+        acc += ct[j] * glwe_sk[j];
+    }
+    ct[BIG_N] = acc + rng_noise(&r, GLWE_NOISE) + (m << DELTA_LOG);
+    *rng_state = r.s;
+}
+u64 orc_phase(const u64 *glwe_sk, const u64 *ct) {
+    u64 acc = 0;
+    for (int j = 0; j < BIG_N; j++) acc += ct[j] * glwe_sk[j];
+    return ct[BIG_N] - acc;
+}
+/* decrypt to [0,32): 4 message+carry bits and the padding bit */
+u64 orc_decrypt_block(const u64 *glwe_sk, const u64 *ct) {
+    u64 ph = orc_phase(glwe_sk, ct);
+    return ((ph + (1ull << (DELTA_LOG - 1))) >> DELTA_LOG) & 31;
+}
+/* u8 -> 4 blocks of 2 bits, little endian (src/ciphertext/fheasciichar.rs:27-29) */
+void orc_encrypt_char(const u64 *glwe_sk, unsigned v, u64 *rng_state, u64 *ct4) {
+    for (int b = 0; b < 4; b++)
+        orc_encrypt_block(glwe_sk, (v >> (2 * b)) & 3, rng_state, ct4 + (size_t)b * BIG_CT);
+}
+/* decrypt::<u8>: sum block_i * 4^i (mod 256), carries included like tfhe's radix decrypt */
+unsigned orc_decrypt_char(const u64 *glwe_sk, const u64 *ct4) {
+    unsigned v = 0;
+    for (int b = 0; b < 4; b++)
+        v += (unsigned)(orc_decrypt_block(glwe_sk, ct4 + (size_t)b * BIG_CT) & 15) << (2 * b);
+    return v & 255;
+}
+
+/* ---- LUT generation (SURVEY.md Appendix A "LUT generation") ------------- */
+/* f_table[16]: output block values (mod 32 allowed, e.g. 31 for -1) */
+void orc_make_lut(const u64 *f_table, u64 *lut) {
+    const int box = POLY_N / 16, half = box / 2;
+    u64 tmp[POLY_N];
+    for (int x = 0; x < 16; x++)
+        for (int t = 0; t < box; t++) tmp[x * box + t] = f_table[x] << DELTA_LOG;
+    for (int i = 0; i < POLY_N - half; i++) lut[i] = tmp[i + half];
+    for (int t = 0; t < half; t++) lut[POLY_N - half + t] = (u64)0 - tmp[t];
+}
+
+/* ---- keyswitch + modulus switch ------------------------------------------ */
+/* out[743]: a~_0..a~_741, b~ in [0,4096) */
+void orc_keyswitch_modswitch(const orc_server_key *k, const u64 *in, u32 *out) {
+    u64 acc[SMALL_CT];
+    memset(acc, 0, sizeof(acc));
+    acc[LWE_N] = in[BIG_N];
+    const int tot = KS_BASE_LOG * KS_LEVEL; /* 15 */
+    for (int i = 0; i < BIG_N; i++) {
+        /* closest representable on 15 bits, then balanced base-8 digits */
+        u64 v = (in[i] + (1ull << (63 - tot))) >> (64 - tot);
+        for (int l = KS_LEVEL - 1; l >= 0; l--) { /* least significant level first */
+            i64 d = (i64)(v & 7);
+            v >>= 3;
+            if (d >= 4) { d -= 8; v += 1; }
+            if (d == 0) continue;
+            const u64 *row = k->ksk + ((size_t)i * KS_LEVEL + l) * SMALL_CT;
+            u64 du = (u64)d;
+            for (int j = 0; j < SMALL_CT; j++) acc[j] -= du * row[j];
+        }
+    }
+    for (int j = 0; j < SMALL_CT; j++)
+        out[j] = (u32)(((acc[j] + (1ull << 51)) >> 52) & 4095);
+}
+/* raw keyswitch output (before mod switch), for kernel-level tests */
+void orc_keyswitch(const orc_server_key *k, const u64 *in, u64 *out) {
+    memset(out, 0, SMALL_CT * sizeof(u64));
+    out[LWE_N] = in[BIG_N];
+    const int tot = KS_BASE_LOG * KS_LEVEL;
+    for (int i = 0; i < BIG_N; i++) {
+        u64 v = (in[i] + (1ull << (63 - tot))) >> (64 - tot);
+        for (int l = KS_LEVEL - 1; l >= 0; l--) {
+            i64 d = (i64)(v & 7);
+            v >>= 3;
+            if (d >= 4) { d -= 8; v += 1; }
+            if (d == 0) continue;
+            const u64 *row = k->ksk + ((size_t)i * KS_LEVEL + l) * SMALL_CT;
+            u64 du = (u64)d;
+            for (int j = 0; j < SMALL_CT; j++) out[j] -= du * row[j];
+        }
+    }
+}
+
+/* ---- blind rotation ------------------------------------------------------- */
+/* out = X^a * in, a in [0, 2N) */
+static void poly_rotate(const u64 *in, unsigned a, u64 *out) {
+    unsigned s = a & (POLY_N - 1);
+    int neg = (a >> 11) & 1;
+    for (unsigned n = 0; n < POLY_N; n++) {
+        u64 v = (n >= s) ? in[n - s] : (u64)0 - in[n + POLY_N - s];
+        out[n] = neg ? (u64)0 - v : v;
+    }
+}
+static inline i64 pbs_digit(u64 x) { /* closest multiple of 2^41, as signed 23-bit digit */
+    u64 v = ((x + (1ull << 40)) >> 41) & ((1ull << 23) - 1);
+    return (v >= (1ull << 22)) ? (i64)v - (1ll << 23) : (i64)v;
+}
+
+/* schoolbook ground truth: res += d (*) b  mod (X^N+1, 2^64) */
+static void negacyclic_mac_schoolbook(const i64 *d, const u64 *b, u64 *res) {
+    for (unsigned i = 0; i < POLY_N; i++) {
+        u64 di = (u64)d[i];
+        if (!di) continue;
+        for (unsigned j = 0; j < POLY_N - i; j++) res[i + j] += di * b[j];
+        for (unsigned j = POLY_N - i; j < POLY_N; j++) res[i + j - POLY_N] -= di * b[j];
+    }
+}
+
+/* mode 0: Goldilocks NTT (2 x 29-bit key limbs, exact); mode 1: schoolbook */
+static void blind_rotate(const orc_server_key *k, const u32 *ms, const u64 *lut,
+                         u64 *acc /* [2][N] */, int mode) {
+    u64 *rot = (u64 *)malloc(POLY_N * sizeof(u64));
+    i64 *dig = (i64 *)malloc(2 * POLY_N * sizeof(i64));
+    u64 *dn = (u64 *)malloc(2 * POLY_N * sizeof(u64));
+    u64 *tt = (u64 *)malloc(2 * POLY_N * sizeof(u64));
+    u64 *res = (u64 *)malloc(2 * POLY_N * sizeof(u64));
+    memset(acc, 0, POLY_N * sizeof(u64));
+    poly_rotate(lut, (2 * POLY_N - ms[LWE_N]) & (2 * POLY_N - 1), acc + POLY_N);
+    for (int i = 0; i < LWE_N; i++) {
+        unsigned a = ms[i];
+        if (a == 0) continue; /* X^0*acc - acc == 0: exact no-op */
+        for (int c = 0; c < 2; c++) {
+            poly_rotate(acc + c * POLY_N, a, rot);
+            for (int n = 0; n < POLY_N; n++) dig[c * POLY_N + n] = pbs_digit(rot[n] - acc[c * POLY_N + n]);
+        }
+        if (mode == 1) {
+            memset(res, 0, 2 * POLY_N * sizeof(u64));
+            for (int row = 0; row < 2; row++)
+                for (int col = 0; col < 2; col++)
+                    negacyclic_mac_schoolbook(dig + row * POLY_N,
+                                              k->bsk + (((size_t)i * 2 + row) * 2 + col) * POLY_N,
+                                              res + col * POLY_N);
+            for (int n = 0; n < 2 * POLY_N; n++) acc[n] += res[n];
+        } else {
+            for (int c = 0; c < 2; c++) {
+                for (int n = 0; n < POLY_N; n++) {
+                    i64 d = dig[c * POLY_N + n];
+                    dn[c * POLY_N + n] = d < 0 ? GP - (u64)(-d) : (u64)d;
+                }
+                g_ntt_fwd(dn + c * POLY_N);
+            }
+            for (int col = 0; col < 2; col++) {
+                for (int limb = 0; limb < 2; limb++) {
+                    const u64 *b0 = k->bsk_ntt + ((((size_t)i * 2 + 0) * 2 + col) * 2 + limb) * POLY_N;
+                    const u64 *b1 = k->bsk_ntt + ((((size_t)i * 2 + 1) * 2 + col) * 2 + limb) * POLY_N;
+                    u64 *t = tt + limb * POLY_N;
+                    for (int n = 0; n < POLY_N; n++)
+                        t[n] = g_add(g_mul(dn[n], b0[n]), g_mul(dn[POLY_N + n], b1[n]));
+                    g_ntt_inv(t);
+                }
+                for (int n = 0; n < POLY_N; n++) {
+                    /* lift to signed (|R| < 2^63 < p/2), recombine limbs mod 2^64 */
+                    u64 r0 = tt[n], r1 = tt[POLY_N + n];
+                    u64 s0 = (r0 > GP / 2) ? r0 - GP : r0; /* wraps to the signed value mod 2^64 */
+                    u64 s1 = (r1 > GP / 2) ? r1 - GP : r1;
+                    acc[col * POLY_N + n] += (s0 + (s1 << 29)) << BSK_QUANT_BITS;
+                }
+            }
+        }
+    }
+    free(rot); free(dig); free(dn); free(tt); free(res);
+}
+
+/* one PBS: in big LWE [2049], lut [2048] -> out big LWE [2049] */
+void orc_pbs(const orc_server_key *k, const u64 *in, const u64 *lut, u64 *out, int mode) {
+    u32 ms[SMALL_CT];
+    orc_keyswitch_modswitch(k, in, ms);
+    u64 *acc = (u64 *)malloc(2 * POLY_N * sizeof(u64));
+    blind_rotate(k, ms, lut, acc, mode);
+    /* sample extract, coefficient 0 */
+    out[0] = acc[0];
+    for (int j = 1; j < POLY_N; j++) out[j] = (u64)0 - acc[POLY_N - j];
+    out[BIG_N] = acc[POLY_N];
+    free(acc);
+}
+/* blind rotation only, from given mod-switched values (kernel-level tests) */
+void orc_blind_rotate(const orc_server_key *k, const u32 *ms, const u64 *lut, u64 *acc, int mode) {
+    blind_rotate(k, ms, lut, acc, mode);
+}
+
+/* ---- batched PBS over host threads (also the cpu_baseline leg) ----------- */
+typedef struct {
+    const orc_server_key *k;
+    const u64 *in; const u32 *lut_idx; const u64 *luts; u64 *out;
+    u64 B; int mode; volatile u64 *next;
+} pbs_job;
+static void *pbs_worker(void *p) {
+    pbs_job *j = (pbs_job *)p;
+    for (;;) {
+        u64 b = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
+        if (b >= j->B) break;
+        orc_pbs(j->k, j->in + b * BIG_CT, j->luts + (size_t)j->lut_idx[b] * POLY_N,
+                j->out + b * BIG_CT, j->mode);
+    }
+    return 0;
+}
+void orc_pbs_batch(const orc_server_key *k, const u64 *in, const u32 *lut_idx, const u64 *luts,
+                   u64 *out, u64 B, int nthreads, int mode) {
+    volatile u64 next = 0;
+    pbs_job job = { k, in, lut_idx, luts, out, B, mode, &next };
+    if (nthreads < 1) nthreads = 1;
+    if ((u64)nthreads > B) nthreads = (int)B;
+    if (nthreads <= 1) { pbs_worker(&job); return; }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], 0, pbs_worker, &job);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], 0);
+    free(th);
+}
+
+/* exact negacyclic product helpers exported for NTT-vs-schoolbook tests */
+void orc_negacyclic_schoolbook(const i64 *d, const u64 *b, u64 *res) {
+    memset(res, 0, POLY_N * sizeof(u64));
+    negacyclic_mac_schoolbook(d, b, res);
+}
+void orc_negacyclic_ntt(const i64 *d, const u64 *b_quantised, u64 *res) {
+    g_init_tables();
+    u64 dn[POLY_N], l0[POLY_N], l1[POLY_N];
+    const u64 lm = (1ull << 29) - 1;
+    for (int n = 0; n < POLY_N; n++) {
+        dn[n] = d[n] < 0 ? GP - (u64)(-d[n]) : (u64)d[n];
+        u64 v = b_quantised[n] >> BSK_QUANT_BITS;
+        l0[n] = v & lm; l1[n] = v >> 29;
+    }
+    g_ntt_fwd(dn); g_ntt_fwd(l0); g_ntt_fwd(l1);
+    for (int n = 0; n < POLY_N; n++) { l0[n] = g_mul(l0[n], dn[n]); l1[n] = g_mul(l1[n], dn[n]); }
+    g_ntt_inv(l0); g_ntt_inv(l1);
+    for (int n = 0; n < POLY_N; n++) {
+        u64 s0 = (l0[n] > GP / 2) ? l0[n] - GP : l0[n];
+        u64 s1 = (l1[n] > GP / 2) ? l1[n] - GP : l1[n];
+        res[n] = (s0 + (s1 << 29)) << BSK_QUANT_BITS;
+    }
+}

@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED = 0xF5E57121
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle_keys():
+    from oracle import core
+    return core.Keys(SEED)
+
+
+@pytest.fixture(scope="session")
+def oracle_sk(oracle_keys):
+    from oracle import core
+    return core.ServerKey(oracle_keys)

@@ -1,0 +1,86 @@
+"""Runs one golden vector (tests/golden/ref_tests.json) through a string-op provider.
+
+`ops` exposes the reference's MyServerKey method names; `enc_string(text, pad)`,
+`enc_pattern(text)`, `enc_char(v)` mirror MyClientKey::{encrypt, encrypt_no_padding,
+encrypt_char} (src/client_key.rs:45-87); `dec_string`, `dec_char` mirror decrypt.
+"""
+import json
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_tests.json")
+
+
+def load_vectors():
+    with open(GOLDEN) as f:
+        return json.load(f)["vectors"]
+
+
+def python_expected(v):
+    """Cross-check of the transcription with python str semantics (== Rust std here)."""
+    op, s = v["op"], v.get("string")
+    if "string_repeat" in v:
+        return None
+    p = v.get("pattern")
+    if op == "contains": return int(p in s)
+    if op == "starts_with": return int(s.startswith(p))
+    if op == "ends_with": return int(s.endswith(p))
+    if op == "to_upper": return s.upper()
+    if op == "to_lower": return s.lower()
+    if op == "repeat": return s * v["n"]
+    if op == "replace": return s.replace(v["from"], v["to"])
+    if op == "replacen": return s.replace(v["from"], v["to"], v["n"])
+    ws = " \t\n\x0b\x0c\r"
+    if op == "trim_end": return s.rstrip(ws)
+    if op == "trim_start": return s.lstrip(ws)
+    if op == "trim": return s.strip(ws)
+    if op == "is_empty": return int(s == "")
+    if op == "len": return len(s)
+    if op == "find": return s.find(p) if p in s else 255
+    if op == "rfind": return s.rfind(p) if p in s else 255
+    if op == "eq": return int(s == v["other"])
+    if op == "eq_ignore_case": return int(s.lower() == v["other"].lower())
+    if op == "concatenate": return s + v["other"]
+    if op == "lt": return int(s < v["other"])
+    if op == "le": return int(s <= v["other"])
+    if op == "gt": return int(s > v["other"])
+    if op == "ge": return int(s >= v["other"])
+    if op == "strip_prefix": return s[len(p):] if s.startswith(p) else s
+    if op == "strip_suffix": return s[:len(s) - len(p)] if s.endswith(p) else s
+    raise KeyError(op)
+
+
+def run_vector(v, ops, enc_string, enc_pattern, enc_char, dec_string, dec_char):
+    op = v["op"]
+    text = v["string"] if "string" in v else v["string_repeat"][0] * v["string_repeat"][1]
+    s = enc_string(text, v["pad"])
+    if op in ("contains", "starts_with", "ends_with", "find", "rfind"):
+        pat = enc_pattern(v["pattern"])
+        return dec_char(getattr(ops, op)(s, pat))
+    if op in ("to_upper", "to_lower", "trim_end", "trim_start", "trim"):
+        return dec_string(getattr(ops, op)(s))
+    if op in ("is_empty", "len"):
+        return dec_char(getattr(ops, op)(s))
+    if op == "repeat":
+        return dec_string(ops.repeat(s, enc_char(v["n"])))
+    if op == "replace":
+        return dec_string(ops.replace(s, enc_pattern(v["from"]), enc_pattern(v["to"])))
+    if op == "replacen":
+        return dec_string(ops.replacen(s, enc_pattern(v["from"]), enc_pattern(v["to"]), enc_char(v["n"])))
+    if op in ("eq", "eq_ignore_case", "lt", "le", "gt", "ge"):
+        o = enc_string(v["other"], v["other_pad"])
+        return dec_char(getattr(ops, op)(s, o))
+    if op == "concatenate":
+        o = enc_string(v["other"], v["other_pad"])
+        return dec_string(ops.concatenate(s, o))
+    if op in ("strip_prefix", "strip_suffix"):
+        pat = enc_string(v["pattern"], v["pattern_pad"]) if "pattern_pad" in v else enc_pattern(v["pattern"])
+        out, found = getattr(ops, op)(s, pat)
+        return dec_string(out), dec_char(found)
+    raise KeyError(op)
+
+
+def check_vector(v, got):
+    if v["op"] in ("strip_prefix", "strip_suffix"):
+        assert got == (v["expected"], v["expected_found"]), (v["name"], got)
+    else:
+        assert got == v["expected"], (v["name"], got)

@@ -1,0 +1,102 @@
+"""Pins oracle/tfhe_oracle.c: exact NTT product == schoolbook mod 2^64, and
+decrypt(PBS(enc m, f)) == f(m) (the only level the reference itself pins)."""
+import numpy as np
+import pytest
+
+from oracle import core, radix
+from oracle import strings as ostr
+from golden_util import load_vectors, run_vector, check_vector
+
+
+def test_ntt_product_is_exact():
+    rng = np.random.default_rng(7)
+    for _ in range(3):
+        d = rng.integers(-2**22, 2**22, core.POLY_N, dtype=np.int64)
+        b = rng.integers(0, 2**64, core.POLY_N, dtype=np.uint64) & np.uint64(0xFFFFFFFFFFFFFFC0)
+        assert np.array_equal(core.negacyclic_schoolbook(d, b), core.negacyclic_ntt(d, b))
+    d = np.full(core.POLY_N, -2**22, np.int64)          # worst-case magnitude
+    b = np.full(core.POLY_N, 2**64 - 64, np.uint64)
+    assert np.array_equal(core.negacyclic_schoolbook(d, b), core.negacyclic_ntt(d, b))
+
+
+def test_keygen_is_on_the_58_bit_grid(oracle_keys):
+    assert not np.any(oracle_keys.bsk & np.uint64(63))
+    q = oracle_keys.bsk.copy()
+    core.lib().orc_bsk_quantize(q, q.size)
+    assert np.array_equal(q, oracle_keys.bsk)
+
+
+def test_pbs_ntt_equals_schoolbook_bit_exact(oracle_keys, oracle_sk):
+    ct = oracle_keys.encrypt_block(6)
+    lut = core.make_lut(lambda v: (3 * v + 1) & 15)
+    assert np.array_equal(oracle_sk.pbs(ct, lut, mode=0), oracle_sk.pbs(ct, lut, mode=1))
+
+
+@pytest.mark.parametrize("name", ["msg", "carry", "eq_biv", "cmp_le"])
+def test_pbs_decrypts_to_lut_value_for_all_inputs(oracle_keys, oracle_sk, name):
+    lut = radix.lut_poly(name)
+    cts = np.stack([oracle_keys.encrypt_block(m) for m in range(16)])
+    outs = oracle_sk.pbs_batch(cts, np.zeros(16, np.uint32), lut[None])
+    for m in range(16):
+        assert oracle_keys.decrypt_block(outs[m]) == radix.LUTS[name](m)
+
+
+def test_negacyclic_padding_bit_rule(oracle_keys, oracle_sk):
+    # an input with the padding bit set (v+16) yields -f(v): what lt/le/gt/ge rely on
+    lut = radix.lut_poly("sign")
+    cts = np.stack([oracle_keys.encrypt_block(m) for m in (0, 3, 16 + 9, 31)])
+    outs = oracle_sk.pbs_batch(cts, np.zeros(4, np.uint32), lut[None])
+    assert [oracle_keys.decrypt_block(o) for o in outs] == [0, 1, 31, 31]
+
+
+def test_pbs_output_noise_is_small(oracle_keys, oracle_sk):
+    lut = radix.lut_poly("msg")
+    cts = np.stack([oracle_keys.encrypt_block(2) for _ in range(8)])
+    outs = oracle_sk.pbs_batch(cts, np.zeros(8, np.uint32), lut[None])
+    errs = []
+    for o in outs:
+        e = (oracle_keys.phase(o) - (2 << core.DELTA_LOG)) & (2**64 - 1)
+        errs.append(e - 2**64 if e >= 2**63 else e)
+    assert max(abs(e) for e in errs) < 2**53     # budget before the next KS is 2^58
+
+
+def _cipher_env(keys, sk):
+    eng = radix.Engine(sk)
+    ops = ostr.Ops(radix.CipherChar, eng)
+    enc_c = lambda v: radix.CipherChar.from_cts(keys.encrypt_char(v), eng)
+    enc_s = lambda t, pad: [enc_c(b) for b in ostr.pad_plain(t, pad)]
+    enc_p = lambda t: [enc_c(b) for b in ostr.pad_plain(t, 0)]
+    dec_c = lambda c: keys.decrypt_char(c.cts())
+    dec_s = lambda s: ostr.truncate_plain([dec_c(c) for c in s])
+    return eng, (ops, enc_s, enc_p, enc_c, dec_s, dec_c)
+
+
+def test_char_ops_decrypt_like_u8(oracle_keys, oracle_sk):
+    """All 13 boundary ops of fheasciichar.rs on a few operand pairs, one lazy batch."""
+    eng, _ = _cipher_env(oracle_keys, oracle_sk)
+    pairs = [(0x61, 0x7A), (0x00, 0xFF), (0xC3, 0xC3), (0x80, 0x7F)]
+    results = []
+    for a, b in pairs:
+        ca = radix.CipherChar.from_cts(oracle_keys.encrypt_char(a), eng)
+        cb = radix.CipherChar.from_cts(oracle_keys.encrypt_char(b), eng)
+        tb = radix.CipherChar.trivial(b, eng)
+        results += [
+            (ca.eq(cb), int(a == b)), (ca.ne(cb), int(a != b)), (ca.eq(tb), int(a == b)),
+            (ca.lt(cb), int(a < b)), (ca.le(cb), int(a <= b)), (ca.gt(cb), int(a > b)),
+            (ca.ge(cb), int(a >= b)), (ca.le(tb), int(a <= b)),
+            (ca.bitand(cb), a & b), (ca.bitor(cb), a | b),
+            (ca.add(cb), (a + b) & 255), (ca.sub(cb), (a - b) & 255),
+            (ca.eq(cb).flip(), int(a != b)),
+            (ca.if_then_else(cb, ca), b if a else a), (ca.ne(cb).if_then_else(ca, cb), a if a != b else b),
+        ]
+    eng.materialize([blk for ch, _ in results for blk in ch.b])
+    for ch, exp in results:
+        assert oracle_keys.decrypt_char(ch.cts()) == exp
+    assert eng.levels <= 12
+
+
+def test_cipher_model_golden_less_than(oracle_keys, oracle_sk):
+    """One encrypted end-to-end golden vector on the CPU oracle (src/main.rs:819)."""
+    v = [x for x in load_vectors() if x["name"] == "less_than"][0]
+    eng, env = _cipher_env(oracle_keys, oracle_sk)
+    check_vector(v, run_vector(v, *env))
