@@ -1,0 +1,76 @@
+// extern "C" boundary, part 1: context, server key, raw batched PBS (include/fhestring_hip.h).
+#include "../../include/fhestring_hip.h"
+#include "engine.h"
+
+using fhs::Engine;
+
+struct fhs_ctx {
+    Engine eng;
+};
+
+extern "C" {
+
+int fhs_ctx_create(int device_id, fhs_ctx **out) {
+    if (!out) return FHS_ERR_ARG;
+    *out = nullptr;
+    fhs_ctx *c = new (std::nothrow) fhs_ctx();
+    if (!c) return FHS_ERR_STATE;
+    int rc = c->eng.ctx.init(device_id);
+    if (rc) {
+        // keep the object alive so the caller can read the error text
+        *out = c;
+        return rc;
+    }
+    *out = c;
+    return FHS_OK;
+}
+
+void fhs_ctx_destroy(fhs_ctx *ctx) {
+    if (!ctx) return;
+    ctx->eng.shutdown();
+    delete ctx;
+}
+
+const char *fhs_last_error(const fhs_ctx *ctx) { return ctx ? ctx->eng.ctx.err.c_str() : "null context"; }
+
+int fhs_load_server_key(fhs_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) {
+    if (!ctx) return FHS_ERR_ARG;
+    int rc = ctx->eng.ctx.load_server_key(bsk, ksk);
+    if (rc) return rc;
+    return ctx->eng.on_key_loaded();
+}
+
+int fhs_pbs_batch(fhs_ctx *ctx, const uint64_t *in, const uint32_t *lut_idx, const uint64_t *luts,
+                  size_t n_luts, uint64_t *out, size_t B) {
+    if (!ctx) return FHS_ERR_ARG;
+    return ctx->eng.ctx.pbs_batch_host(in, lut_idx, luts, n_luts, out, B);
+}
+
+int fhs_keyswitch_modswitch_batch(fhs_ctx *ctx, const uint64_t *in, uint32_t *ms_out, size_t B) {
+    if (!ctx) return FHS_ERR_ARG;
+    return ctx->eng.ctx.ks_ms_batch_host(in, ms_out, B);
+}
+
+int fhs_pbs_batch_device(fhs_ctx *ctx, const uint64_t *d_in, const uint32_t *d_lut_idx, const uint64_t *d_luts,
+                         uint64_t *d_out, size_t B, void *hip_stream) {
+    if (!ctx) return FHS_ERR_ARG;
+    if (!d_in || !d_lut_idx || !d_luts || !d_out) return ctx->eng.ctx.fail(FHS_ERR_ARG, "null device pointer");
+    return ctx->eng.ctx.pbs_batch_device(d_in, d_lut_idx, d_luts, d_out, B,
+                                         hip_stream ? (hipStream_t)hip_stream : ctx->eng.ctx.stream);
+}
+
+int fhs_kernel_timing(fhs_ctx *ctx, int reset, double *blind_rotate_ms, double *keyswitch_ms,
+                      uint64_t *n_blind_rotate, uint64_t *n_keyswitch, uint64_t *pbs_in_launches) {
+    if (!ctx) return FHS_ERR_ARG;
+    auto &t = ctx->eng.ctx.timer;
+    t.resolve();
+    if (blind_rotate_ms) *blind_rotate_ms = t.n[0] ? t.ms[0] / (double)t.n[0] : 0.0;
+    if (keyswitch_ms) *keyswitch_ms = t.n[1] ? t.ms[1] / (double)t.n[1] : 0.0;
+    if (n_blind_rotate) *n_blind_rotate = t.n[0];
+    if (n_keyswitch) *n_keyswitch = t.n[1];
+    if (pbs_in_launches) *pbs_in_launches = t.units[0];
+    if (reset) t.reset();
+    return FHS_OK;
+}
+
+}  // extern "C"

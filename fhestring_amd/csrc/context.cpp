@@ -1,0 +1,212 @@
+#include "context.h"
+
+#include <algorithm>
+#include <thread>
+
+namespace fhs {
+
+#define HIP_TRY(expr, what)                                \
+    do {                                                   \
+        hipError_t e__ = (expr);                           \
+        if (e__ != hipSuccess) return hip_fail(e__, what); \
+    } while (0)
+
+hipError_t DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    size_t want = std::max(bytes, (size_t)1 << 20);
+    hipError_t e = hipMalloc(&ptr, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+}
+void DevBuf::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+}
+
+hipEvent_t KernelTimer::get() {
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void KernelTimer::begin(int kind, uint64_t u, hipStream_t s) {
+    if (!enabled) return;
+    if (pending.size() > 4096) resolve();
+    Pending p{get(), get(), kind, u};
+    (void)hipEventRecord(p.e0, s);
+    pending.push_back(p);
+}
+void KernelTimer::end(hipStream_t s) {
+    if (!enabled || pending.empty()) return;
+    (void)hipEventRecord(pending.back().e1, s);
+}
+void KernelTimer::resolve() {
+    for (auto &p : pending) {
+        (void)hipEventSynchronize(p.e1);
+        float t = 0;
+        if (hipEventElapsedTime(&t, p.e0, p.e1) == hipSuccess) {
+            ms[p.kind] += t;
+            n[p.kind] += 1;
+            units[p.kind] += p.units;
+        }
+        pool.push_back(p.e0);
+        pool.push_back(p.e1);
+    }
+    pending.clear();
+}
+void KernelTimer::reset() {
+    resolve();
+    ms[0] = ms[1] = 0;
+    n[0] = n[1] = 0;
+    units[0] = units[1] = 0;
+}
+void KernelTimer::destroy() {
+    resolve();
+    for (auto e : pool) (void)hipEventDestroy(e);
+    pool.clear();
+}
+
+int Context::hip_fail(hipError_t e, const char *what) {
+    err = std::string(what) + ": " + hipGetErrorString(e);
+    return -2;
+}
+
+int Context::init(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(-2, "no HIP device visible: this backend has no CPU fallback");
+    if (device_id < 0 || device_id >= n) return fail(-1, "device_id out of range");
+    device = device_id;
+    HIP_TRY(hipSetDevice(device), "hipSetDevice");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(-2, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+    return 0;
+}
+
+void Context::shutdown() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    timer.destroy();
+    ms_buf.release();
+    in_buf.release();
+    out_buf.release();
+    lutidx_buf.release();
+    luts_buf.release();
+    if (d_ksk) (void)hipFree(d_ksk);
+    if (d_bsk_ntt) (void)hipFree(d_bsk_ntt);
+    if (d_tables) (void)hipFree(d_tables);
+    d_ksk = nullptr;
+    d_bsk_ntt = nullptr;
+    d_tables = nullptr;
+    if (stream) (void)hipStreamDestroy(stream);
+    stream = nullptr;
+}
+
+int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
+    if (!bsk || !ksk) return fail(-1, "null key pointer");
+    HIP_TRY(hipSetDevice(device), "hipSetDevice");
+    const size_t ksk_bytes = (size_t)BIG_N * KS_LEVEL * SMALL_CT * sizeof(uint64_t);
+    const size_t bsk_ntt_doubles = (size_t)LWE_N * 4 * 2 * POLY_N;
+    if (!d_ksk) HIP_TRY(hipMalloc(&d_ksk, ksk_bytes), "hipMalloc ksk");
+    if (!d_bsk_ntt) HIP_TRY(hipMalloc(&d_bsk_ntt, bsk_ntt_doubles * sizeof(double)), "hipMalloc bsk");
+    HIP_TRY(hipMemcpy(d_ksk, ksk, ksk_bytes, hipMemcpyHostToDevice), "copy ksk");
+    {
+        std::vector<double> host(bsk_ntt_doubles);
+        unsigned hc = std::thread::hardware_concurrency();
+        convert_bsk_to_ntt(bsk, host.data(), (int)std::min(32u, std::max(1u, hc)));
+        HIP_TRY(hipMemcpy(d_bsk_ntt, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice),
+                "copy bsk");
+    }
+    HostNttTables ht;
+    build_ntt_tables(ht);
+    const size_t n_tab = ht.fwd_uni.size() + ht.fwd_lane.size() + ht.inv_uni.size() + ht.inv_lane.size();
+    if (!d_tables) HIP_TRY(hipMalloc(&d_tables, n_tab * sizeof(double)), "hipMalloc tables");
+    double *pd = d_tables;
+    auto up = [&](const std::vector<double> &v, const double *&slot) -> hipError_t {
+        slot = pd;
+        hipError_t e = hipMemcpy(pd, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
+        pd += v.size();
+        return e;
+    };
+    HIP_TRY(up(ht.fwd_uni, tw.fwd_uni), "copy tables");
+    HIP_TRY(up(ht.fwd_lane, tw.fwd_lane), "copy tables");
+    HIP_TRY(up(ht.inv_uni, tw.inv_uni), "copy tables");
+    HIP_TRY(up(ht.inv_lane, tw.inv_lane), "copy tables");
+    crt_c = ht.crt_c;
+    key_loaded = true;
+    return 0;
+}
+
+int Context::pbs_batch_device(const uint64_t *d_in, const uint32_t *d_lut_idx, const uint64_t *d_luts,
+                              uint64_t *d_out, size_t B, hipStream_t s) {
+    if (!key_loaded) return fail(-3, "server key not loaded");
+    if (B == 0) return 0;
+    if (B > (size_t)1 << 24) return fail(-1, "batch too large");
+    HIP_TRY(ms_buf.reserve(B * SMALL_CT * sizeof(uint32_t)), "hipMalloc ms");
+    timer.begin(1, B, s);
+    HIP_TRY(launch_keyswitch_modswitch(d_in, d_ksk, ms_buf.as<uint32_t>(), (int)B, s), "keyswitch launch");
+    timer.end(s);
+    BlindRotateParams p{};
+    p.ms = ms_buf.as<uint32_t>();
+    p.lut_idx = d_lut_idx;
+    p.luts = d_luts;
+    p.bsk_ntt = d_bsk_ntt;
+    p.tw = tw;
+    p.crt_c = crt_c;
+    p.out = d_out;
+    p.B = (int)B;
+    timer.begin(0, B, s);
+    HIP_TRY(launch_blind_rotate(p, s), "blind_rotate launch");
+    timer.end(s);
+    return 0;
+}
+
+int Context::pbs_batch_host(const uint64_t *in, const uint32_t *lut_idx, const uint64_t *luts, size_t n_luts,
+                            uint64_t *out, size_t B) {
+    if (!in || !lut_idx || !luts || !out) return fail(-1, "null pointer");
+    if (B == 0) return 0;
+    for (size_t b = 0; b < B; b++)
+        if (lut_idx[b] >= n_luts) return fail(-1, "lut_idx out of range");
+    HIP_TRY(hipSetDevice(device), "hipSetDevice");
+    HIP_TRY(in_buf.reserve(B * BIG_CT * 8), "hipMalloc");
+    HIP_TRY(out_buf.reserve(B * BIG_CT * 8), "hipMalloc");
+    HIP_TRY(lutidx_buf.reserve(B * 4), "hipMalloc");
+    HIP_TRY(luts_buf.reserve(n_luts * POLY_N * 8), "hipMalloc");
+    HIP_TRY(hipMemcpyAsync(in_buf.ptr, in, B * BIG_CT * 8, hipMemcpyHostToDevice, stream), "H2D");
+    HIP_TRY(hipMemcpyAsync(lutidx_buf.ptr, lut_idx, B * 4, hipMemcpyHostToDevice, stream), "H2D");
+    HIP_TRY(hipMemcpyAsync(luts_buf.ptr, luts, n_luts * POLY_N * 8, hipMemcpyHostToDevice, stream), "H2D");
+    int rc = pbs_batch_device(in_buf.as<uint64_t>(), lutidx_buf.as<uint32_t>(), luts_buf.as<uint64_t>(),
+                              out_buf.as<uint64_t>(), B, stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, out_buf.ptr, B * BIG_CT * 8, hipMemcpyDeviceToHost, stream), "D2H");
+    HIP_TRY(hipStreamSynchronize(stream), "sync");
+    return 0;
+}
+
+int Context::ks_ms_batch_host(const uint64_t *in, uint32_t *ms_out, size_t B) {
+    if (!key_loaded) return fail(-3, "server key not loaded");
+    if (!in || !ms_out) return fail(-1, "null pointer");
+    if (B == 0) return 0;
+    HIP_TRY(hipSetDevice(device), "hipSetDevice");
+    HIP_TRY(in_buf.reserve(B * BIG_CT * 8), "hipMalloc");
+    HIP_TRY(ms_buf.reserve(B * SMALL_CT * 4), "hipMalloc");
+    HIP_TRY(hipMemcpyAsync(in_buf.ptr, in, B * BIG_CT * 8, hipMemcpyHostToDevice, stream), "H2D");
+    HIP_TRY(launch_keyswitch_modswitch(in_buf.as<uint64_t>(), d_ksk, ms_buf.as<uint32_t>(), (int)B, stream),
+            "keyswitch launch");
+    HIP_TRY(hipMemcpyAsync(ms_out, ms_buf.ptr, B * SMALL_CT * 4, hipMemcpyDeviceToHost, stream), "D2H");
+    HIP_TRY(hipStreamSynchronize(stream), "sync");
+    return 0;
+}
+
+}  // namespace fhs

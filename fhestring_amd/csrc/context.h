@@ -1,0 +1,72 @@
+// Host runtime: device context, key material, batched-PBS dispatch, kernel timing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "ntt_tables.h"
+#include "pbs_kernels.h"
+
+namespace fhs {
+
+// grow-only device buffer
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes);
+    void release();
+    template <class T> T *as() const { return reinterpret_cast<T *>(ptr); }
+};
+
+// HIP-event timing of the two PBS kernels on the stream they are launched on
+struct KernelTimer {
+    struct Pending { hipEvent_t e0, e1; int kind; uint64_t units; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[2] = {0, 0};        // 0 = blind rotation, 1 = keyswitch
+    uint64_t n[2] = {0, 0};
+    uint64_t units[2] = {0, 0};   // PBS covered by the timed launches
+    bool enabled = true;
+    hipEvent_t get();
+    void begin(int kind, uint64_t units, hipStream_t s);
+    void end(hipStream_t s);
+    void resolve();   // synchronises pending events and accumulates
+    void reset();
+    void destroy();
+};
+
+class Context {
+  public:
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool key_loaded = false;
+
+    // key material on device
+    uint64_t *d_ksk = nullptr;
+    double *d_bsk_ntt = nullptr;
+    double *d_tables = nullptr;   // fwd_uni | fwd_lane | inv_uni | inv_lane
+    NttTables tw{};
+    double crt_c = 0;
+
+    // scratch
+    DevBuf ms_buf, in_buf, out_buf, lutidx_buf, luts_buf;
+    KernelTimer timer;
+
+    int init(int device_id);
+    void shutdown();
+    int fail(int code, const std::string &msg) { err = msg; return code; }
+    int hip_fail(hipError_t e, const char *what);
+
+    int load_server_key(const uint64_t *bsk, const uint64_t *ksk);
+    // all device pointers; enqueues KS+MS then blind rotation on `s`
+    int pbs_batch_device(const uint64_t *d_in, const uint32_t *d_lut_idx, const uint64_t *d_luts,
+                         uint64_t *d_out, size_t B, hipStream_t s);
+    int pbs_batch_host(const uint64_t *in, const uint32_t *lut_idx, const uint64_t *luts, size_t n_luts,
+                       uint64_t *out, size_t B);
+    int ks_ms_batch_host(const uint64_t *in, uint32_t *ms_out, size_t B);
+};
+
+}  // namespace fhs

@@ -1,0 +1,68 @@
+// Device kernels of the batched programmable bootstrap (gfx950 only).
+// Replaces tfhe::shortint's keyswitch -> modulus switch -> blind rotation -> sample extract
+// (SURVEY.md 3.3 / Appendix A), reached by the reference from src/ciphertext/fheasciichar.rs:36-102.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace fhs {
+
+constexpr int LWE_N = 742;
+constexpr int POLY_N = 2048;
+constexpr int BIG_N = 2048;
+constexpr int BIG_CT = 2049;
+constexpr int SMALL_CT = 743;
+constexpr int KS_LEVEL = 5;
+constexpr int KS_BASE_LOG = 3;
+constexpr int DELTA_LOG = 59;
+constexpr int BSK_QUANT_BITS = 6;
+
+// NTT primes: the two largest p < 2^47 with p = 1 (mod 4096).  p0*p1 > 2^93 bounds the exact
+// integer result of one external product on the 58-bit key grid (|x| <= 2^91).
+constexpr uint64_t NTT_P0 = 140737488273409ull;  // 0x7ffffffec001
+constexpr uint64_t NTT_P1 = 140737488252929ull;  // 0x7ffffffe7001
+constexpr uint64_t NTT_PSI0 = 124135596386681ull;  // primitive 4096-th roots
+constexpr uint64_t NTT_PSI1 = 116052249937262ull;
+
+// Twiddle tables (doubles holding exact centred residues), see ntt_tables.cpp.
+struct NttTables {
+    const double *fwd_uni;   // [2 primes][32]      Psi[1..31]           (lane-uniform stages)
+    const double *fwd_lane;  // [2][32 entries][64] per-lane stages t=32..1
+    const double *inv_uni;   // [2][64]             PsiInv[1..63]        (t=32 stage + uniform stages)
+    const double *inv_lane;  // [2][32][64]         per-lane stages t=1..16 (entry 0 unused)
+};
+
+struct BlindRotateParams {
+    const uint32_t *ms;       // [B][743] mod-switched small LWE, values in [0,4096)
+    const uint32_t *lut_idx;  // [B]
+    const uint64_t *luts;     // [L][2048]
+    const double *bsk_ntt;    // [742][row 2][col 2][prime 2][32][64], pre-scaled by N^-1
+    NttTables tw;
+    double crt_c;             // p0^-1 mod p1, centred
+    uint64_t *out;            // [B][2049]
+    int B;
+};
+
+// One lincomb output: out[dst] = sum_t coef[t] * src[t] + konst * 2^59 (body only)
+struct LinDesc {
+    uint32_t first_term;
+    uint32_t n_terms;
+    uint64_t konst_body;      // already shifted: (k mod 32) << 59
+};
+struct LinTerm {
+    const uint64_t *src;      // device block
+    int64_t coef;
+};
+
+size_t blind_rotate_lds_bytes();
+hipError_t launch_blind_rotate(const BlindRotateParams &p, hipStream_t s);
+hipError_t launch_keyswitch_modswitch(const uint64_t *d_in /*[B][2049]*/, const uint64_t *d_ksk,
+                                      uint32_t *d_ms /*[B][743]*/, int B, hipStream_t s);
+hipError_t launch_lincomb(const LinDesc *d_desc, const LinTerm *d_terms, uint64_t *d_out /*[n][2049]*/,
+                          int n, hipStream_t s);
+// gathers scattered blocks into a dense batch: out[i] = *src[i]
+hipError_t launch_gather_blocks(const uint64_t *const *d_src, uint64_t *d_out, int n, hipStream_t s);
+hipError_t launch_scatter_blocks(const uint64_t *d_in, uint64_t *const *d_dst, int n, hipStream_t s);
+
+}  // namespace fhs

@@ -1,0 +1,422 @@
+// Hand-written HIP kernels for gfx950 (MI355X): batched TFHE programmable bootstrap.
+//
+// Blind rotation = 742 sequential CMUXes, each a GGSW x GLWE external product over
+// Z_{2^64}[X]/(X^2048+1).  The negacyclic products are computed
+// EXACTLY with a number-theoretic transform over two 47-bit primes whose residues are carried
+// in FP64 registers: a*b mod p = fma-split product + one rounded quotient (6 VALU ops, no carry
+// chains), add/sub are single v_add_f64 with lazy ranges.  On gfx950 v_fma_f64 issues at the
+// same rate as v_mad_u64_u32 / v_addc_co_u32 (tools/ubench_valu.hip), so this needs ~3x fewer
+// issue cycles than a 64-bit integer (Goldilocks) NTT.  No MFMA: this is torus arithmetic.
+//
+// Mapping: one workgroup (4 wavefronts) per ciphertext; wavefront (j,q) owns GLWE polynomial j
+// modulo prime q.  A 2048-point NTT lives in one wavefront's registers (32 coefficients/lane):
+// 5 radix-2 stages in the "strided" layout (lane = n mod 64), one transpose through LDS with the
+// only cross-lane stage (t=32) fused into the transposed read, 5 stages in the "contiguous"
+// layout (lane = n div 32).  The accumulator stays in registers for all 742 iterations.
+#include "pbs_kernels.h"
+
+namespace fhs {
+
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------------------------------
+// exact modular arithmetic in FP64 (all values are integers with |x| < 2^52)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double mulmod(double a, double w, double p, double pinv) {
+    double h = a * w;
+    double l = __builtin_fma(a, w, -h);      // a*w == h + l exactly
+    double q = __builtin_rint(h * pinv);
+    double r = __builtin_fma(-q, p, h);      // exact: |h - q*p| < 2^52 and integral
+    return r + l;                            // |result| <= p*(1/2 + |a|*2^-53)
+}
+__device__ __forceinline__ double reduce_once(double a, double p, double pinv) {
+    double q = __builtin_rint(a * pinv);
+    return __builtin_fma(-q, p, a);
+}
+
+// LDS layout used by the transposes: 8-byte slot of coefficient n, padded by 2 slots per 32 so
+// that both the strided (lane = n mod 64) and the contiguous (lane = n div 32) access patterns
+// are bank-conflict free with ds_read_b128 / ds_write_b128.
+__device__ __forceinline__ int pad_slot(int n) { return n + 2 * (n >> 5); }
+constexpr int LDS_WAVE_SLOTS = POLY_N + 2 * (POLY_N / 32);   // 2176 doubles = 17 408 B per wave
+
+// ---- forward negacyclic NTT (Cooley-Tukey, merged psi powers, bit-reversed twiddle table) ----
+// in : x[r] = coefficient (lane + 64 r)              (strided layout, natural order)
+// out: x[c] = transform value at array index 32*lane + c (contiguous layout, CT output order)
+__device__ __forceinline__ void ntt_forward(double (&x)[32], double *lds, int lane,
+                                            const double *__restrict__ uni,   // uniform: Psi[1..31]
+                                            const double *__restrict__ lanetw, // [32][64]
+                                            double p, double pinv) {
+    // stages t = 1024..64: a 32-point CT on the register index, lane-uniform twiddles
+#pragma unroll
+    for (int T = 16; T >= 1; T >>= 1) {
+        const int m = 16 / T;
+#pragma unroll
+        for (int i = 0; i < m; i++) {
+            const double w = uni[m + i];
+#pragma unroll
+            for (int r = 2 * i * T; r < 2 * i * T + T; r++) {
+                double v = mulmod(x[r + T], w, p, pinv);
+                x[r + T] = x[r] - v;
+                x[r] = x[r] + v;
+            }
+        }
+    }
+    // transpose strided -> contiguous through LDS
+#pragma unroll
+    for (int r = 0; r < 32; r++) lds[pad_slot(lane + 64 * r)] = x[r];
+    __builtin_amdgcn_wave_barrier();
+    // stage t = 32 fused into the read: lanes (2k, 2k+1) share one 64-coefficient group
+    {
+        const double w = lanetw[0 * 64 + lane];           // Psi[32 + lane/2]
+        const double sgn = (lane & 1) ? -1.0 : 1.0;
+        const double *lo = lds + pad_slot(32 * (lane & ~1));
+        const double *hi = lds + pad_slot(32 * (lane | 1));
+#pragma unroll
+        for (int c = 0; c < 32; c++) {
+            double v = mulmod(hi[c], w, p, pinv);
+            x[c] = __builtin_fma(v, sgn, lo[c]);          // even lane: lo + v, odd lane: lo - v
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // stages t = 16..1: in-lane, per-lane twiddles
+#pragma unroll
+    for (int t = 16; t >= 1; t >>= 1) {
+        const int G = 16 / t;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const double w = lanetw[(G + g) * 64 + lane];   // Psi[64G + G*lane + g]
+#pragma unroll
+            for (int c = 2 * g * t; c < 2 * g * t + t; c++) {
+                double v = mulmod(x[c + t], w, p, pinv);
+                x[c + t] = x[c] - v;
+                x[c] = x[c] + v;
+            }
+        }
+    }
+}
+
+// ---- inverse negacyclic NTT (Gentleman-Sande), 1/N folded into the key ----
+// in : x[c] at array index 32*lane + c (contiguous layout), |x| <= 1.5 p
+// out: x[r] = coefficient (lane + 64 r) (strided layout), |x| <= 4.1 p, congruent mod p
+__device__ __forceinline__ void ntt_inverse(double (&x)[32], double *lds, int lane,
+                                            const double *__restrict__ uni,    // PsiInv[1..63]
+                                            const double *__restrict__ lanetw,  // [32][64]
+                                            double p, double pinv) {
+#pragma unroll
+    for (int t = 1; t <= 16; t <<= 1) {
+        const int G = 16 / t;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const double w = lanetw[(G + g) * 64 + lane];
+#pragma unroll
+            for (int c = 2 * g * t; c < 2 * g * t + t; c++) {
+                double u = x[c], v = x[c + t];
+                x[c] = u + v;
+                x[c + t] = mulmod(u - v, w, p, pinv);
+            }
+        }
+        if (t == 8) {   // magnitudes reached 24 p: bring everything back below p
+#pragma unroll
+            for (int c = 0; c < 32; c++) x[c] = reduce_once(x[c], p, pinv);
+        }
+    }
+    // transpose contiguous -> strided, stage t = 32 fused into the read
+#pragma unroll
+    for (int c = 0; c < 32; c++) lds[pad_slot(32 * lane) + c] = x[c];
+    __builtin_amdgcn_wave_barrier();
+    {
+        const bool upper = lane >= 32;
+        const int l5 = lane & 31;
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            double a = lds[pad_slot(l5 + 64 * r)];
+            double b = lds[pad_slot(l5 + 32 + 64 * r)];
+            double s = a + b;
+            double d = mulmod(a - b, uni[32 + r], p, pinv);
+            x[r] = upper ? d : s;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // stages t = 64..1024 on the register index, lane-uniform twiddles
+#pragma unroll
+    for (int T = 1; T <= 16; T <<= 1) {
+        const int h = 16 / T;
+#pragma unroll
+        for (int i = 0; i < h; i++) {
+            const double w = uni[h + i];
+#pragma unroll
+            for (int r = 2 * i * T; r < 2 * i * T + T; r++) {
+                double u = x[r], v = x[r + T];
+                x[r] = u + v;
+                x[r + T] = mulmod(u - v, w, p, pinv);
+            }
+        }
+        if (T == 2) {   // second range reset (8 stages since the first)
+#pragma unroll
+            for (int r = 0; r < 32; r++) x[r] = reduce_once(x[r], p, pinv);
+        }
+    }
+}
+
+__device__ __forceinline__ int64_t f64_to_i64_exact(double v) {   // |v| < 2^51, integral
+    const double M = 6755399441055744.0;                            // 1.5 * 2^52
+    return (int64_t)(__builtin_bit_cast(uint64_t, v + M) - __builtin_bit_cast(uint64_t, M));
+}
+
+// ------------------------------------------------------------------------------------------
+// blind rotation + sample extract: grid = B workgroups, block = 256 threads (4 wavefronts)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ct = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = wave >> 1;   // GLWE polynomial (0 mask, 1 body)
+    const int q = wave & 1;    // prime
+    double *my = reinterpret_cast<double *>(smem) + wave * LDS_WAVE_SLOTS;
+    const double *partner = reinterpret_cast<double *>(smem) + (wave ^ 2) * LDS_WAVE_SLOTS;  // other poly
+    const double *sibling = reinterpret_cast<double *>(smem) + (wave ^ 1) * LDS_WAVE_SLOTS;  // other prime
+    uint64_t *my_u = reinterpret_cast<uint64_t *>(my);
+
+    const double p = q ? (double)NTT_P1 : (double)NTT_P0;
+    const double pinv = 1.0 / p;
+    const double p1 = (double)NTT_P1, p1inv = 1.0 / p1;
+    const double crt_c = P.crt_c;                     // p0^-1 mod p1, centred
+
+    const uint32_t *ms = P.ms + (size_t)ct * SMALL_CT;
+    const double *fwd_uni = P.tw.fwd_uni + q * 32;
+    const double *fwd_lane = P.tw.fwd_lane + q * 32 * 64;
+    const double *inv_uni = P.tw.inv_uni + q * 64;
+    const double *inv_lane = P.tw.inv_lane + q * 32 * 64;
+
+    // acc[r] = coefficient (lane + 64 r) of GLWE polynomial j, u64 torus
+    uint64_t acc[32];
+    {
+        const uint32_t b = ms[LWE_N];
+        const uint32_t a = (2 * POLY_N - b) & (2 * POLY_N - 1);     // X^{-b} = X^{2N-b}
+        const uint32_t s = a & (POLY_N - 1);
+        const bool neg = a >= POLY_N;
+        const uint64_t *lut = P.luts + (size_t)P.lut_idx[ct] * POLY_N;
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            uint64_t v = 0;
+            if (j == 1) {
+                const uint32_t n = lane + 64 * r;
+                v = (n >= s) ? lut[n - s] : (uint64_t)0 - lut[n - s + POLY_N];
+                if (neg) v = (uint64_t)0 - v;
+            }
+            acc[r] = v;
+        }
+    }
+
+    for (int i = 0; i < LWE_N; i++) {
+        const uint32_t a = ms[i];
+        if (a == 0) continue;   // X^0*acc - acc == 0: exact no-op (uniform for the workgroup)
+        const uint32_t s = a & (POLY_N - 1);
+        const bool neg = a >= POLY_N;
+
+        // ---- rotate, subtract, decompose (closest multiple of 2^41 -> signed 23-bit digit) ----
+        double x[32];
+#pragma unroll
+        for (int r = 0; r < 32; r++) my_u[lane + 64 * r] = acc[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            const uint32_t n = lane + 64 * r;
+            const bool wrap = n < s;
+            uint64_t v = my_u[wrap ? n - s + POLY_N : n - s];
+            if (wrap != neg) v = (uint64_t)0 - v;
+            const uint64_t d = v - acc[r];
+            const int32_t dig = (int32_t)((uint32_t)(d >> 32) + 0x100u) >> 9;
+            x[r] = (double)dig;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        ntt_forward(x, my, lane, fwd_uni, fwd_lane, p, pinv);
+
+        // ---- publish, pointwise multiply-accumulate with GGSW_i ----
+#pragma unroll
+        for (int c = 0; c < 32; c++) my[c * 64 + lane] = x[c];
+        __syncthreads();
+        {
+            // rows: 0 multiplies the mask digit polynomial, 1 the body digit polynomial
+            const double *b_own = P.bsk_ntt + ((((size_t)i * 2 + j) * 2 + j) * 2 + q) * POLY_N + lane;
+            const double *b_par = P.bsk_ntt + ((((size_t)i * 2 + (1 - j)) * 2 + j) * 2 + q) * POLY_N + lane;
+#pragma unroll
+            for (int c = 0; c < 32; c++) {
+                const double o = partner[c * 64 + lane];
+                x[c] = mulmod(x[c], b_own[c * 64], p, pinv) + mulmod(o, b_par[c * 64], p, pinv);
+            }
+        }
+        __syncthreads();
+
+        ntt_inverse(x, my, lane, inv_uni, inv_lane, p, pinv);
+
+        // ---- CRT of the two residues, accumulate ----
+#pragma unroll
+        for (int r = 0; r < 32; r++) my[r * 64 + lane] = x[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            const double o = sibling[r * 64 + lane];
+            const double r0 = q ? o : x[r];
+            const double r1 = q ? x[r] : o;
+            const double t = mulmod(r1 - r0, crt_c, p1, p1inv);
+            const uint64_t v = (uint64_t)f64_to_i64_exact(r0) + NTT_P0 * (uint64_t)f64_to_i64_exact(t);
+            acc[r] += v << BSK_QUANT_BITS;
+        }
+        __syncthreads();
+    }
+
+    // ---- sample extract (coefficient 0): a'[0] = A[0], a'[n] = -A[N-n], b' = B[0] ----
+    uint64_t *out = P.out + (size_t)ct * BIG_CT;
+    if (q == 0) {
+        if (j == 0) {
+#pragma unroll
+            for (int r = 0; r < 32; r++) {
+                const int n = lane + 64 * r;
+                if (n == 0) out[0] = acc[r];
+                else out[POLY_N - n] = (uint64_t)0 - acc[r];
+            }
+        } else if (lane == 0) {
+            out[BIG_N] = acc[0];
+        }
+    }
+}
+
+size_t blind_rotate_lds_bytes() { return (size_t)4 * LDS_WAVE_SLOTS * sizeof(double); }
+
+hipError_t launch_blind_rotate(const BlindRotateParams &p, hipStream_t s) {
+    if (p.B <= 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(blind_rotate_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)blind_rotate_lds_bytes());
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(blind_rotate_kernel, dim3(p.B), dim3(256), blind_rotate_lds_bytes(), s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// keyswitch (big key -> small key) + modulus switch to Z_4096
+// out[ct][j] = round_12( b*[j==742] - sum_{i,l} d(ct,i,l) * KSK[i][l][j] )
+// block = 256 threads: one output column per thread, KS_CT_TILE ciphertexts per workgroup so a
+// KSK row streamed from L2/HBM is reused KS_CT_TILE times; digits staged in LDS.
+// ------------------------------------------------------------------------------------------
+constexpr int KS_CT_TILE = 8;
+constexpr int KS_COLS = 256;
+
+__global__ __launch_bounds__(256) void keyswitch_modswitch_kernel(const uint64_t *__restrict__ in,
+                                                                  const uint64_t *__restrict__ ksk,
+                                                                  uint32_t *__restrict__ ms, int B) {
+    __shared__ uint16_t digs[KS_CT_TILE][BIG_N];   // 5 balanced base-8 digits, 3 bits each (biased +4)
+    const int ct0 = blockIdx.x * KS_CT_TILE;
+    const int col = blockIdx.y * KS_COLS + threadIdx.x;
+    const int nct = min(KS_CT_TILE, B - ct0);
+    for (int e = threadIdx.x; e < KS_CT_TILE * BIG_N; e += 256) {
+        const int c = e / BIG_N, i = e % BIG_N;
+        uint16_t packed = 0;
+        if (c < nct) {
+            const uint64_t a = in[(size_t)(ct0 + c) * BIG_CT + i];
+            uint32_t v = (uint32_t)((a + (1ull << 48)) >> 49);   // closest representable on 15 bits
+#pragma unroll
+            for (int l = KS_LEVEL - 1; l >= 0; l--) {            // least significant level first
+                int d = (int)(v & 7u);
+                v >>= 3;
+                if (d >= 4) { d -= 8; v += 1; }
+                packed |= (uint16_t)((d + 4) << (3 * l));
+            }
+        } else {
+            packed = 0x4924;   // all digits zero (biased 4 in each 3-bit field)
+        }
+        digs[c][i] = packed;
+    }
+    __syncthreads();
+    uint64_t acc[KS_CT_TILE];
+#pragma unroll
+    for (int c = 0; c < KS_CT_TILE; c++) acc[c] = 0;
+    if (col < SMALL_CT) {
+        for (int i = 0; i < BIG_N; i++) {
+            uint64_t k[KS_LEVEL];
+#pragma unroll
+            for (int l = 0; l < KS_LEVEL; l++) k[l] = ksk[((size_t)i * KS_LEVEL + l) * SMALL_CT + col];
+#pragma unroll
+            for (int c = 0; c < KS_CT_TILE; c++) {
+                const uint32_t pk = __builtin_amdgcn_readfirstlane((uint32_t)digs[c][i]);
+#pragma unroll
+                for (int l = 0; l < KS_LEVEL; l++) {
+                    const int64_t d = (int64_t)((pk >> (3 * l)) & 7u) - 4;
+                    acc[c] -= (uint64_t)d * k[l];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < KS_CT_TILE; c++) {
+            if (c < nct) {
+                uint64_t v = acc[c];
+                if (col == LWE_N) v += in[(size_t)(ct0 + c) * BIG_CT + BIG_N];
+                ms[(size_t)(ct0 + c) * SMALL_CT + col] = (uint32_t)(((v + (1ull << 51)) >> 52) & 4095u);
+            }
+        }
+    }
+}
+
+hipError_t launch_keyswitch_modswitch(const uint64_t *d_in, const uint64_t *d_ksk, uint32_t *d_ms, int B,
+                                      hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    dim3 grid((B + KS_CT_TILE - 1) / KS_CT_TILE, (SMALL_CT + KS_COLS - 1) / KS_COLS);
+    hipLaunchKernelGGL(keyswitch_modswitch_kernel, grid, dim3(256), 0, s, d_in, d_ksk, d_ms, B);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// linear layer: out[k] = sum_t coef*src + const (u64 wrapping); gather / scatter of blocks
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lincomb_kernel(const LinDesc *__restrict__ desc,
+                                                      const LinTerm *__restrict__ terms,
+                                                      uint64_t *__restrict__ out) {
+    const LinDesc d = desc[blockIdx.x];
+    uint64_t *o = out + (size_t)blockIdx.x * BIG_CT;
+    for (int e = threadIdx.x; e < BIG_CT; e += 256) {
+        uint64_t v = (e == BIG_N) ? d.konst_body : 0;
+        for (uint32_t t = 0; t < d.n_terms; t++) {
+            const LinTerm tm = terms[d.first_term + t];
+            v += (uint64_t)tm.coef * tm.src[e];
+        }
+        o[e] = v;
+    }
+}
+hipError_t launch_lincomb(const LinDesc *d_desc, const LinTerm *d_terms, uint64_t *d_out, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lincomb_kernel, dim3(n), dim3(256), 0, s, d_desc, d_terms, d_out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void gather_blocks_kernel(const uint64_t *const *__restrict__ src,
+                                                            uint64_t *__restrict__ out) {
+    const uint64_t *s = src[blockIdx.x];
+    uint64_t *o = out + (size_t)blockIdx.x * BIG_CT;
+    for (int e = threadIdx.x; e < BIG_CT; e += 256) o[e] = s[e];
+}
+__global__ __launch_bounds__(256) void scatter_blocks_kernel(const uint64_t *__restrict__ in,
+                                                             uint64_t *const *__restrict__ dst) {
+    uint64_t *o = dst[blockIdx.x];
+    const uint64_t *s = in + (size_t)blockIdx.x * BIG_CT;
+    for (int e = threadIdx.x; e < BIG_CT; e += 256) o[e] = s[e];
+}
+hipError_t launch_gather_blocks(const uint64_t *const *d_src, uint64_t *d_out, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_blocks_kernel, dim3(n), dim3(256), 0, s, d_src, d_out);
+    return hipGetLastError();
+}
+hipError_t launch_scatter_blocks(const uint64_t *d_in, uint64_t *const *d_dst, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_blocks_kernel, dim3(n), dim3(256), 0, s, d_in, d_dst);
+    return hipGetLastError();
+}
+
+}  // namespace fhs

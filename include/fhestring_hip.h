@@ -1,0 +1,170 @@
+/*
+ * fhestring_hip.h -- C ABI of the MI355X-native TFHE backend that sits under
+ * the FheString server-key operations of MakisChristou/fhestring.
+ *
+ * The reference has no FFI: its seam is the set of `tfhe::integer` calls made
+ * from src/ciphertext/fheasciichar.rs and src/client_key.rs.
+ * Every entry point below names the reference interface it replaces.  Plain
+ * pointers and sizes only; every function returns 0 on success or a negative
+ * error code (text via fhs_last_error); nothing unwinds across the boundary.
+ *
+ * Ciphertext layout (unchanged from the reference's types):
+ *   block   = big LWE ciphertext, 2049 x u64 (2048 mask + body), 16 392 B
+ *   char    = FheAsciiChar = 4 blocks, little-endian 2-bit digits, 65 568 B
+ *             (src/ciphertext/fheasciichar.rs:8-10)
+ *   string  = contiguous array of chars (src/ciphertext/fhestring.rs:6-9)
+ * Keys: PARAM_MESSAGE_2_CARRY_2_KS_PBS (src/main.rs:3,43)
+ *   bsk[742][2][2][2048] u64  standard-domain GGSW rows (row 0 mask, row 1 body)
+ *   ksk[2048][5][743]    u64
+ */
+#ifndef FHESTRING_HIP_H
+#define FHESTRING_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FHS_LWE_N 742
+#define FHS_POLY_N 2048
+#define FHS_BIG_CT 2049          /* u64 words per block */
+#define FHS_SMALL_CT 743
+#define FHS_BLOCKS_PER_CHAR 4    /* MAX_BLOCKS, src/main.rs:23 */
+#define FHS_CHAR_WORDS (4 * 2049)
+#define FHS_BSK_WORDS ((size_t)742 * 4 * 2048)
+#define FHS_KSK_WORDS ((size_t)2048 * 5 * 743)
+#define FHS_MAX_FIND_LENGTH 255  /* src/main.rs:20 */
+#define FHS_MAX_REPETITIONS 16   /* src/main.rs:17 */
+
+#define FHS_OK 0
+#define FHS_ERR_ARG (-1)
+#define FHS_ERR_HIP (-2)
+#define FHS_ERR_STATE (-3)
+#define FHS_ERR_LIMIT (-4)       /* the reference's panic!("Maximum supported size for find reached") */
+
+typedef struct fhs_ctx fhs_ctx;
+typedef struct fhs_client fhs_client;
+typedef uint64_t fhs_char_t;     /* opaque handle of one lazily evaluated FheAsciiChar */
+
+/* ---- context / server key -------------------------------------------------
+ * replaces: tfhe::integer::ServerKey held by MyServerKey (src/server_key/mod.rs:13-16) */
+int fhs_ctx_create(int device_id, fhs_ctx **out);
+void fhs_ctx_destroy(fhs_ctx *ctx);
+const char *fhs_last_error(const fhs_ctx *ctx);
+/* Copies the key to the device; the BSK is rounded to the 58-bit torus grid and
+ * transformed to the device NTT representation (DESIGN.md "BSK precision"). */
+int fhs_load_server_key(fhs_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk);
+
+/* ---- raw batched PBS (the hot path; kernel-level parity tests use these) ----
+ * replaces: tfhe::shortint::ServerKey::apply_lookup_table on B blocks.
+ * in[B][2049], lut_idx[B], luts[L][2048] (LUT body polynomials), out[B][2049]: host memory. */
+int fhs_pbs_batch(fhs_ctx *ctx, const uint64_t *in, const uint32_t *lut_idx, const uint64_t *luts,
+                  size_t n_luts, uint64_t *out, size_t B);
+/* keyswitch + modulus switch only: ms_out[B][743] values in [0,4096) */
+int fhs_keyswitch_modswitch_batch(fhs_ctx *ctx, const uint64_t *in, uint32_t *ms_out, size_t B);
+/* Device-resident variant used by bench.py: all pointers are device pointers
+ * (e.g. torch tensors' data_ptr); work is enqueued on `hip_stream` (0 = default). */
+int fhs_pbs_batch_device(fhs_ctx *ctx, const uint64_t *d_in, const uint32_t *d_lut_idx,
+                         const uint64_t *d_luts, uint64_t *d_out, size_t B, void *hip_stream);
+/* Average duration (ms) of the blind-rotation / keyswitch kernel launches since the last
+ * reset, measured with HIP events on the launch stream; and number of launches timed. */
+int fhs_kernel_timing(fhs_ctx *ctx, int reset, double *blind_rotate_ms, double *keyswitch_ms,
+                      uint64_t *n_blind_rotate, uint64_t *n_keyswitch, uint64_t *pbs_in_launches);
+
+/* ---- FheAsciiChar boundary ops (lazy DAG nodes) ------------------------------
+ * Each constructor mirrors one method of src/ciphertext/fheasciichar.rs and returns a
+ * handle; nothing runs until fhs_flush / fhs_download. 0 is never a valid handle. */
+fhs_char_t fhs_trivial(fhs_ctx *ctx, uint8_t value);                    /* encrypt_trivial :17-25 */
+fhs_char_t fhs_upload(fhs_ctx *ctx, const uint64_t *blocks /*[4][2049]*/); /* FheAsciiChar::new :13 */
+fhs_char_t fhs_eq(fhs_ctx *ctx, fhs_char_t a, fhs_char_t b);            /* eq  :35-38 */
+fhs_char_t fhs_ne(fhs_ctx *ctx, fhs_char_t a, fhs_char_t b);            /* ne  :40-43 */
+fhs_char_t fhs_le(fhs_ctx *ctx, fhs_char_t a, fhs_char_t b);            /* le  :45-48 */
+fhs_char_t fhs_lt(fhs_ctx *ctx, fhs_char_t a, fhs_char_t b);            /* lt  :50-53 */
+fhs_char_t fhs_ge(fhs_ctx *ctx, fhs_char_t a, fhs_char_t b);            /* ge  :55-58 */
+fhs_char_t fhs_gt(fhs_ctx *ctx, fhs_char_t a, fhs_char_t b);            /* gt  :60-63 */
+fhs_char_t fhs_bitand(fhs_ctx *ctx, fhs_char_t a, fhs_char_t b);        /* bitand :65-72 */
+fhs_char_t fhs_bitor(fhs_ctx *ctx, fhs_char_t a, fhs_char_t b);         /* bitor  :74-81 */
+fhs_char_t fhs_sub(fhs_ctx *ctx, fhs_char_t a, fhs_char_t b);           /* sub :83-86 */
+fhs_char_t fhs_add(fhs_ctx *ctx, fhs_char_t a, fhs_char_t b);           /* add :88-91 */
+fhs_char_t fhs_if_then_else(fhs_ctx *ctx, fhs_char_t cond, fhs_char_t t, fhs_char_t f); /* :93-104 */
+fhs_char_t fhs_flip(fhs_ctx *ctx, fhs_char_t a);                        /* flip :161-168 */
+fhs_char_t fhs_is_whitespace(fhs_ctx *ctx, fhs_char_t a);               /* :106-130 */
+fhs_char_t fhs_is_uppercase(fhs_ctx *ctx, fhs_char_t a);                /* :132-144 */
+fhs_char_t fhs_is_lowercase(fhs_ctx *ctx, fhs_char_t a);                /* :146-158 */
+fhs_char_t fhs_clone(fhs_ctx *ctx, fhs_char_t a);                       /* #[derive(Clone)] :7 */
+int fhs_release(fhs_ctx *ctx, fhs_char_t a);
+int fhs_flush(fhs_ctx *ctx);                                             /* run every pending level */
+int fhs_download(fhs_ctx *ctx, fhs_char_t a, uint64_t *blocks /*[4][2049]*/);
+/* device-to-device import/export of one char (multi-GPU gather of partial results) */
+int fhs_export_device(fhs_ctx *ctx, fhs_char_t a, uint64_t *d_blocks /*[4][2049] device*/);
+fhs_char_t fhs_import_device(fhs_ctx *ctx, const uint64_t *d_blocks);
+
+/* ---- MyServerKey string methods (src/server_key/mod.rs, trim.rs) --------------
+ * Strings are arrays of handles (FheString.bytes). mode: 0 = as written in the reference
+ * (same op sequence), 1 = re-associated (log-depth trees, single-block flags; decrypts
+ * identically).  Outputs are fresh handles owned by the caller. */
+#define FHS_MODE_AS_WRITTEN 0
+#define FHS_MODE_FUSED 1
+int fhs_set_mode(fhs_ctx *ctx, int mode);
+int fhs_str_contains(fhs_ctx *c, const fhs_char_t *s, size_t n, const fhs_char_t *pat, size_t m, fhs_char_t *out);      /* mod.rs:151 */
+int fhs_str_contains_clear(fhs_ctx *c, const fhs_char_t *s, size_t n, const char *pat, size_t m, fhs_char_t *out);      /* mod.rs:198 */
+int fhs_str_starts_with(fhs_ctx *c, const fhs_char_t *s, size_t n, const fhs_char_t *pat, size_t m, fhs_char_t *out);   /* mod.rs:344 */
+int fhs_str_ends_with(fhs_ctx *c, const fhs_char_t *s, size_t n, const fhs_char_t *pat, size_t m, fhs_char_t *out);     /* mod.rs:241 */
+int fhs_str_find(fhs_ctx *c, const fhs_char_t *s, size_t n, const fhs_char_t *pat, size_t m, fhs_char_t *out);          /* mod.rs:1010 */
+int fhs_str_find_clear(fhs_ctx *c, const fhs_char_t *s, size_t n, const char *pat, size_t m, fhs_char_t *out);          /* mod.rs:1075 */
+int fhs_str_rfind(fhs_ctx *c, const fhs_char_t *s, size_t n, const fhs_char_t *pat, size_t m, fhs_char_t *out);         /* mod.rs:727 */
+int fhs_str_is_empty(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out);                                       /* mod.rs:431 */
+int fhs_str_len(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out);                                            /* mod.rs:478 */
+int fhs_str_eq(fhs_ctx *c, const fhs_char_t *a, size_t na, const fhs_char_t *b, size_t nb, fhs_char_t *out);            /* mod.rs:1122 */
+int fhs_str_ne(fhs_ctx *c, const fhs_char_t *a, size_t na, const fhs_char_t *b, size_t nb, fhs_char_t *out);            /* mod.rs:1178 */
+int fhs_str_eq_ignore_case(fhs_ctx *c, const fhs_char_t *a, size_t na, const fhs_char_t *b, size_t nb, fhs_char_t *out);/* mod.rs:1221 */
+/* cmp: 0 lt, 1 le, 2 gt, 3 ge (enum Comparison, fhestring.rs:11-16) */
+int fhs_str_compare(fhs_ctx *c, const fhs_char_t *a, size_t na, const fhs_char_t *b, size_t nb, int cmp, fhs_char_t *out); /* mod.rs:1470 */
+int fhs_str_to_upper(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out /*[n]*/);                               /* mod.rs:65 */
+int fhs_str_to_lower(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out /*[n]*/);                               /* mod.rs:110 */
+/* out_cap >= fhs_str_replace_len(n, m_from, m_to); *out_len receives the produced length */
+size_t fhs_str_replace_len(size_t n, size_t m_from, size_t m_to);
+int fhs_str_replace(fhs_ctx *c, const fhs_char_t *s, size_t n, const fhs_char_t *from, size_t mf,
+                    const fhs_char_t *to, size_t mt, fhs_char_t *out, size_t out_cap, size_t *out_len);                 /* mod.rs:624 */
+int fhs_str_replacen(fhs_ctx *c, const fhs_char_t *s, size_t n, const fhs_char_t *from, size_t mf,
+                     const fhs_char_t *to, size_t mt, fhs_char_t count, fhs_char_t *out, size_t out_cap, size_t *out_len); /* mod.rs:1729 */
+int fhs_str_repeat(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t count, fhs_char_t *out /*[16*n]*/);             /* mod.rs:567 */
+int fhs_str_repeat_clear(fhs_ctx *c, const fhs_char_t *s, size_t n, size_t count, fhs_char_t *out /*[count*n]*/);        /* mod.rs:517 */
+int fhs_str_concatenate(fhs_ctx *c, const fhs_char_t *a, size_t na, const fhs_char_t *b, size_t nb, fhs_char_t *out /*[na+nb]*/); /* mod.rs:1864 */
+int fhs_str_strip_prefix(fhs_ctx *c, const fhs_char_t *s, size_t n, const fhs_char_t *pat, size_t m, fhs_char_t *out /*[n]*/, fhs_char_t *found); /* mod.rs:1261 */
+int fhs_str_strip_suffix(fhs_ctx *c, const fhs_char_t *s, size_t n, const fhs_char_t *pat, size_t m, fhs_char_t *out /*[n]*/, fhs_char_t *found); /* mod.rs:1335 */
+int fhs_str_trim_end(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out /*[n]*/);                               /* trim.rs:36 */
+int fhs_str_trim_start(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out /*[n]*/);                             /* trim.rs:86 */
+int fhs_str_trim(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out /*[n]*/);                                   /* trim.rs:146 */
+int fhs_bubble_zeroes_right(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out /*[n]*/);                        /* utils.rs:28 */
+
+/* ---- statistics ---------------------------------------------------------------- */
+typedef struct {
+    uint64_t pbs_executed;     /* PBS actually run on the GPU (constant-folded ones excluded) */
+    uint64_t pbs_folded;       /* PBS on all-trivial inputs folded at DAG construction */
+    uint64_t levels;           /* dependency levels launched */
+    uint64_t max_level_width;
+    uint64_t blocks_live;      /* device ciphertext blocks currently allocated */
+} fhs_stats;
+int fhs_get_stats(fhs_ctx *ctx, fhs_stats *out);
+int fhs_reset_stats(fhs_ctx *ctx);
+
+/* ---- client side (MyClientKey, src/client_key.rs) -- host CPU, like the reference -- */
+int fhs_client_create(uint64_t seed, fhs_client **out);                  /* from_params :30-35 */
+void fhs_client_destroy(fhs_client *ck);
+const uint64_t *fhs_client_bsk(const fhs_client *ck);                    /* get_server_key :37-39 */
+const uint64_t *fhs_client_ksk(const fhs_client *ck);
+int fhs_client_encrypt_char(fhs_client *ck, uint8_t v, uint64_t *blocks /*[4][2049]*/); /* encrypt_char :85-87 */
+int fhs_client_decrypt_char(const fhs_client *ck, const uint64_t *blocks, uint8_t *out); /* decrypt_char :81-83 */
+/* encrypt :45-65 (ASCII, no NUL, `padding` NULs appended): out[(len+padding)][4][2049] */
+int fhs_client_encrypt_str(fhs_client *ck, const char *s, size_t len, size_t padding, uint64_t *out);
+/* decrypt :89-106 (truncates at the first NUL); returns the number of bytes written */
+int fhs_client_decrypt_str(const fhs_client *ck, const uint64_t *chars, size_t n, char *out, size_t *out_len);
+int fhs_client_secret_keys(const fhs_client *ck, uint64_t *lwe_sk /*[742]*/, uint64_t *glwe_sk /*[2048]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
