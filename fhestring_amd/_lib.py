@@ -52,11 +52,93 @@ def _declare(L):
     L.fhs_kernel_timing.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.fhs_kernel_timing.restype = i
-    for name, args, res in _OPTIONAL:
-        if hasattr(L, name):
-            f = getattr(L, name)
-            f.argtypes = args
-            f.restype = res
+    h = C.c_uint64                     # fhs_char_t
+    hp = C.POINTER(C.c_uint64)
+    L.fhs_trivial.argtypes = [vp, u8]
+    L.fhs_trivial.restype = h
+    L.fhs_upload.argtypes = [vp, vp]
+    L.fhs_upload.restype = h
+    L.fhs_import_device.argtypes = [vp, vp]
+    L.fhs_import_device.restype = h
+    for name in ("eq", "ne", "le", "lt", "ge", "gt", "bitand", "bitor", "sub", "add"):
+        f = getattr(L, "fhs_" + name)
+        f.argtypes = [vp, h, h]
+        f.restype = h
+    L.fhs_if_then_else.argtypes = [vp, h, h, h]
+    L.fhs_if_then_else.restype = h
+    for name in ("flip", "is_whitespace", "is_uppercase", "is_lowercase", "clone"):
+        f = getattr(L, "fhs_" + name)
+        f.argtypes = [vp, h]
+        f.restype = h
+    L.fhs_release.argtypes = [vp, h]
+    L.fhs_release.restype = i
+    L.fhs_flush.argtypes = [vp]
+    L.fhs_flush.restype = i
+    L.fhs_download.argtypes = [vp, h, vp]
+    L.fhs_download.restype = i
+    L.fhs_export_device.argtypes = [vp, h, vp]
+    L.fhs_export_device.restype = i
+    L.fhs_set_mode.argtypes = [vp, i]
+    L.fhs_set_mode.restype = i
+    for name in ("contains", "starts_with", "ends_with", "find", "rfind", "eq", "ne", "eq_ignore_case"):
+        f = getattr(L, "fhs_str_" + name)
+        f.argtypes = [vp, hp, sz, hp, sz, hp]
+        f.restype = i
+    for name in ("contains_clear", "find_clear"):
+        f = getattr(L, "fhs_str_" + name)
+        f.argtypes = [vp, hp, sz, C.c_char_p, sz, hp]
+        f.restype = i
+    for name in ("is_empty", "len"):
+        f = getattr(L, "fhs_str_" + name)
+        f.argtypes = [vp, hp, sz, hp]
+        f.restype = i
+    L.fhs_str_compare.argtypes = [vp, hp, sz, hp, sz, i, hp]
+    L.fhs_str_compare.restype = i
+    for name in ("fhs_str_to_upper", "fhs_str_to_lower", "fhs_str_trim_end", "fhs_str_trim_start",
+                 "fhs_str_trim", "fhs_bubble_zeroes_right"):
+        f = getattr(L, name)
+        f.argtypes = [vp, hp, sz, hp]
+        f.restype = i
+    L.fhs_str_replace_len.argtypes = [sz, sz, sz]
+    L.fhs_str_replace_len.restype = sz
+    L.fhs_str_replace.argtypes = [vp, hp, sz, hp, sz, hp, sz, hp, sz, C.POINTER(sz)]
+    L.fhs_str_replace.restype = i
+    L.fhs_str_replacen.argtypes = [vp, hp, sz, hp, sz, hp, sz, h, hp, sz, C.POINTER(sz)]
+    L.fhs_str_replacen.restype = i
+    L.fhs_str_repeat.argtypes = [vp, hp, sz, h, hp]
+    L.fhs_str_repeat.restype = i
+    L.fhs_str_repeat_clear.argtypes = [vp, hp, sz, sz, hp]
+    L.fhs_str_repeat_clear.restype = i
+    L.fhs_str_concatenate.argtypes = [vp, hp, sz, hp, sz, hp]
+    L.fhs_str_concatenate.restype = i
+    for name in ("strip_prefix", "strip_suffix"):
+        f = getattr(L, "fhs_str_" + name)
+        f.argtypes = [vp, hp, sz, hp, sz, hp, hp]
+        f.restype = i
+    L.fhs_get_stats.argtypes = [vp, vp]
+    L.fhs_get_stats.restype = i
+    L.fhs_reset_stats.argtypes = [vp]
+    L.fhs_reset_stats.restype = i
+    L.fhs_client_create.argtypes = [u64, C.POINTER(vp)]
+    L.fhs_client_create.restype = i
+    L.fhs_client_destroy.argtypes = [vp]
+    L.fhs_client_destroy.restype = None
+    L.fhs_client_bsk.argtypes = [vp]
+    L.fhs_client_bsk.restype = C.POINTER(C.c_uint64)
+    L.fhs_client_ksk.argtypes = [vp]
+    L.fhs_client_ksk.restype = C.POINTER(C.c_uint64)
+    L.fhs_client_encrypt_char.argtypes = [vp, u8, vp]
+    L.fhs_client_encrypt_char.restype = i
+    L.fhs_client_decrypt_char.argtypes = [vp, vp, C.POINTER(u8)]
+    L.fhs_client_decrypt_char.restype = i
+    L.fhs_client_encrypt_str.argtypes = [vp, C.c_char_p, sz, sz, vp]
+    L.fhs_client_encrypt_str.restype = i
+    L.fhs_client_decrypt_str.argtypes = [vp, vp, sz, C.c_char_p, C.POINTER(sz)]
+    L.fhs_client_decrypt_str.restype = i
+    L.fhs_client_secret_keys.argtypes = [vp, vp, vp]
+    L.fhs_client_secret_keys.restype = i
 
 
-_OPTIONAL = []
+class Stats(C.Structure):
+    _fields_ = [("pbs_executed", C.c_uint64), ("pbs_folded", C.c_uint64), ("levels", C.c_uint64),
+                ("max_level_width", C.c_uint64), ("blocks_live", C.c_uint64)]

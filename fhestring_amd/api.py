@@ -82,3 +82,384 @@ class Context:
                                               C.byref(nk), C.byref(units)))
         return {"blind_rotate_ms": br.value, "keyswitch_ms": ks.value, "n_blind_rotate": nb.value,
                 "n_keyswitch": nk.value, "pbs_in_launches": units.value}
+
+
+# ---------------------------------------------------------------------------------------------
+# Mirror of the reference's types: MyClientKey (src/client_key.rs), FheAsciiChar / FheString
+# (src/ciphertext), MyServerKey (src/server_key/mod.rs).  Same method names and argument meaning;
+# `public_parameters` is accepted and ignored like the reference's dead parameter.
+# ---------------------------------------------------------------------------------------------
+CHAR_WORDS = 4 * BIG_CT
+MAX_FIND_LENGTH = 255
+MAX_REPETITIONS = 16
+STRING_PADDING = 1
+MODE_AS_WRITTEN = 0
+MODE_FUSED = 1
+
+
+class MyClientKey:
+    """Host-CPU client key (keygen / encrypt / decrypt), like the reference's."""
+
+    def __init__(self, seed=0xF5E57121):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.fhs_client_create(int(seed), C.byref(h))
+        if rc != 0:
+            raise FhsError("fhs_client_create failed (%d)" % rc)
+        self._h = h
+
+    @classmethod
+    def from_params(cls, params=None, num_blocks=4, seed=0xF5E57121):   # client_key.rs:30-35
+        assert num_blocks == 4
+        return cls(seed)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fhs_client_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bsk(self):
+        return np.ctypeslib.as_array(self._L.fhs_client_bsk(self._h), shape=(742 * 4 * 2048,))
+
+    def ksk(self):
+        return np.ctypeslib.as_array(self._L.fhs_client_ksk(self._h), shape=(2048 * 5 * 743,))
+
+    def secret_keys(self):
+        lwe = np.zeros(742, np.uint64)
+        glwe = np.zeros(2048, np.uint64)
+        self._L.fhs_client_secret_keys(self._h, _ptr(lwe), _ptr(glwe))
+        return lwe, glwe
+
+    def get_server_key(self, device_id=0):                               # client_key.rs:37-39
+        return MyServerKey.from_client_key(self, device_id)
+
+    def encrypt_char_raw(self, v):
+        out = np.zeros((4, BIG_CT), np.uint64)
+        self._L.fhs_client_encrypt_char(self._h, int(v) & 255, _ptr(out))
+        return out
+
+    def encrypt_str_raw(self, text, padding):
+        data = text.encode("ascii") if isinstance(text, str) else bytes(text)
+        out = np.zeros((len(data) + padding, 4, BIG_CT), np.uint64)
+        rc = self._L.fhs_client_encrypt_str(self._h, data, len(data), int(padding), _ptr(out))
+        if rc != 0:
+            raise AssertionError("The input string must only contain ascii letters and not include null characters")
+        return out
+
+    def decrypt_char_raw(self, blocks):
+        v = C.c_uint8()
+        blocks = np.ascontiguousarray(blocks, np.uint64)
+        self._L.fhs_client_decrypt_char(self._h, _ptr(blocks), C.byref(v))
+        return v.value
+
+    def decrypt_str_raw(self, chars):
+        chars = np.ascontiguousarray(chars, np.uint64).reshape(-1, 4, BIG_CT)
+        buf = C.create_string_buffer(chars.shape[0] + 1)
+        n = C.c_size_t()
+        self._L.fhs_client_decrypt_str(self._h, _ptr(chars), chars.shape[0], buf, C.byref(n))
+        return buf.raw[:n.value].decode("ascii")
+
+    # reference-shaped API (server key needed to place ciphertexts on the device)
+    def encrypt(self, string, padding, public_parameters=None, server_key=None):   # :45-65
+        return server_key.upload_string(self.encrypt_str_raw(string, padding))
+
+    def encrypt_no_padding(self, string, server_key=None):                         # :67-79
+        return server_key.upload_string(self.encrypt_str_raw(string, 0)).chars
+
+    def encrypt_char(self, v, server_key=None):                                    # :85-87
+        return server_key.upload_char(self.encrypt_char_raw(v))
+
+    def decrypt_char(self, ch):                                                    # :81-83
+        return self.decrypt_char_raw(ch.download())
+
+    def decrypt(self, fhe_string):                                                 # :89-106
+        return self.decrypt_str_raw(fhe_string.download())
+
+
+class FheAsciiChar:
+    """Handle of one lazily evaluated encrypted char (fheasciichar.rs:8-10)."""
+    __slots__ = ("sk", "h")
+
+    def __init__(self, sk, h):
+        if not h:
+            raise FhsError("null char handle: " + sk.ctx._L.fhs_last_error(sk.ctx._h).decode())
+        self.sk = sk
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h and self.sk.ctx._h:
+                self.sk.ctx._L.fhs_release(self.sk.ctx._h, self.h)
+        except Exception:
+            pass
+
+    @staticmethod
+    def encrypt_trivial(value, public_parameters, server_key):           # :17-25
+        return server_key.trivial(value)
+
+    def _bin(self, name, other):
+        L, c = self.sk.ctx._L, self.sk.ctx._h
+        return FheAsciiChar(self.sk, getattr(L, "fhs_" + name)(c, self.h, other.h))
+
+    def eq(self, o): return self._bin("eq", o)
+    def ne(self, o): return self._bin("ne", o)
+    def le(self, o): return self._bin("le", o)
+    def lt(self, o): return self._bin("lt", o)
+    def ge(self, o): return self._bin("ge", o)
+    def gt(self, o): return self._bin("gt", o)
+    def bitand(self, o): return self._bin("bitand", o)
+    def bitor(self, o): return self._bin("bitor", o)
+    def sub(self, o): return self._bin("sub", o)
+    def add(self, o): return self._bin("add", o)
+
+    def if_then_else(self, t, f):
+        return FheAsciiChar(self.sk, self.sk.ctx._L.fhs_if_then_else(self.sk.ctx._h, self.h, t.h, f.h))
+
+    def _un(self, name):
+        return FheAsciiChar(self.sk, getattr(self.sk.ctx._L, "fhs_" + name)(self.sk.ctx._h, self.h))
+
+    def flip(self): return self._un("flip")
+    def is_whitespace(self): return self._un("is_whitespace")
+    def is_uppercase(self): return self._un("is_uppercase")
+    def is_lowercase(self): return self._un("is_lowercase")
+    def clone(self): return self._un("clone")
+
+    def download(self):
+        out = np.zeros((4, BIG_CT), np.uint64)
+        self.sk.ctx._check(self.sk.ctx._L.fhs_download(self.sk.ctx._h, self.h, _ptr(out)))
+        return out
+
+
+class FheString:
+    """Vec<FheAsciiChar> (fhestring.rs:6-9)."""
+
+    def __init__(self, chars):
+        self.chars = list(chars)
+
+    def __len__(self):
+        return len(self.chars)
+
+    def __getitem__(self, i):
+        return self.chars[i]
+
+    def download(self):
+        if not self.chars:
+            return np.zeros((0, 4, BIG_CT), np.uint64)
+        return np.stack([c.download() for c in self.chars])
+
+
+def _harr(chars):
+    arr = (C.c_uint64 * max(1, len(chars)))()
+    for i, ch in enumerate(chars):
+        arr[i] = ch.h
+    return arr
+
+
+class MyServerKey:
+    """MyServerKey (src/server_key/mod.rs:13-16) on one MI355X."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self._stats = None
+
+    @classmethod
+    def from_client_key(cls, client_key, device_id=0):
+        ctx = Context(device_id)
+        ctx.load_server_key(client_key.bsk(), client_key.ksk())
+        return cls(ctx)
+
+    @classmethod
+    def from_raw_keys(cls, bsk, ksk, device_id=0):
+        ctx = Context(device_id)
+        ctx.load_server_key(bsk, ksk)
+        return cls(ctx)
+
+    def close(self):
+        self.ctx.close()
+
+    def set_mode(self, mode):
+        self.ctx._check(self.ctx._L.fhs_set_mode(self.ctx._h, int(mode)))
+
+    # ---- ciphertext placement ------------------------------------------------
+    def trivial(self, v):
+        return FheAsciiChar(self, self.ctx._L.fhs_trivial(self.ctx._h, int(v) & 255))
+
+    def upload_char(self, blocks):
+        blocks = np.ascontiguousarray(blocks, np.uint64)
+        return FheAsciiChar(self, self.ctx._L.fhs_upload(self.ctx._h, _ptr(blocks)))
+
+    def upload_string(self, chars):
+        chars = np.ascontiguousarray(chars, np.uint64).reshape(-1, 4, BIG_CT)
+        return FheString([self.upload_char(chars[i]) for i in range(chars.shape[0])])
+
+    def import_device(self, d_ptr):
+        return FheAsciiChar(self, self.ctx._L.fhs_import_device(self.ctx._h, C.c_void_p(d_ptr)))
+
+    def export_device(self, ch, d_ptr):
+        self.ctx._check(self.ctx._L.fhs_export_device(self.ctx._h, ch.h, C.c_void_p(d_ptr)))
+
+    def flush(self):
+        self.ctx._check(self.ctx._L.fhs_flush(self.ctx._h))
+
+    def stats(self, reset=False):
+        from ._lib import Stats
+        st = Stats()
+        self.ctx._check(self.ctx._L.fhs_get_stats(self.ctx._h, C.byref(st)))
+        out = {k: getattr(st, k) for k, _ in Stats._fields_}
+        if reset:
+            self.ctx._L.fhs_reset_stats(self.ctx._h)
+        return out
+
+    # ---- helpers -------------------------------------------------------------
+    @staticmethod
+    def _chars(x):
+        return x.chars if isinstance(x, FheString) else list(x)
+
+    def _flag_op(self, name, s, pat):
+        s, pat = self._chars(s), self._chars(pat)
+        out = C.c_uint64()
+        rc = getattr(self.ctx._L, "fhs_str_" + name)(self.ctx._h, _harr(s), len(s), _harr(pat), len(pat),
+                                                      C.byref(out))
+        if rc == -4:
+            raise OverflowError(self.ctx._L.fhs_last_error(self.ctx._h).decode())
+        self.ctx._check(rc)
+        return FheAsciiChar(self, out.value)
+
+    def _map_op(self, name, s, n_out=None):
+        s = self._chars(s)
+        n_out = len(s) if n_out is None else n_out
+        out = (C.c_uint64 * max(1, n_out))()
+        self.ctx._check(getattr(self.ctx._L, name)(self.ctx._h, _harr(s), len(s), out))
+        return FheString([FheAsciiChar(self, out[i]) for i in range(n_out)])
+
+    # ---- the reference's methods (public_parameters accepted and ignored) -----
+    def contains(self, string, needle, public_parameters=None):          # mod.rs:151
+        return self._flag_op("contains", string, needle)
+
+    def contains_clear(self, string, clear_needle, public_parameters=None):   # mod.rs:198
+        s = self._chars(string)
+        data = clear_needle.encode("ascii")
+        out = C.c_uint64()
+        self.ctx._check(self.ctx._L.fhs_str_contains_clear(self.ctx._h, _harr(s), len(s), data, len(data),
+                                                           C.byref(out)))
+        return FheAsciiChar(self, out.value)
+
+    def starts_with(self, string, pattern, public_parameters=None):      # mod.rs:344
+        return self._flag_op("starts_with", string, pattern)
+
+    def ends_with(self, string, needle, public_parameters=None):         # mod.rs:241
+        return self._flag_op("ends_with", string, needle)
+
+    def find(self, string, pattern, public_parameters=None):             # mod.rs:1010
+        return self._flag_op("find", string, pattern)
+
+    def find_clear(self, string, clear_pattern, public_parameters=None):  # mod.rs:1075
+        s = self._chars(string)
+        data = clear_pattern.encode("ascii")
+        out = C.c_uint64()
+        rc = self.ctx._L.fhs_str_find_clear(self.ctx._h, _harr(s), len(s), data, len(data), C.byref(out))
+        if rc == -4:
+            raise OverflowError(self.ctx._L.fhs_last_error(self.ctx._h).decode())
+        self.ctx._check(rc)
+        return FheAsciiChar(self, out.value)
+
+    def rfind(self, string, pattern, public_parameters=None):            # mod.rs:727
+        return self._flag_op("rfind", string, pattern)
+
+    def is_empty(self, string, public_parameters=None):                  # mod.rs:431
+        s = self._chars(string)
+        out = C.c_uint64()
+        self.ctx._check(self.ctx._L.fhs_str_is_empty(self.ctx._h, _harr(s), len(s), C.byref(out)))
+        return FheAsciiChar(self, out.value)
+
+    def len(self, string, public_parameters=None):                       # mod.rs:478
+        s = self._chars(string)
+        out = C.c_uint64()
+        self.ctx._check(self.ctx._L.fhs_str_len(self.ctx._h, _harr(s), len(s), C.byref(out)))
+        return FheAsciiChar(self, out.value)
+
+    def eq(self, string, other, public_parameters=None):                 # mod.rs:1122
+        return self._flag_op("eq", string, other)
+
+    def ne(self, string, other, public_parameters=None):                 # mod.rs:1178
+        return self._flag_op("ne", string, other)
+
+    def eq_ignore_case(self, string, other, public_parameters=None):     # mod.rs:1221
+        return self._flag_op("eq_ignore_case", string, other)
+
+    def _compare(self, a, b, cmp):
+        a, b = self._chars(a), self._chars(b)
+        out = C.c_uint64()
+        self.ctx._check(self.ctx._L.fhs_str_compare(self.ctx._h, _harr(a), len(a), _harr(b), len(b), cmp,
+                                                    C.byref(out)))
+        return FheAsciiChar(self, out.value)
+
+    def lt(self, a, b, public_parameters=None): return self._compare(a, b, 0)   # mod.rs:1577
+    def le(self, a, b, public_parameters=None): return self._compare(a, b, 1)   # mod.rs:1613
+    def gt(self, a, b, public_parameters=None): return self._compare(a, b, 2)   # mod.rs:1649
+    def ge(self, a, b, public_parameters=None): return self._compare(a, b, 3)   # mod.rs:1685
+
+    def to_upper(self, s, public_parameters=None): return self._map_op("fhs_str_to_upper", s)   # mod.rs:65
+    def to_lower(self, s, public_parameters=None): return self._map_op("fhs_str_to_lower", s)   # mod.rs:110
+    def trim_end(self, s, public_parameters=None): return self._map_op("fhs_str_trim_end", s)   # trim.rs:36
+    def trim_start(self, s, public_parameters=None): return self._map_op("fhs_str_trim_start", s)  # trim.rs:86
+    def trim(self, s, public_parameters=None): return self._map_op("fhs_str_trim", s)            # trim.rs:146
+    def bubble_zeroes_right(self, s): return self._map_op("fhs_bubble_zeroes_right", s)           # utils.rs:28
+
+    def _replace(self, s, frm, to, n=None):
+        s, frm, to = self._chars(s), self._chars(frm), self._chars(to)
+        cap = self.ctx._L.fhs_str_replace_len(len(s), len(frm), len(to))
+        out = (C.c_uint64 * max(1, cap))()
+        n_out = C.c_size_t()
+        if n is None:
+            rc = self.ctx._L.fhs_str_replace(self.ctx._h, _harr(s), len(s), _harr(frm), len(frm), _harr(to),
+                                             len(to), out, cap, C.byref(n_out))
+        else:
+            rc = self.ctx._L.fhs_str_replacen(self.ctx._h, _harr(s), len(s), _harr(frm), len(frm), _harr(to),
+                                              len(to), n.h, out, cap, C.byref(n_out))
+        self.ctx._check(rc)
+        return FheString([FheAsciiChar(self, out[i]) for i in range(n_out.value)])
+
+    def replace(self, s, frm, to, public_parameters=None): return self._replace(s, frm, to)          # mod.rs:624
+    def replacen(self, s, frm, to, n, public_parameters=None): return self._replace(s, frm, to, n)  # mod.rs:1729
+
+    def replace_clear(self, s, clear_from, clear_to, public_parameters=None):                        # mod.rs:679
+        return self._replace(s, [self.trivial(b) for b in clear_from.encode("ascii")],
+                             [self.trivial(b) for b in clear_to.encode("ascii")])
+
+    def repeat(self, s, n, public_parameters=None):                       # mod.rs:567
+        s = self._chars(s)
+        n_out = MAX_REPETITIONS * len(s)
+        out = (C.c_uint64 * max(1, n_out))()
+        self.ctx._check(self.ctx._L.fhs_str_repeat(self.ctx._h, _harr(s), len(s), n.h, out))
+        return FheString([FheAsciiChar(self, out[i]) for i in range(n_out)])
+
+    def repeat_clear(self, s, n, public_parameters=None):                 # mod.rs:517
+        s = self._chars(s)
+        n_out = n * len(s)
+        out = (C.c_uint64 * max(1, n_out))()
+        self.ctx._check(self.ctx._L.fhs_str_repeat_clear(self.ctx._h, _harr(s), len(s), n, out))
+        return FheString([FheAsciiChar(self, out[i]) for i in range(n_out)])
+
+    def concatenate(self, a, b, public_parameters=None):                  # mod.rs:1864
+        a, b = self._chars(a), self._chars(b)
+        out = (C.c_uint64 * max(1, len(a) + len(b)))()
+        self.ctx._check(self.ctx._L.fhs_str_concatenate(self.ctx._h, _harr(a), len(a), _harr(b), len(b), out))
+        return FheString([FheAsciiChar(self, out[i]) for i in range(len(a) + len(b))])
+
+    def _strip(self, name, s, pat):
+        s, pat = self._chars(s), self._chars(pat)
+        out = (C.c_uint64 * max(1, len(s)))()
+        found = C.c_uint64()
+        self.ctx._check(getattr(self.ctx._L, name)(self.ctx._h, _harr(s), len(s), _harr(pat), len(pat), out,
+                                                   C.byref(found)))
+        return FheString([FheAsciiChar(self, out[i]) for i in range(len(s))]), FheAsciiChar(self, found.value)
+
+    def strip_prefix(self, s, pat, public_parameters=None): return self._strip("fhs_str_strip_prefix", s, pat)   # mod.rs:1261
+    def strip_suffix(self, s, pat, public_parameters=None): return self._strip("fhs_str_strip_suffix", s, pat)   # mod.rs:1335

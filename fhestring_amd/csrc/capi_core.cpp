@@ -1,12 +1,7 @@
 // extern "C" boundary, part 1: context, server key, raw batched PBS (include/fhestring_hip.h).
-#include "../../include/fhestring_hip.h"
-#include "engine.h"
+#include <new>
 
-using fhs::Engine;
-
-struct fhs_ctx {
-    Engine eng;
-};
+#include "capi_internal.h"
 
 extern "C" {
 

@@ -1,0 +1,183 @@
+// Client side: host-CPU mirror of MyClientKey (src/client_key.rs) -- key generation, encryption and
+// decryption of FheAsciiChar / FheString under PARAM_MESSAGE_2_CARRY_2_KS_PBS.  The reference does
+// this on the CPU through tfhe::integer::{gen_keys_radix, RadixClientKey}; so does this file.  Own
+// seeded generator (SplitMix64 + Box-Muller): keys cannot be shared with tfhe-rs anyway.
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "../../include/fhestring_hip.h"
+#include "pbs_kernels.h"
+
+namespace {
+
+using namespace fhs;
+constexpr double LWE_NOISE = 7.069849454709433e-6;
+constexpr double GLWE_NOISE = 2.9403601535432533e-16;
+constexpr int PBS_BASE_LOG = 23;
+
+struct Rng {
+    uint64_t s;
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    double unit() { return ((double)(next() >> 11) + 1.0) * (1.0 / 9007199254740992.0); }
+    uint64_t noise(double std_frac) {
+        const double u1 = unit(), u2 = unit();
+        const double g = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586476925 * u2);
+        return (uint64_t)(int64_t)std::llround(g * std_frac * 18446744073709551616.0);
+    }
+};
+inline uint64_t mix(uint64_t seed, uint64_t stream) {
+    Rng r{seed ^ (stream * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull)};
+    r.next();
+    return r.next();
+}
+
+}  // namespace
+
+struct fhs_client {
+    uint64_t seed;
+    std::vector<uint64_t> lwe_sk, glwe_sk, bsk, ksk;
+    Rng enc_rng;
+};
+
+namespace {
+
+// negacyclic a (*) S, S binary
+void mul_binary(const uint64_t *a, const uint64_t *s, uint64_t *out) {
+    std::memset(out, 0, POLY_N * 8);
+    for (int j = 0; j < POLY_N; j++) {
+        if (!s[j]) continue;
+        for (int k = 0; k < j; k++) out[k] -= a[k + POLY_N - j];
+        for (int k = j; k < POLY_N; k++) out[k] += a[k - j];
+    }
+}
+
+void keygen(fhs_client *ck) {
+    Rng r{mix(ck->seed, 1)};
+    ck->lwe_sk.resize(LWE_N);
+    ck->glwe_sk.resize(POLY_N);
+    for (auto &b : ck->lwe_sk) b = r.next() >> 63;
+    for (auto &b : ck->glwe_sk) b = r.next() >> 63;
+    ck->bsk.assign((size_t)LWE_N * 4 * POLY_N, 0);
+    ck->ksk.assign((size_t)BIG_N * KS_LEVEL * SMALL_CT, 0);
+    const uint64_t qmask = ~((1ull << BSK_QUANT_BITS) - 1), qhalf = 1ull << (BSK_QUANT_BITS - 1);
+    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    // bootstrapping key: GGSW_i(lwe_sk[i]) with one level of base 2^23, on the 58-bit torus grid
+    auto bsk_work = [&](unsigned tid) {
+        std::vector<uint64_t> prod(POLY_N);
+        for (int i = tid; i < LWE_N; i += nt) {
+            Rng g{mix(ck->seed, 1000 + i)};
+            for (int row = 0; row < 2; row++) {
+                uint64_t *mask = ck->bsk.data() + (((size_t)i * 2 + row) * 2 + 0) * POLY_N;
+                uint64_t *body = mask + POLY_N;
+                for (int n = 0; n < POLY_N; n++) mask[n] = g.next() & qmask;
+                mul_binary(mask, ck->glwe_sk.data(), prod.data());
+                for (int n = 0; n < POLY_N; n++) {
+                    uint64_t m;
+                    if (row == 0) m = (uint64_t)0 - ((ck->lwe_sk[i] * ck->glwe_sk[n]) << (64 - PBS_BASE_LOG));
+                    else m = n == 0 ? ck->lwe_sk[i] << (64 - PBS_BASE_LOG) : 0;
+                    body[n] = (prod[n] + g.noise(GLWE_NOISE) + m + qhalf) & qmask;
+                }
+            }
+        }
+    };
+    // keyswitching key: ksk[i][l] = LWE_small(glwe_sk[i] * 2^(64 - 3(l+1)))
+    auto ksk_work = [&](unsigned tid) {
+        for (int i = tid; i < BIG_N; i += nt) {
+            Rng g{mix(ck->seed, 100000 + i)};
+            for (int l = 0; l < KS_LEVEL; l++) {
+                uint64_t *ct = ck->ksk.data() + ((size_t)i * KS_LEVEL + l) * SMALL_CT;
+                uint64_t acc = 0;
+                for (int j = 0; j < LWE_N; j++) {
+                    ct[j] = g.next();
+                    acc += ct[j] * ck->lwe_sk[j];
+                }
+                ct[LWE_N] = acc + g.noise(LWE_NOISE) + (ck->glwe_sk[i] << (64 - KS_BASE_LOG * (l + 1)));
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] { bsk_work(t); ksk_work(t); });
+    for (auto &x : th) x.join();
+}
+
+void encrypt_block(fhs_client *ck, uint64_t m, uint64_t *ct) {
+    uint64_t acc = 0;
+    for (int j = 0; j < BIG_N; j++) {
+        ct[j] = ck->enc_rng.next();
+        acc += ct[j] * ck->glwe_sk[j];
+    }
+    ct[BIG_N] = acc + ck->enc_rng.noise(GLWE_NOISE) + (m << DELTA_LOG);
+}
+uint64_t decrypt_block(const fhs_client *ck, const uint64_t *ct) {
+    uint64_t acc = 0;
+    for (int j = 0; j < BIG_N; j++) acc += ct[j] * ck->glwe_sk[j];
+    const uint64_t ph = ct[BIG_N] - acc;
+    return ((ph + (1ull << (DELTA_LOG - 1))) >> DELTA_LOG) & 31;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fhs_client_create(uint64_t seed, fhs_client **out) {   // MyClientKey::from_params (client_key.rs:30-35)
+    if (!out) return FHS_ERR_ARG;
+    fhs_client *ck = new (std::nothrow) fhs_client();
+    if (!ck) return FHS_ERR_STATE;
+    ck->seed = seed;
+    ck->enc_rng = Rng{mix(seed, 7)};
+    keygen(ck);
+    *out = ck;
+    return FHS_OK;
+}
+void fhs_client_destroy(fhs_client *ck) { delete ck; }
+const uint64_t *fhs_client_bsk(const fhs_client *ck) { return ck ? ck->bsk.data() : nullptr; }
+const uint64_t *fhs_client_ksk(const fhs_client *ck) { return ck ? ck->ksk.data() : nullptr; }
+
+int fhs_client_encrypt_char(fhs_client *ck, uint8_t v, uint64_t *blocks) {   // FheAsciiChar::encrypt (fheasciichar.rs:27-29)
+    if (!ck || !blocks) return FHS_ERR_ARG;
+    for (int b = 0; b < 4; b++) encrypt_block(ck, (v >> (2 * b)) & 3, blocks + (size_t)b * BIG_CT);
+    return FHS_OK;
+}
+int fhs_client_decrypt_char(const fhs_client *ck, const uint64_t *blocks, uint8_t *out) {   // decrypt::<u8> (:31-33)
+    if (!ck || !blocks || !out) return FHS_ERR_ARG;
+    unsigned v = 0;
+    for (int b = 0; b < 4; b++) v += (unsigned)(decrypt_block(ck, blocks + (size_t)b * BIG_CT) & 15) << (2 * b);
+    *out = (uint8_t)(v & 255);
+    return FHS_OK;
+}
+int fhs_client_encrypt_str(fhs_client *ck, const char *s, size_t len, size_t padding, uint64_t *out) {   // encrypt (:45-65)
+    if (!ck || (len && !s) || !out) return FHS_ERR_ARG;
+    for (size_t i = 0; i < len; i++)
+        if ((unsigned char)s[i] >= 128 || s[i] == 0) return FHS_ERR_ARG;   // the reference asserts ASCII, no NUL (:52-55)
+    for (size_t i = 0; i < len + padding; i++)
+        fhs_client_encrypt_char(ck, i < len ? (uint8_t)s[i] : 0, out + i * FHS_CHAR_WORDS);
+    return FHS_OK;
+}
+int fhs_client_decrypt_str(const fhs_client *ck, const uint64_t *chars, size_t n, char *out, size_t *out_len) {   // decrypt (:89-106)
+    if (!ck || (n && !chars) || !out || !out_len) return FHS_ERR_ARG;
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t v;
+        fhs_client_decrypt_char(ck, chars + i * FHS_CHAR_WORDS, &v);
+        if (v == 0) break;   // truncate at the first NUL (:91-96)
+        out[k++] = (char)v;
+    }
+    *out_len = k;
+    return FHS_OK;
+}
+int fhs_client_secret_keys(const fhs_client *ck, uint64_t *lwe_sk, uint64_t *glwe_sk) {
+    if (!ck || !lwe_sk || !glwe_sk) return FHS_ERR_ARG;
+    std::memcpy(lwe_sk, ck->lwe_sk.data(), LWE_N * 8);
+    std::memcpy(glwe_sk, ck->glwe_sk.data(), POLY_N * 8);
+    return FHS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,405 @@
+#include "engine.h"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+
+namespace fhs {
+
+namespace {
+constexpr size_t POOL_STRIDE = 2050;        // u64 words per pooled block (16-byte aligned rows)
+constexpr size_t POOL_CHUNK_BLOCKS = 2048;  // 33.6 MB per hipMalloc
+}  // namespace
+
+int Engine::on_key_loaded() {
+    if (!d_luts_) {
+        std::vector<uint64_t> host((size_t)LUT_COUNT * POLY_N);
+        for (int id = 0; id < LUT_COUNT; id++) make_lut_poly(id, host.data() + (size_t)id * POLY_N);
+        hipError_t e = hipMalloc(&d_luts_, host.size() * 8);
+        if (e != hipSuccess) return ctx.hip_fail(e, "hipMalloc luts");
+        e = hipMemcpy(d_luts_, host.data(), host.size() * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return ctx.hip_fail(e, "copy luts");
+    }
+    return 0;
+}
+
+void Engine::shutdown() {
+    if (ctx.stream) (void)hipStreamSynchronize(ctx.stream);
+    for (void *c : chunks_) (void)hipFree(c);
+    chunks_.clear();
+    free_blocks_.clear();
+    if (d_luts_) (void)hipFree(d_luts_);
+    d_luts_ = nullptr;
+    plan_buf_.release();
+    batch_in_.release();
+    ctx.shutdown();
+}
+
+uint64_t *Engine::alloc_block() {
+    if (free_blocks_.empty()) {
+        void *c = nullptr;
+        if (hipMalloc(&c, POOL_CHUNK_BLOCKS * POOL_STRIDE * 8) != hipSuccess) return nullptr;
+        chunks_.push_back(c);
+        uint64_t *base = static_cast<uint64_t *>(c);
+        for (size_t i = POOL_CHUNK_BLOCKS; i-- > 0;) free_blocks_.push_back(base + i * POOL_STRIDE);
+    }
+    uint64_t *p = free_blocks_.back();
+    free_blocks_.pop_back();
+    live_dev_blocks_++;
+    return p;
+}
+void Engine::free_block(uint64_t *p) {
+    free_blocks_.push_back(p);
+    live_dev_blocks_--;
+}
+
+Bid Engine::new_node() {
+    Bid id;
+    if (!free_nodes_.empty()) {
+        id = free_nodes_.back();
+        free_nodes_.pop_back();
+    } else {
+        id = (Bid)nodes_.size();
+        nodes_.emplace_back();
+    }
+    BlockNode &n = nodes_[id];
+    n = BlockNode();
+    n.refs = 1;
+    return id;
+}
+
+void Engine::retain(Bid b) { nodes_[b].refs++; }
+
+void Engine::release(Bid b) {
+    // iterative: chains of pending nodes can be tens of thousands deep (as-written `len`)
+    std::vector<Bid> stack{b};
+    while (!stack.empty()) {
+        Bid id = stack.back();
+        stack.pop_back();
+        BlockNode &n = nodes_[id];
+        if (--n.refs > 0) continue;
+        if (n.kind == BlockNode::MAT && n.dev) free_block(n.dev);
+        if (n.kind == BlockNode::PBS && n.src) stack.push_back(n.src);
+        if (n.kind == BlockNode::LIN)
+            for (const Term &t : n.terms) stack.push_back(t.blk);
+        n.terms.clear();
+        n.terms.shrink_to_fit();
+        n.kind = BlockNode::FREE;
+        n.dev = nullptr;
+        n.src = 0;
+        free_nodes_.push_back(id);
+    }
+}
+
+Bid Engine::triv(int v) {
+    Bid id = new_node();
+    nodes_[id].kind = BlockNode::TRIV;
+    nodes_[id].triv = (uint8_t)(v & 31);
+    return id;
+}
+
+Bid Engine::from_host(const uint64_t *ct) {
+    uint64_t *d = alloc_block();
+    if (!d) return 0;
+    if (hipMemcpyAsync(d, ct, BIG_CT * 8, hipMemcpyHostToDevice, ctx.stream) != hipSuccess) {
+        free_block(d);
+        return 0;
+    }
+    Bid id = new_node();
+    nodes_[id].kind = BlockNode::MAT;
+    nodes_[id].dev = d;
+    return id;
+}
+
+Bid Engine::from_device(const uint64_t *d_ct) {
+    uint64_t *d = alloc_block();
+    if (!d) return 0;
+    if (hipMemcpyAsync(d, d_ct, BIG_CT * 8, hipMemcpyDeviceToDevice, ctx.stream) != hipSuccess) {
+        free_block(d);
+        return 0;
+    }
+    Bid id = new_node();
+    nodes_[id].kind = BlockNode::MAT;
+    nodes_[id].dev = d;
+    return id;
+}
+
+// sum(coef*blk) + konst.  Trivial terms fold into the constant, nested LINs are flattened and
+// duplicate blocks merged, so a LIN only ever refers to MAT or PBS nodes.
+Bid Engine::lin(const Term *terms, size_t n, int konst) {
+    int64_t k = konst;
+    std::vector<Term> flat;
+    auto add = [&](int64_t c, Bid b) {
+        if (c == 0) return;
+        for (Term &t : flat)
+            if (t.blk == b) { t.coef += c; return; }
+        flat.push_back({c, b});
+    };
+    for (size_t i = 0; i < n; i++) {
+        const int64_t c = terms[i].coef;
+        const BlockNode &s = nodes_[terms[i].blk];
+        if (c == 0) continue;
+        if (s.kind == BlockNode::TRIV) k += c * s.triv;
+        else if (s.kind == BlockNode::LIN) {
+            k += c * s.konst;
+            for (const Term &t : s.terms) add(c * t.coef, t.blk);
+        } else add(c, terms[i].blk);
+    }
+    flat.erase(std::remove_if(flat.begin(), flat.end(), [](const Term &t) { return t.coef == 0; }), flat.end());
+    if (flat.empty()) return triv((int)(((k % 32) + 32) % 32));
+    if (flat.size() == 1 && flat[0].coef == 1 && (((k % 32) + 32) % 32) == 0) {
+        retain(flat[0].blk);   // identity: share the block
+        return flat[0].blk;
+    }
+    Bid id = new_node();
+    uint32_t lvl = 0;
+    for (const Term &t : flat) {
+        retain(t.blk);
+        lvl = std::max(lvl, nodes_[t.blk].level);
+    }
+    BlockNode &nn = nodes_[id];
+    nn.kind = BlockNode::LIN;
+    nn.konst = (int32_t)(((k % 32) + 32) % 32);
+    nn.level = lvl;
+    nn.terms = std::move(flat);
+    return id;
+}
+
+Bid Engine::pbs(Bid x, int lut) {
+    const BlockNode &s = nodes_[x];
+    if (s.kind == BlockNode::TRIV) {   // constant folding: no PBS is executed
+        stats.pbs_folded++;
+        return triv(lut_eval(lut, s.triv));
+    }
+    const uint32_t lvl = s.level + 1;
+    retain(x);
+    Bid id = new_node();
+    BlockNode &n = nodes_[id];
+    n.kind = BlockNode::PBS;
+    n.src = x;
+    n.lut = (uint16_t)lut;
+    n.level = lvl;
+    pending_.push_back(id);
+    return id;
+}
+
+// ------------------------------------------------------------------------------------------
+// flush: plan every level on the host, upload the plan once, enqueue all launches
+// ------------------------------------------------------------------------------------------
+int Engine::flush() {
+    if (pending_.empty()) return 0;
+    if (!ctx.key_loaded) return ctx.fail(-3, "server key not loaded");
+    if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
+
+    std::map<uint32_t, std::vector<Bid>> by_level;
+    for (Bid b : pending_)
+        if (nodes_[b].kind == BlockNode::PBS) by_level[nodes_[b].level].push_back(b);
+    pending_.clear();
+    if (by_level.empty()) return 0;
+
+    struct LevelPlan { size_t first, count; };
+    std::vector<LevelPlan> levels;
+    std::vector<LinDesc> descs;
+    std::vector<LinTerm> terms;
+    std::vector<uint32_t> lut_idx;
+    std::vector<uint64_t *> out_ptrs;
+    size_t max_width = 0;
+
+    for (auto &kv : by_level) {
+        std::vector<Bid> &lv = kv.second;
+        const size_t first = descs.size();
+        for (Bid b : lv) {
+            BlockNode &n = nodes_[b];
+            const BlockNode &s = nodes_[n.src];
+            LinDesc d{};
+            d.first_term = (uint32_t)terms.size();
+            if (s.kind == BlockNode::MAT) {
+                terms.push_back({s.dev, 1});
+                d.n_terms = 1;
+                d.konst_body = 0;
+            } else if (s.kind == BlockNode::LIN) {
+                for (const Term &t : s.terms) {
+                    const BlockNode &tb = nodes_[t.blk];
+                    if (tb.kind != BlockNode::MAT || !tb.dev)
+                        return ctx.fail(-3, "internal: lincomb term not materialised at its level");
+                    terms.push_back({tb.dev, t.coef});
+                }
+                d.n_terms = (uint32_t)s.terms.size();
+                d.konst_body = (uint64_t)(s.konst & 31) << DELTA_LOG;
+            } else {
+                return ctx.fail(-3, "internal: PBS source is neither MAT nor LIN");
+            }
+            descs.push_back(d);
+            lut_idx.push_back(n.lut);
+            uint64_t *o = alloc_block();
+            if (!o) return ctx.fail(-2, "device block pool exhausted (hipMalloc failed)");
+            out_ptrs.push_back(o);
+        }
+        // commit the level: nodes become materialised, their inputs can be recycled by later levels
+        for (size_t k = 0; k < lv.size(); k++) {
+            BlockNode &n = nodes_[lv[k]];
+            const Bid src = n.src;
+            n.kind = BlockNode::MAT;
+            n.dev = out_ptrs[first + k];
+            n.src = 0;
+            n.level = 0;
+            release(src);
+        }
+        levels.push_back({first, lv.size()});
+        max_width = std::max(max_width, lv.size());
+    }
+
+    // one upload: [descs | terms | lut_idx | out_ptrs]
+    const size_t off_desc = 0;
+    const size_t off_terms = off_desc + descs.size() * sizeof(LinDesc);
+    const size_t off_lut = off_terms + terms.size() * sizeof(LinTerm);
+    const size_t off_out = (off_lut + lut_idx.size() * 4 + 15) & ~(size_t)15;
+    const size_t total = off_out + out_ptrs.size() * sizeof(uint64_t *);
+    std::vector<uint8_t> host(total);
+    std::memcpy(host.data() + off_desc, descs.data(), descs.size() * sizeof(LinDesc));
+    std::memcpy(host.data() + off_terms, terms.data(), terms.size() * sizeof(LinTerm));
+    std::memcpy(host.data() + off_lut, lut_idx.data(), lut_idx.size() * 4);
+    std::memcpy(host.data() + off_out, out_ptrs.data(), out_ptrs.size() * sizeof(uint64_t *));
+    // the previous flush may still be reading the old plan buffer: order through the stream
+    hipError_t e = plan_buf_.cap >= total ? hipSuccess : hipStreamSynchronize(ctx.stream);
+    if (e == hipSuccess) e = plan_buf_.reserve(total);
+    if (e != hipSuccess) return ctx.hip_fail(e, "plan buffer");
+    e = hipMemcpyAsync(plan_buf_.ptr, host.data(), total, hipMemcpyHostToDevice, ctx.stream);
+    if (e != hipSuccess) return ctx.hip_fail(e, "plan upload");
+    if (batch_in_.cap < max_width * BIG_CT * 8) {
+        e = hipStreamSynchronize(ctx.stream);
+        if (e == hipSuccess) e = batch_in_.reserve(max_width * BIG_CT * 8);
+        if (e != hipSuccess) return ctx.hip_fail(e, "batch buffer");
+    }
+    if (ctx.ms_buf.cap < max_width * SMALL_CT * 4) {
+        e = hipStreamSynchronize(ctx.stream);
+        if (e == hipSuccess) e = ctx.ms_buf.reserve(max_width * SMALL_CT * 4);
+        if (e != hipSuccess) return ctx.hip_fail(e, "ms buffer");
+    }
+    // pageable host memory: hipMemcpyAsync has consumed `host` when it returns
+
+    const uint8_t *dp = plan_buf_.as<uint8_t>();
+    for (const LevelPlan &lp : levels) {
+        const LinDesc *d_desc = reinterpret_cast<const LinDesc *>(dp + off_desc) + lp.first;
+        const LinTerm *d_terms = reinterpret_cast<const LinTerm *>(dp + off_terms);
+        const uint32_t *d_lut = reinterpret_cast<const uint32_t *>(dp + off_lut) + lp.first;
+        uint64_t *const *d_out = reinterpret_cast<uint64_t *const *>(dp + off_out) + lp.first;
+        e = launch_lincomb(d_desc, d_terms, batch_in_.as<uint64_t>(), (int)lp.count, ctx.stream);
+        if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
+        ctx.timer.begin(1, lp.count, ctx.stream);
+        e = launch_keyswitch_modswitch(batch_in_.as<uint64_t>(), ctx.d_ksk, ctx.ms_buf.as<uint32_t>(),
+                                       (int)lp.count, ctx.stream);
+        ctx.timer.end(ctx.stream);
+        if (e != hipSuccess) return ctx.hip_fail(e, "keyswitch launch");
+        BlindRotateParams p{};
+        p.ms = ctx.ms_buf.as<uint32_t>();
+        p.lut_idx = d_lut;
+        p.luts = d_luts_;
+        p.bsk_ntt = ctx.d_bsk_ntt;
+        p.tw = ctx.tw;
+        p.crt_c = ctx.crt_c;
+        p.out = nullptr;
+        p.out_ptrs = d_out;
+        p.B = (int)lp.count;
+        ctx.timer.begin(0, lp.count, ctx.stream);
+        e = launch_blind_rotate(p, ctx.stream);
+        ctx.timer.end(ctx.stream);
+        if (e != hipSuccess) return ctx.hip_fail(e, "blind_rotate launch");
+        stats.pbs_executed += lp.count;
+        stats.levels += 1;
+        stats.max_level_width = std::max<uint64_t>(stats.max_level_width, lp.count);
+    }
+    return 0;
+}
+
+int Engine::materialize_lin(Bid b) {
+    BlockNode &n = nodes_[b];
+    if (n.kind != BlockNode::LIN) return 0;
+    std::vector<LinTerm> terms;
+    for (const Term &t : n.terms) {
+        const BlockNode &tb = nodes_[t.blk];
+        if (tb.kind != BlockNode::MAT) return ctx.fail(-3, "internal: lincomb term pending after flush");
+        terms.push_back({tb.dev, t.coef});
+    }
+    LinDesc d{0, (uint32_t)terms.size(), (uint64_t)(n.konst & 31) << DELTA_LOG};
+    const size_t total = sizeof(LinDesc) + terms.size() * sizeof(LinTerm);
+    std::vector<uint8_t> host(total);
+    std::memcpy(host.data(), &d, sizeof(d));
+    std::memcpy(host.data() + sizeof(d), terms.data(), terms.size() * sizeof(LinTerm));
+    hipError_t e = hipStreamSynchronize(ctx.stream);   // plan_buf_ may be in use by queued launches
+    if (e == hipSuccess) e = plan_buf_.reserve(total);
+    if (e == hipSuccess) e = hipMemcpyAsync(plan_buf_.ptr, host.data(), total, hipMemcpyHostToDevice, ctx.stream);
+    if (e != hipSuccess) return ctx.hip_fail(e, "materialize upload");
+    uint64_t *o = alloc_block();
+    if (!o) return ctx.fail(-2, "device block pool exhausted");
+    e = launch_lincomb(plan_buf_.as<LinDesc>(),
+                       reinterpret_cast<const LinTerm *>(plan_buf_.as<uint8_t>() + sizeof(LinDesc)), o, 1,
+                       ctx.stream);
+    if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
+    std::vector<Term> old;
+    old.swap(n.terms);
+    n.kind = BlockNode::MAT;
+    n.dev = o;
+    n.level = 0;
+    for (const Term &t : old) release(t.blk);
+    return 0;
+}
+
+int Engine::read_block(Bid b, uint64_t *host_out) {
+    int rc = flush();
+    if (rc) return rc;
+    if (nodes_[b].kind == BlockNode::TRIV) {
+        std::memset(host_out, 0, BIG_CT * 8);
+        host_out[BIG_N] = (uint64_t)nodes_[b].triv << DELTA_LOG;
+        return 0;
+    }
+    if (nodes_[b].kind == BlockNode::LIN && (rc = materialize_lin(b))) return rc;
+    if (nodes_[b].kind != BlockNode::MAT) return ctx.fail(-3, "internal: block not materialised");
+    hipError_t e = hipMemcpyAsync(host_out, nodes_[b].dev, BIG_CT * 8, hipMemcpyDeviceToHost, ctx.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx.stream);
+    if (e != hipSuccess) return ctx.hip_fail(e, "download");
+    return 0;
+}
+
+int Engine::copy_block_to_device(Bid b, uint64_t *d_out) {
+    int rc = flush();
+    if (rc) return rc;
+    hipError_t e;
+    if (nodes_[b].kind == BlockNode::TRIV) {
+        e = hipMemsetAsync(d_out, 0, BIG_CT * 8, ctx.stream);
+        const uint64_t body = (uint64_t)nodes_[b].triv << DELTA_LOG;
+        if (e == hipSuccess) e = hipMemcpyAsync(d_out + BIG_N, &body, 8, hipMemcpyHostToDevice, ctx.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx.stream);
+    } else {
+        if (nodes_[b].kind == BlockNode::LIN && (rc = materialize_lin(b))) return rc;
+        if (nodes_[b].kind != BlockNode::MAT) return ctx.fail(-3, "internal: block not materialised");
+        e = hipMemcpyAsync(d_out, nodes_[b].dev, BIG_CT * 8, hipMemcpyDeviceToDevice, ctx.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx.stream);
+    }
+    if (e != hipSuccess) return ctx.hip_fail(e, "export");
+    return 0;
+}
+
+uint64_t Engine::new_char(const Bid b[4]) {
+    uint64_t h;
+    if (!free_chars_.empty()) {
+        h = free_chars_.back();
+        free_chars_.pop_back();
+    } else {
+        chars_.emplace_back();
+        h = chars_.size();
+    }
+    CharRec &c = chars_[h - 1];
+    for (int i = 0; i < 4; i++) c.b[i] = b[i];
+    c.used = true;
+    return h;
+}
+
+void Engine::free_char(uint64_t h) {
+    CharRec &c = chars_[h - 1];
+    for (int i = 0; i < 4; i++) release(c.b[i]);
+    c.used = false;
+    free_chars_.push_back(h);
+}
+
+}  // namespace fhs

@@ -1,14 +1,116 @@
-// Lazy DAG engine over the batched-PBS context (filled in by engine.cpp).
+// Lazy DAG engine: records shortint-block operations, folds constants, levelises the pending
+// programmable bootstraps and launches each dependency level as one wide batch.
+//
+// The reference evaluates every FheAsciiChar op eagerly and blocking; behind that
+// API a GPU would only ever see 4-8 PBS at a time.  Here an op only creates nodes; flush() plans
+// all levels on the host, uploads the plan once and enqueues lincomb -> keyswitch -> blind-rotate
+// per level on one stream with no host round trip in between.
 #pragma once
+#include <cstdint>
+#include <utility>
+#include <vector>
+
 #include "context.h"
+#include "luts.h"
 
 namespace fhs {
+
+using Bid = uint32_t;   // block id; 0 is never valid
+
+struct Term {
+    int64_t coef;
+    Bid blk;
+};
+
+struct BlockNode {
+    enum Kind : uint8_t { FREE, TRIV, MAT, LIN, PBS };
+    Kind kind = FREE;
+    uint8_t triv = 0;        // TRIV: value mod 32
+    uint16_t lut = 0;        // PBS
+    int32_t konst = 0;       // LIN: constant (mod 32)
+    uint32_t level = 0;      // PBS depth since the last flush
+    uint32_t refs = 0;
+    Bid src = 0;             // PBS: input block
+    uint64_t *dev = nullptr; // MAT: device ciphertext (2049 u64)
+    std::vector<Term> terms; // LIN
+};
+
+struct EngineStats {
+    uint64_t pbs_executed = 0, pbs_folded = 0, levels = 0, max_level_width = 0;
+};
 
 class Engine {
   public:
     Context ctx;
-    int on_key_loaded() { return 0; }
-    void shutdown() { ctx.shutdown(); }
+    EngineStats stats;
+    int mode = 0;   // 0 as written, 1 fused (string layer)
+
+    int on_key_loaded();
+    void shutdown();
+
+    // ---- block graph (all returned ids carry one reference owned by the caller) ----
+    Bid triv(int v);
+    Bid from_host(const uint64_t *ct);          // uploads 2049 words
+    Bid from_device(const uint64_t *d_ct);      // D2D copy
+    Bid lin(const Term *terms, size_t n, int konst);
+    Bid pbs(Bid x, int lut);
+    void retain(Bid b);
+    void release(Bid b);
+    const BlockNode &node(Bid b) const { return nodes_[b]; }
+    bool is_triv(Bid b) const { return nodes_[b].kind == BlockNode::TRIV; }
+    int triv_val(Bid b) const { return nodes_[b].triv; }
+
+    int flush();
+    int read_block(Bid b, uint64_t *host_out);        // flushes if needed
+    int copy_block_to_device(Bid b, uint64_t *d_out);  // flushes if needed
+    uint64_t blocks_live() const { return live_dev_blocks_; }
+
+    // ---- char handles (fhs_char_t) ----
+    struct CharRec { Bid b[4]; bool used; };
+    uint64_t new_char(const Bid b[4]);   // takes over the 4 references
+    bool valid_char(uint64_t h) const { return h >= 1 && h <= chars_.size() && chars_[h - 1].used; }
+    const Bid *char_blocks(uint64_t h) const { return chars_[h - 1].b; }
+    void free_char(uint64_t h);
+
+  private:
+    std::vector<BlockNode> nodes_{1};   // slot 0 reserved
+    std::vector<Bid> free_nodes_;
+    std::vector<Bid> pending_;
+    std::vector<CharRec> chars_;
+    std::vector<uint64_t> free_chars_;
+
+    // device block pool
+    std::vector<void *> chunks_;
+    std::vector<uint64_t *> free_blocks_;
+    uint64_t live_dev_blocks_ = 0;
+    uint64_t *alloc_block();
+    void free_block(uint64_t *p);
+
+    // LUT table on device (catalogue)
+    uint64_t *d_luts_ = nullptr;
+    DevBuf plan_buf_, batch_in_;
+
+    Bid new_node();
+    int materialize_lin(Bid b);
+};
+
+// RAII reference to a block
+class Ref {
+  public:
+    Ref() = default;
+    Ref(Engine *e, Bid id) : e_(e), id_(id) {}   // adopts one reference
+    Ref(const Ref &o) : e_(o.e_), id_(o.id_) { if (id_) e_->retain(id_); }
+    Ref(Ref &&o) noexcept : e_(o.e_), id_(o.id_) { o.id_ = 0; }
+    Ref &operator=(Ref o) noexcept { std::swap(e_, o.e_); std::swap(id_, o.id_); return *this; }
+    ~Ref() { if (id_) e_->release(id_); }
+    Bid id() const { return id_; }
+    Engine *engine() const { return e_; }
+    Bid detach() { Bid t = id_; id_ = 0; return t; }   // caller takes the reference
+    explicit operator bool() const { return id_ != 0; }
+
+  private:
+    Engine *e_ = nullptr;
+    Bid id_ = 0;
 };
 
 }  // namespace fhs

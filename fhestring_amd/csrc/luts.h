@@ -1,0 +1,84 @@
+// LUT catalogue of the radix layer: name -> f(v), v in [0,16).  Same functions as the oracle's
+// table (oracle/radix.py LUTS) so that both sides bootstrap with identical polynomials.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace fhs {
+
+enum LutId : uint16_t {
+    LUT_EQ_BIV = 0, LUT_NE_BIV, LUT_AND_BIV, LUT_OR_BIV, LUT_IS4, LUT_NZ, LUT_MSG, LUT_CARRY, LUT_SIGN,
+    LUT_CMP_LT, LUT_CMP_LE, LUT_CMP_GT, LUT_CMP_GE, LUT_SEL_T, LUT_SEL_F,
+    LUT_EQ_C0, LUT_EQ_C1, LUT_EQ_C2, LUT_EQ_C3, LUT_NE_C0, LUT_NE_C1, LUT_NE_C2, LUT_NE_C3,
+    // fused-mode helpers (single-block flags, wide fan-in sums)
+    LUT_IS1, LUT_IS2, LUT_IS3, LUT_IS5, LUT_IS6, LUT_IS7, LUT_IS8, LUT_IS9, LUT_IS10, LUT_IS11, LUT_IS12,
+    LUT_IS13, LUT_IS14, LUT_IS15,
+    LUT_IS0,           // v == 0
+    LUT_HI2,           // v >> 2 (same as carry, kept for readability)
+    LUT_SEL_T_FLAG,    // 4*cond + x -> cond ? x : 0 with x a flag (same table as SEL_T)
+    LUT_MUX2,          // 2*cond + x (x in {0,1}) helper: v -> (v>>1) ? (v&1) : 0
+    LUT_LE10,          // v <= 10 (low nibble of 'P'..'Z' / 'p'..'z')
+    LUT_CASEFLAG,      // v = (h_a + lo_nz) + 4*(h_b + lo_le10) -> letter-of-that-case flag
+    LUT_COUNT
+};
+
+inline int sel_sign(int v) {   // v = 4*s_hi + s_lo, s in {0:lt, 1:eq, 2:gt}; most significant decides
+    const int hi = v >> 2, lo = v & 3;
+    return hi != 1 ? hi : lo;
+}
+
+// plaintext function of a LUT on v in [0,16); result is a block value (mod 32)
+inline int lut_function(int id, int v) {
+    switch (id) {
+        case LUT_EQ_BIV: return (v >> 2) == (v & 3);
+        case LUT_NE_BIV: return (v >> 2) != (v & 3);
+        case LUT_AND_BIV: return (v >> 2) & (v & 3);
+        case LUT_OR_BIV: return (v >> 2) | (v & 3);
+        case LUT_IS4: return v == 4;
+        case LUT_NZ: return v != 0;
+        case LUT_MSG: return v & 3;
+        case LUT_CARRY: return (v >> 2) & 3;
+        case LUT_HI2: return (v >> 2) & 3;
+        case LUT_SIGN: return v != 0;
+        case LUT_CMP_LT: return sel_sign(v) == 0;
+        case LUT_CMP_LE: return sel_sign(v) == 0 || sel_sign(v) == 1;
+        case LUT_CMP_GT: return sel_sign(v) == 2;
+        case LUT_CMP_GE: return sel_sign(v) == 1 || sel_sign(v) == 2;
+        case LUT_SEL_T: case LUT_SEL_T_FLAG: return (v >> 2) ? (v & 3) : 0;
+        case LUT_SEL_F: return (v >> 2) ? 0 : (v & 3);
+        case LUT_IS0: return v == 0;
+        case LUT_MUX2: return (v >> 1) ? (v & 1) : 0;
+        case LUT_LE10: return v <= 10;
+        case LUT_CASEFLAG: return ((v & 3) == 2) || ((v >> 2) == 2);
+        default: break;
+    }
+    if (id >= LUT_EQ_C0 && id <= LUT_EQ_C3) return v == id - LUT_EQ_C0;
+    if (id >= LUT_NE_C0 && id <= LUT_NE_C3) return v != id - LUT_NE_C0;
+    if (id >= LUT_IS1 && id <= LUT_IS3) return v == 1 + (id - LUT_IS1);
+    if (id >= LUT_IS5 && id <= LUT_IS15) return v == 5 + (id - LUT_IS5);
+    return 0;
+}
+inline int lut_is_k(int k) {   // LUT id of v -> (v == k), k in [0,15]
+    if (k == 0) return LUT_IS0;
+    if (k == 4) return LUT_IS4;
+    if (k <= 3) return LUT_IS1 + (k - 1);
+    return LUT_IS5 + (k - 5);
+}
+
+// value of a PBS on a plaintext v in [0,32), padding-bit (negacyclic) rule included
+inline int lut_eval(int id, int v) {
+    v &= 31;
+    return v < 16 ? (lut_function(id, v) & 31) : ((-lut_function(id, v - 16)) & 31);
+}
+
+// LUT body polynomial (SURVEY.md Appendix A "LUT generation"): 16 boxes of 128, rotated by half a box
+inline void make_lut_poly(int id, uint64_t *lut /*[2048]*/) {
+    const int N = 2048, box = N / 16, half = box / 2;
+    std::vector<uint64_t> tmp(N);
+    for (int x = 0; x < 16; x++)
+        for (int t = 0; t < box; t++) tmp[x * box + t] = (uint64_t)(lut_function(id, x) & 31) << 59;
+    for (int i = 0; i < N - half; i++) lut[i] = tmp[i + half];
+    for (int t = 0; t < half; t++) lut[N - half + t] = (uint64_t)0 - tmp[t];
+}
+
+}  // namespace fhs

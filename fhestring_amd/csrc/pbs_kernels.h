@@ -40,7 +40,8 @@ struct BlindRotateParams {
     const double *bsk_ntt;    // [742][row 2][col 2][prime 2][32][64], pre-scaled by N^-1
     NttTables tw;
     double crt_c;             // p0^-1 mod p1, centred
-    uint64_t *out;            // [B][2049]
+    uint64_t *out;            // [B][2049] dense output, or
+    uint64_t *const *out_ptrs; // [B] per-ciphertext output blocks (used when non-null)
     int B;
 };
 

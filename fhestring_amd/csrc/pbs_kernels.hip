@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
     }
 
     // ---- sample extract (coefficient 0): a'[0] = A[0], a'[n] = -A[N-n], b' = B[0] ----
-    uint64_t *out = P.out + (size_t)ct * BIG_CT;
+    uint64_t *out = P.out_ptrs ? P.out_ptrs[ct] : P.out + (size_t)ct * BIG_CT;
     if (q == 0) {
         if (j == 0) {
 #pragma unroll

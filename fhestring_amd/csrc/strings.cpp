@@ -1,0 +1,526 @@
+#include "strings.h"
+
+#include <algorithm>
+
+#include "../../include/fhestring_hip.h"
+
+namespace fhs {
+
+static size_t adjust_end_of_pattern(size_t e) { return e == 0 ? 1 : e; }   // utils.rs:106-112
+
+FStr Strings::clear(const char *s, size_t n) const {
+    FStr r;
+    for (size_t i = 0; i < n; i++) r.push_back(t((uint8_t)s[i]));
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// as written (same op sequence as the reference; cf. oracle/strings.py)
+// ---------------------------------------------------------------------------------------------
+FStr Strings::bubble_zeroes_right(const FStr &in) {          // utils.rs:28-46
+    FStr s = in;
+    const FChar zero = t(0);
+    for (size_t pass = 0; pass < s.size(); pass++)
+        for (size_t i = 0; i + 1 < s.size(); i++) {
+            FChar swap = ch_eq(s[i], zero);
+            FChar a = ch_ite(swap, s[i + 1], s[i]);
+            FChar b = ch_ite(swap, zero, s[i + 1]);
+            s[i] = a;
+            s[i + 1] = b;
+        }
+    return s;
+}
+
+FStr Strings::to_upper(const FStr &s) {                      // mod.rs:65-84
+    if (fused()) return f_case(s, false);
+    const FChar zero = t(0), cst = t(32);
+    FStr r;
+    for (const FChar &b : s) r.push_back(ch_sub(b, ch_ite(ch_flip(ch_is_lowercase(b)), zero, cst)));
+    return r;
+}
+FStr Strings::to_lower(const FStr &s) {                      // mod.rs:110-128
+    if (fused()) return f_case(s, true);
+    const FChar zero = t(0), cst = t(32);
+    FStr r;
+    for (const FChar &b : s) r.push_back(ch_add(b, ch_ite(ch_flip(ch_is_uppercase(b)), zero, cst)));
+    return r;
+}
+
+FChar Strings::contains(const FStr &s, const FStr &needle) { // mod.rs:151-182
+    if (s.empty() && needle.empty()) return t(1);
+    if (needle.size() > s.size()) return t(0);
+    if (fused()) return f_contains(s, needle);
+    FChar result = t(0);
+    const FChar one = t(1);
+    for (size_t i = 0; i + needle.size() <= s.size(); i++) {
+        FChar cur = one;
+        for (size_t j = 0; j < needle.size(); j++) cur = ch_bitand(cur, ch_eq(s[i + j], needle[j]));
+        result = ch_bitor(result, cur);
+    }
+    return result;
+}
+
+FChar Strings::ends_with(const FStr &s, const FStr &needle) {   // mod.rs:241-288
+    if (s.empty() && needle.empty()) return t(1);
+    if (needle.size() > s.size()) return t(0);
+    FChar result = t(0);
+    const FChar one = t(1), zero = t(0);
+    for (size_t i = 0; i + needle.size() <= s.size(); i++) {
+        FChar cur = one, nonzero = one;
+        for (size_t j = 0; j < needle.size(); j++) {
+            cur = ch_bitand(cur, ch_eq(s[i + j], needle[j]));
+            nonzero = ch_bitand(nonzero, ch_ne(s[i + j], zero));
+        }
+        result = ch_ite(nonzero, cur, result);
+    }
+    return result;
+}
+
+FChar Strings::starts_with(const FStr &s, const FStr &pat) { // mod.rs:344-371
+    if (pat.size() > s.size()) return t(0);
+    if (s.empty() && pat.empty()) return t(1);
+    if (fused()) {
+        if (pat.empty()) return t(1);
+        return ch_flag(e_, window_match(s, 0, pat));
+    }
+    FChar result = t(1);
+    for (size_t i = 0; i < std::min(pat.size(), s.size()); i++) result = ch_bitand(result, ch_eq(s[i], pat[i]));
+    return result;
+}
+
+FChar Strings::is_empty(const FStr &s) {                     // mod.rs:431-451
+    if (s.empty()) return t(1);
+    const FChar zero = t(0);
+    if (fused()) {
+        std::vector<Ref> f;
+        for (const FChar &c : s)
+            for (const Ref &x : block_eq_flags(c, zero)) f.push_back(x);
+        return ch_flag(e_, and_tree(f));
+    }
+    FChar result = t(1);
+    for (const FChar &c : s) result = ch_bitand(result, ch_eq(c, zero));
+    return result;
+}
+
+FChar Strings::len(const FStr &s) {                          // mod.rs:478-493
+    const FChar zero = t(0);
+    if (s.empty()) return zero;
+    if (fused()) return f_len(s);
+    FChar result = t(0);
+    for (const FChar &c : s) result = ch_add(result, ch_ne(c, zero));
+    return result;
+}
+
+FStr Strings::repeat_clear(const FStr &s, size_t n) {        // mod.rs:517-538
+    if (n == 0) return {};
+    FStr r;
+    for (size_t k = 0; k < n; k++) r.insert(r.end(), s.begin(), s.end());
+    return bubble_zeroes_right(r);
+}
+
+FStr Strings::repeat(const FStr &s, const FChar &n) {        // mod.rs:567-591
+    const FChar zero = t(0);
+    FStr r(FHS_MAX_REPETITIONS * s.size(), zero);
+    for (size_t i = 0; i < FHS_MAX_REPETITIONS; i++) {
+        FChar flag = ch_lt(t((uint8_t)i), n);
+        for (size_t j = 0; j < s.size(); j++) r[i * s.size() + j] = ch_ite(flag, s[j], zero);
+    }
+    return bubble_zeroes_right(r);
+}
+
+FStr Strings::replace(const FStr &s, const FStr &from, const FStr &to) {   // mod.rs:624-653
+    const FChar n = t(0);
+    if (from.size() >= to.size()) return longer_from(s, from, to, n, false);
+    return shorter_from(s, from, to, n, false);
+}
+FStr Strings::replacen(const FStr &s, const FStr &from, const FStr &to, const FChar &n) {   // mod.rs:1729-1757
+    if (from.size() >= to.size()) return longer_from(s, from, to, n, true);
+    return shorter_from(s, from, to, n, true);
+}
+
+FStr Strings::longer_from(const FStr &s, const FStr &from, FStr to, const FChar &n, bool use_counter) {   // mod.rs:828-882
+    const FChar zero = t(0), one = t(1);
+    FStr data = s;
+    data.push_back(zero);                                   // :841
+    while (to.size() < from.size()) to.push_back(zero);     // :847-849
+    FChar counter = t(0);
+    FStr result = data;
+    if (from.size() <= result.size()) {
+        const size_t end = adjust_end_of_pattern(result.size() - from.size());
+        for (size_t i = 0; i < end; i++) {
+            FChar flag = one;
+            for (size_t j = 0; j < from.size(); j++) flag = ch_bitand(flag, ch_eq(from[j], data[i + j]));
+            if (use_counter) {                              // :868-872
+                counter = ch_add(counter, flag);
+                flag = ch_bitand(flag, ch_ge(n, counter));
+            }
+            for (size_t k = 0; k < to.size(); k++) result[i + k] = ch_ite(flag, to[k], result[i + k]);
+        }
+    }
+    return bubble_zeroes_right(result);                     // :881
+}
+
+FStr Strings::shorter_from(const FStr &s, const FStr &from, const FStr &to, const FChar &n, bool use_counter) {   // mod.rs:885-980
+    const FChar zero = t(0), one = t(1);
+    FStr data = s;
+    data.push_back(zero);
+    const size_t size_diff = to.size() - from.size();
+    FChar counter = t(0);
+    size_t max_len = data.empty() ? to.size() : to.size() * data.size() + data.size();
+    if (from.empty()) max_len = (data.size() + (data.size() + 1) * to.size()) + 1;
+    FStr result = data;
+    result.resize(max_len, zero);
+    FStr copy_buffer(max_len, zero);
+    FStr ignore_mask(max_len, one);
+    for (size_t i = 0; i + to.size() < result.size(); i++) {
+        FChar flag = one;
+        for (size_t j = 0; j < from.size(); j++) {
+            flag = ch_bitand(flag, ch_eq(from[j], result[i + j]));
+            flag = ch_bitand(flag, ignore_mask[i + j]);
+        }
+        if (from.empty()) flag = (i % (to.size() + 1) == 0) ? one : zero;
+        if (use_counter) {
+            counter = ch_add(counter, flag);
+            flag = ch_bitand(flag, ch_ge(n, counter));
+        }
+        for (size_t k = 0; k < max_len; k++) copy_buffer[k] = ch_ite(flag, result[k], zero);
+        for (size_t k = 0; k < to.size(); k++) {
+            result[i + k] = ch_ite(flag, to[k], result[i + k]);
+            ignore_mask[i + k] = ch_bitand(ignore_mask[i + k], ch_ite(flag, zero, one));
+        }
+        for (size_t k = i + to.size(); k < max_len; k++)
+            result[k] = ch_ite(flag, copy_buffer[k - size_diff], result[k]);
+    }
+    return result;
+}
+
+FChar Strings::rfind(const FStr &s_in, const FStr &pat) {    // mod.rs:727-790
+    const FChar one = t(1), zero = t(0);
+    FStr s = s_in;
+    s.push_back(zero);
+    FChar pos = t(FHS_MAX_FIND_LENGTH);
+    if (s.size() >= FHS_MAX_FIND_LENGTH + pat.size()) {
+        err = {FHS_ERR_LIMIT, "Maximum supported size for find reached"};
+        return zero;
+    }
+    if (pat.empty()) {
+        FChar last = zero;
+        for (size_t i = 0; i < s.size(); i++) last = ch_ite(ch_ne(s[i], zero), t((uint8_t)(i + 1)), last);
+        return last;
+    }
+    if (pat.size() > s.size()) return t(255);
+    const size_t end = adjust_end_of_pattern(s.size() - pat.size());
+    for (size_t i = 0; i < end; i++) {
+        FChar flag = one;
+        for (size_t j = 0; j < pat.size(); j++) flag = ch_bitand(flag, ch_eq(pat[j], s[i + j]));
+        pos = ch_ite(flag, t((uint8_t)i), pos);
+    }
+    return pos;
+}
+
+FChar Strings::find(const FStr &s, const FStr &pat) {        // mod.rs:1010-1053
+    if (s.empty() && pat.empty()) return t(0);
+    const FChar one = t(1);
+    FChar pos = t(FHS_MAX_FIND_LENGTH);
+    if (s.size() >= FHS_MAX_FIND_LENGTH + pat.size()) {      // :1025-1027
+        err = {FHS_ERR_LIMIT, "Maximum supported size for find reached"};
+        return t(0);
+    }
+    if (pat.size() > s.size()) return t(255);
+    for (size_t i = s.size() - pat.size() + 1; i-- > 0;) {
+        FChar flag = one;
+        if (fused()) {
+            flag = pat.empty() ? one : ch_flag(e_, window_match(s, i, pat));
+        } else {
+            for (size_t j = pat.size(); j-- > 0;) flag = ch_bitand(flag, ch_eq(pat[j], s[i + j]));
+        }
+        pos = ch_ite(flag, t((uint8_t)i), pos);
+    }
+    return pos;
+}
+
+FChar Strings::eq(const FStr &a, const FStr &b) {            // mod.rs:1122-1149
+    if (fused()) return f_eq(a, b);
+    const FChar zero = t(0), one = t(1);
+    FChar is_eq = one;
+    FChar len_ne = ch_ne(len(a), len(b));
+    for (size_t i = 0; i < std::min(a.size(), b.size()); i++) {
+        FChar same = ch_eq(a[i], b[i]);
+        FChar both0 = ch_bitand(ch_eq(a[i], zero), ch_eq(b[i], zero));
+        is_eq = ch_bitand(is_eq, ch_bitor(both0, same));
+    }
+    return ch_ite(len_ne, zero, is_eq);
+}
+FChar Strings::ne(const FStr &a, const FStr &b) {            // mod.rs:1178-1186
+    FChar r = eq(a, b);
+    if (fused()) {   // 1 - flag on the single live block, no PBS
+        Ref one = trivial_block(e_, 1);
+        return ch_flag(e_, lin(e_, {{1, &one}, {-1, &r.b[0]}}));
+    }
+    return ch_flip(r);
+}
+FChar Strings::eq_ignore_case(const FStr &a, const FStr &b) {   // mod.rs:1221-1231
+    return eq(to_lower(a), to_lower(b));
+}
+
+FStr Strings::strip_prefix(const FStr &s, const FStr &pat, FChar *found) {   // mod.rs:1261-1307
+    const FChar zero = t(0), one = t(1);
+    FStr result = s;
+    FChar flag = one;
+    const size_t end = std::min(pat.size(), result.size());
+    if (pat.size() > result.size()) {
+        *found = zero;
+        return result;
+    }
+    if (end == 0 && !pat.empty() && s.empty()) flag = zero;
+    for (size_t j = 0; j < end; j++) flag = ch_bitand(flag, ch_eq(pat[j], result[j]));
+    for (size_t j = 0; j < std::min(pat.size(), result.size()); j++) result[j] = ch_ite(flag, zero, result[j]);
+    *found = flag;
+    return bubble_zeroes_right(result);
+}
+
+FStr Strings::strip_suffix(const FStr &s_in, const FStr &needle, FChar *found) {   // mod.rs:1335-1404
+    const FChar one = t(1), zero = t(0), t255 = t(255);
+    FStr s = s_in;
+    if (needle.size() > s.size()) {
+        *found = zero;
+        return s;
+    }
+    const size_t end = s.size() - needle.size();
+    FChar pos = t(255);
+    for (size_t i = 0; i <= end; i++) {
+        FChar fnd = one, nonzero = one;
+        for (size_t j = 0; j < needle.size(); j++) {
+            fnd = ch_bitand(fnd, ch_eq(s[i + j], needle[j]));
+            nonzero = ch_bitand(nonzero, ch_ne(s[i + j], zero));
+        }
+        FChar cur = ch_ite(fnd, t((uint8_t)i), t255);
+        pos = ch_ite(nonzero, cur, pos);
+    }
+    *found = ch_ne(pos, t255);
+    for (size_t i = 0; i <= end; i++) {
+        FChar mask = ch_eq(t((uint8_t)i), pos);
+        for (size_t j = 0; j < needle.size(); j++) s[i + j] = ch_ite(mask, zero, s[i + j]);
+    }
+    return s;
+}
+
+FChar Strings::comparison(const FStr &a_in, const FStr &b_in, int cmp) {   // mod.rs:1470-1541
+    const FChar zero = t(0), t255 = t(255);
+    FStr a = a_in, b = b_in;
+    size_t min_len = std::min(a.size(), b.size());
+    FChar seen = zero, became = zero, ret = t(255);
+    if (min_len == 0) {                                      // :1490-1494
+        a.push_back(zero);
+        b.push_back(zero);
+        min_len = 1;
+    }
+    auto op = [&](const FChar &x, const FChar &y) {
+        switch (cmp) {
+            case 0: return ch_lt(x, y);
+            case 1: return ch_le(x, y);
+            case 2: return ch_gt(x, y);
+            default: return ch_ge(x, y);
+        }
+    };
+    for (size_t i = 0; i < min_len; i++) {
+        FChar c = op(a[i], b[i]);
+        seen = ch_bitor(seen, ch_ne(a[i], b[i]));
+        FChar flag = ch_bitand(seen, ch_flip(became));
+        became = ch_bitor(became, flag);
+        ret = ch_ite(flag, c, ret);
+    }
+    FChar sub_eq = ch_eq(ret, t255);
+    FChar l1 = len(a), l2 = len(b);
+    FChar leq = ch_eq(l1, l2), lgt = ch_gt(l1, l2), llt = ch_lt(l1, l2);
+    FChar by_len;
+    switch (cmp) {
+        case 3: by_len = ch_bitor(leq, lgt); break;
+        case 1: by_len = ch_bitor(leq, llt); break;
+        case 2: by_len = lgt; break;
+        default: by_len = llt; break;
+    }
+    return ch_ite(sub_eq, by_len, ret);
+}
+
+FStr Strings::concatenate(const FStr &a, const FStr &b) {    // mod.rs:1864-1875
+    FStr r = a;
+    r.insert(r.end(), b.begin(), b.end());
+    return bubble_zeroes_right(r);
+}
+
+FStr Strings::trim_end(const FStr &s) {                      // trim.rs:36-57
+    const FChar zero = t(0);
+    FChar stop = zero;
+    FStr r(s.size(), zero);
+    for (size_t i = s.size(); i-- > 0;) {
+        FChar not_ws = ch_flip(ch_is_whitespace(s[i]));
+        stop = ch_bitor(stop, ch_bitand(not_ws, ch_ne(s[i], zero)));
+        r[i] = ch_ite(stop, s[i], zero);
+    }
+    return r;
+}
+FStr Strings::trim_start(const FStr &s) {                    // trim.rs:86-115
+    const FChar zero = t(0);
+    FChar stop = zero;
+    FStr r(s.size(), zero);
+    for (size_t i = 0; i < s.size(); i++) {
+        FChar not_ws = ch_flip(ch_is_whitespace(s[i]));
+        stop = ch_bitor(stop, ch_bitand(not_ws, ch_ne(s[i], zero)));
+        r[i] = ch_ite(stop, s[i], zero);
+    }
+    return bubble_zeroes_right(r);
+}
+FStr Strings::trim(const FStr &s) { return trim_start(trim_end(s)); }   // trim.rs:146-149
+
+// ---------------------------------------------------------------------------------------------
+// fused mode: single-block 0/1 flags, sums of up to 15 flags per PBS (the carry space holds 15),
+// log_15-depth AND/OR trees.  Decrypts identically to the as-written mode.
+// ---------------------------------------------------------------------------------------------
+static Ref sum_refs(Engine *e, const Ref *r, size_t n) {
+    Term tt[16];
+    for (size_t i = 0; i < n; i++) tt[i] = {1, r[i].id()};
+    return Ref(e, e->lin(tt, n, 0));
+}
+
+Ref Strings::and_tree(std::vector<Ref> f) {
+    std::vector<Ref> cur;
+    for (Ref &x : f) {
+        if (e_->is_triv(x.id())) {
+            if ((e_->triv_val(x.id()) & 1) == 0) return trivial_block(e_, 0);
+        } else cur.push_back(x);
+    }
+    if (cur.empty()) return trivial_block(e_, 1);
+    while (cur.size() > 1) {
+        std::vector<Ref> nxt;
+        for (size_t i = 0; i < cur.size(); i += 15) {
+            const size_t n = std::min<size_t>(15, cur.size() - i);
+            if (n == 1) nxt.push_back(cur[i]);
+            else nxt.push_back(pbs(sum_refs(e_, &cur[i], n), lut_is_k((int)n)));
+        }
+        cur.swap(nxt);
+    }
+    return cur[0];
+}
+
+Ref Strings::or_tree(std::vector<Ref> f) {
+    std::vector<Ref> cur;
+    for (Ref &x : f) {
+        if (e_->is_triv(x.id())) {
+            if (e_->triv_val(x.id()) & 1) return trivial_block(e_, 1);
+        } else cur.push_back(x);
+    }
+    if (cur.empty()) return trivial_block(e_, 0);
+    while (cur.size() > 1) {
+        std::vector<Ref> nxt;
+        for (size_t i = 0; i < cur.size(); i += 15) {
+            const size_t n = std::min<size_t>(15, cur.size() - i);
+            if (n == 1) nxt.push_back(cur[i]);
+            else nxt.push_back(pbs(sum_refs(e_, &cur[i], n), LUT_NZ));
+        }
+        cur.swap(nxt);
+    }
+    return cur[0];
+}
+
+std::vector<Ref> Strings::block_eq_flags(const FChar &a, const FChar &b) {
+    std::vector<Ref> f;
+    for (int i = 0; i < 4; i++) {
+        const Ref &x = a.b[i], &y = b.b[i];
+        if (e_->is_triv(y.id())) f.push_back(pbs(x, LUT_EQ_C0 + (e_->triv_val(y.id()) & 3)));
+        else if (e_->is_triv(x.id())) f.push_back(pbs(y, LUT_EQ_C0 + (e_->triv_val(x.id()) & 3)));
+        else f.push_back(pbs(lin(e_, {{4, &x}, {1, &y}}), LUT_EQ_BIV));
+    }
+    return f;
+}
+
+Ref Strings::window_match(const FStr &s, size_t at, const FStr &pat) {
+    std::vector<Ref> f;
+    for (size_t j = 0; j < pat.size(); j++)
+        for (Ref &x : block_eq_flags(s[at + j], pat[j])) f.push_back(x);
+    return and_tree(f);
+}
+
+FChar Strings::f_contains(const FStr &s, const FStr &needle) {
+    if (needle.empty()) return t(1);
+    std::vector<Ref> w;
+    for (size_t i = 0; i + needle.size() <= s.size(); i++) w.push_back(window_match(s, i, needle));
+    return ch_flag(e_, or_tree(w));
+}
+
+// sum of 0/1 flags mod 256: groups of 15 -> (low, high) digit pair, then 4-operand radix adds
+FChar Strings::count_flags(std::vector<Ref> flags) {
+    std::vector<FChar> nums;
+    for (size_t i = 0; i < flags.size(); i += 15) {
+        const size_t n = std::min<size_t>(15, flags.size() - i);
+        Ref s = sum_refs(e_, &flags[i], n);
+        FChar c;
+        c.b[0] = pbs(s, LUT_MSG);
+        c.b[1] = n >= 4 ? pbs(s, LUT_CARRY) : trivial_block(e_, 0);
+        c.b[2] = trivial_block(e_, 0);
+        c.b[3] = trivial_block(e_, 0);
+        nums.push_back(c);
+    }
+    if (nums.empty()) return t(0);
+    while (nums.size() > 1) {
+        std::vector<FChar> nxt;
+        for (size_t i = 0; i < nums.size(); i += 4) {
+            const size_t n = std::min<size_t>(4, nums.size() - i);
+            if (n == 1) { nxt.push_back(nums[i]); continue; }
+            FChar r;
+            Ref carry;
+            for (int blk = 0; blk < 4; blk++) {
+                Term tt[8];
+                size_t k = 0;
+                for (size_t u = 0; u < n; u++) tt[k++] = {1, nums[i + u].b[blk].id()};
+                if (carry) tt[k++] = {1, carry.id()};
+                Ref sm(e_, e_->lin(tt, k, 0));   // <= 4*3 + 3 = 15
+                r.b[blk] = pbs(sm, LUT_MSG);
+                if (blk < 3) carry = pbs(sm, LUT_CARRY);
+            }
+            nxt.push_back(r);
+        }
+        nums.swap(nxt);
+    }
+    return nums[0];
+}
+
+FChar Strings::f_len(const FStr &s) {
+    std::vector<Ref> nz;
+    for (const FChar &c : s) nz.push_back(blk_nonzero_flag(c));
+    return count_flags(nz);
+}
+
+FChar Strings::f_eq(const FStr &a, const FStr &b) {
+    // (both zero) or equal == equal, so the per-position test of mod.rs:1137-1146 is a plain equality
+    std::vector<Ref> f;
+    for (size_t i = 0; i < std::min(a.size(), b.size()); i++)
+        for (Ref &x : block_eq_flags(a[i], b[i])) f.push_back(x);
+    f.push_back(blk_eq_flag(f_len(a), f_len(b)));           // mod.rs:1133-1135,1148
+    return ch_flag(e_, and_tree(f));
+}
+
+// 'A'..'Z' = 0x41..0x5A (high nibble 4: low in 1..15; high nibble 5: low in 0..10); 'a'..'z' = +0x20
+Ref Strings::is_upper_flag(const FChar &c, bool lower) {
+    Ref lo = lin(e_, {{1, &c.b[0]}, {4, &c.b[1]}});
+    Ref hi = lin(e_, {{1, &c.b[2]}, {4, &c.b[3]}});
+    Ref ha = pbs(hi, lut_is_k(lower ? 6 : 4));
+    Ref hb = pbs(hi, lut_is_k(lower ? 7 : 5));
+    Ref lnz = pbs(lo, LUT_NZ);
+    Ref lle = pbs(lo, LUT_LE10);
+    return pbs(lin(e_, {{1, &ha}, {1, &lnz}, {4, &hb}, {4, &lle}}), LUT_CASEFLAG);
+}
+
+// the case delta 32 = digit 2 of block 2; letters of the source case never carry/borrow out of it
+FStr Strings::f_case(const FStr &s, bool to_lower) {
+    FStr r;
+    for (const FChar &c : s) {
+        Ref f = is_upper_flag(c, /*lower=*/!to_lower);
+        FChar o = c;
+        o.b[2] = lin(e_, {{1, &c.b[2]}, {to_lower ? 2 : -2, &f}});
+        r.push_back(o);
+    }
+    return r;
+}
+
+}  // namespace fhs

@@ -1,0 +1,68 @@
+// String layer: host-side mirror of the reference's MyServerKey methods
+// (src/server_key/mod.rs, src/server_key/trim.rs, src/utils.rs:28-112) as DAG constructors.
+#pragma once
+#include <vector>
+
+#include "radix.h"
+
+namespace fhs {
+
+using FStr = std::vector<FChar>;   // FheString.bytes (fhestring.rs:6-9); cst = trivial 32 (:24)
+
+struct StrError {
+    int code = 0;   // FHS_ERR_LIMIT for the reference's panic!()
+    const char *msg = "";
+};
+
+class Strings {
+  public:
+    explicit Strings(Engine *e) : e_(e) {}
+    StrError err;
+
+    FStr clear(const char *s, size_t n) const;   // the `_clear` twins trivially encrypt the pattern
+    FChar contains(const FStr &s, const FStr &needle);
+    FChar starts_with(const FStr &s, const FStr &pat);
+    FChar ends_with(const FStr &s, const FStr &needle);
+    FChar find(const FStr &s, const FStr &pat);
+    FChar rfind(const FStr &s, const FStr &pat);
+    FChar is_empty(const FStr &s);
+    FChar len(const FStr &s);
+    FChar eq(const FStr &a, const FStr &b);
+    FChar ne(const FStr &a, const FStr &b);
+    FChar eq_ignore_case(const FStr &a, const FStr &b);
+    FChar comparison(const FStr &a, const FStr &b, int cmp);   // 0 lt, 1 le, 2 gt, 3 ge
+    FStr to_upper(const FStr &s);
+    FStr to_lower(const FStr &s);
+    FStr replace(const FStr &s, const FStr &from, const FStr &to);
+    FStr replacen(const FStr &s, const FStr &from, const FStr &to, const FChar &n);
+    FStr repeat(const FStr &s, const FChar &n);
+    FStr repeat_clear(const FStr &s, size_t n);
+    FStr concatenate(const FStr &a, const FStr &b);
+    FStr strip_prefix(const FStr &s, const FStr &pat, FChar *found);
+    FStr strip_suffix(const FStr &s, const FStr &pat, FChar *found);
+    FStr trim_end(const FStr &s);
+    FStr trim_start(const FStr &s);
+    FStr trim(const FStr &s);
+    FStr bubble_zeroes_right(const FStr &s);
+
+  private:
+    Engine *e_;
+    bool fused() const { return e_->mode == 1; }
+    FChar t(uint8_t v) const { return ch_trivial(e_, v); }
+    FStr longer_from(const FStr &s, const FStr &from, FStr to, const FChar &n, bool use_counter);
+    FStr shorter_from(const FStr &s, const FStr &from, const FStr &to, const FChar &n, bool use_counter);
+
+    // fused-mode helpers on single-block flags
+    Ref and_tree(std::vector<Ref> flags);
+    Ref or_tree(std::vector<Ref> flags);
+    std::vector<Ref> block_eq_flags(const FChar &a, const FChar &b);
+    Ref window_match(const FStr &s, size_t at, const FStr &pat);
+    FChar count_flags(std::vector<Ref> flags);   // sum of 0/1 flags mod 256 as a 4-block char
+    Ref is_upper_flag(const FChar &c, bool lower);
+    FChar f_contains(const FStr &s, const FStr &needle);
+    FChar f_len(const FStr &s);
+    FChar f_eq(const FStr &a, const FStr &b);
+    FStr f_case(const FStr &s, bool to_lower);
+};
+
+}  // namespace fhs

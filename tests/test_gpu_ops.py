@@ -1,0 +1,125 @@
+"""Parity of the op layers on the GPU.
+
+* FheAsciiChar boundary ops: ciphertexts bit-identical to the oracle's (same keys, same inputs,
+  same decompositions) and decrypt-equal to u8 arithmetic.
+* The reference's own test literals (tests/golden/ref_tests.json) end to end through the product:
+  client encrypt -> MyServerKey method on the MI355X -> client decrypt, in both modes.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import load_vectors, run_vector, check_vector
+
+pytestmark = pytest.mark.gpu
+VECTORS = load_vectors()
+# O(n^2 * |to|) / 48-char bubble sort as written: minutes of GPU time; opt in with FHS_SLOW=1
+SLOW = {"replace2", "repeat", "replacen"}
+
+
+@pytest.fixture(scope="module")
+def oracle_gpu(oracle_keys):
+    from fhestring_amd.api import MyServerKey
+    sk = MyServerKey.from_raw_keys(oracle_keys.bsk, oracle_keys.ksk)
+    yield sk
+    sk.close()
+
+
+def test_char_ops_bit_exact_vs_oracle(oracle_gpu, oracle_keys, oracle_sk):
+    from oracle import radix
+    sk = oracle_gpu
+    sk.set_mode(0)
+    eng = radix.Engine(oracle_sk)
+    pairs = [(0x61, 0x7A), (0x00, 0xFF), (0xC3, 0xC3), (0x80, 0x7F), (0x41, 0x20)]
+    want, got, exp = [], [], []
+    for a, b in pairs:
+        cta, ctb = oracle_keys.encrypt_char(a), oracle_keys.encrypt_char(b)
+        oa, ob = radix.CipherChar.from_cts(cta, eng), radix.CipherChar.from_cts(ctb, eng)
+        ot = radix.CipherChar.trivial(b, eng)
+        ga, gb, gt = sk.upload_char(cta), sk.upload_char(ctb), sk.trivial(b)
+        for name, ref in [("eq", int(a == b)), ("ne", int(a != b)), ("lt", int(a < b)), ("le", int(a <= b)),
+                          ("gt", int(a > b)), ("ge", int(a >= b)), ("bitand", a & b), ("bitor", a | b),
+                          ("add", (a + b) & 255), ("sub", (a - b) & 255)]:
+            want.append(getattr(oa, name)(ob)); got.append(getattr(ga, name)(gb)); exp.append(ref)
+        want.append(oa.le(ot)); got.append(ga.le(gt)); exp.append(int(a <= b))
+        want.append(oa.eq(ot)); got.append(ga.eq(gt)); exp.append(int(a == b))
+        want.append(oa.eq(ob).flip()); got.append(ga.eq(gb).flip()); exp.append(int(a != b))
+        want.append(oa.if_then_else(ob, oa)); got.append(ga.if_then_else(gb, ga)); exp.append(b if a else a)
+        want.append(oa.ne(ob).if_then_else(oa, ot)); got.append(ga.ne(gb).if_then_else(ga, gt)); exp.append(a if a != b else b)
+    eng.materialize([blk for ch in want for blk in ch.b])
+    for w, g, e in zip(want, got, exp):
+        gc = g.download()
+        assert np.array_equal(gc, w.cts())
+        assert oracle_keys.decrypt_char(gc) == e
+    assert sk.stats()["pbs_executed"] == eng.pbs_count
+
+
+@pytest.fixture(scope="module")
+def product():
+    from fhestring_amd.api import MyClientKey
+    ck = MyClientKey(0xF5E57121)
+    sk = ck.get_server_key()
+    yield ck, sk
+    sk.close()
+    ck.close()
+
+
+def _env(ck, sk):
+    enc_s = lambda t, pad: ck.encrypt(t, pad, None, sk)
+    enc_p = lambda t: ck.encrypt_no_padding(t, sk)
+    enc_c = lambda v: ck.encrypt_char(v, sk)
+    return sk, enc_s, enc_p, enc_c, ck.decrypt, ck.decrypt_char
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["as_written", "fused"])
+@pytest.mark.parametrize("v", VECTORS, ids=[v["name"] for v in VECTORS])
+def test_golden_vectors_on_gpu(product, v, mode):
+    ck, sk = product
+    sk.set_mode(mode)
+    if v["name"] in SLOW and not os.environ.get("FHS_SLOW"):
+        pytest.skip("as-written O(n^2)/O(n^3) op: set FHS_SLOW=1")
+    if mode == 1 and v["op"] not in ("contains", "starts_with", "is_empty", "len", "eq", "eq_ignore_case",
+                                     "to_upper", "to_lower", "find"):
+        pytest.skip("no fused formulation yet: identical to as-written")
+    env = _env(ck, sk)
+    if "expected_panic" in v:
+        with pytest.raises(OverflowError, match=v["expected_panic"]):
+            run_vector(v, *env)
+        return
+    check_vector(v, run_vector(v, *env))
+
+
+def test_fused_and_as_written_agree_on_random_strings(product):
+    import random
+    ck, sk = product
+    rnd = random.Random(5)
+    for _ in range(3):
+        n, m = rnd.randint(5, 12), rnd.randint(1, 3)
+        s = "".join(chr(rnd.randint(0x20, 0x7E)) for _ in range(n))
+        off = rnd.randint(0, n - m)
+        pat = s[off:off + m] if rnd.random() < 0.5 else "".join(chr(rnd.randint(0x20, 0x7E)) for _ in range(m))
+        res = []
+        for mode in (0, 1):
+            sk.set_mode(mode)
+            es = ck.encrypt(s, 1, None, sk)
+            res.append((ck.decrypt_char(sk.contains_clear(es, pat)),
+                        ck.decrypt_char(sk.len(es)),
+                        ck.decrypt(sk.to_upper(es))))
+        assert res[0] == res[1] == (int(pat in s), len(s), s.upper())
+
+
+def test_edge_cases_match_reference_semantics(product):
+    ck, sk = product
+    sk.set_mode(1)
+    e = lambda t, pad=1: ck.encrypt(t, pad, None, sk)
+    p = lambda t: ck.encrypt_no_padding(t, sk)
+    assert ck.decrypt_char(sk.contains(e("", 0), p(""))) == 1        # both empty (mod.rs:157-159)
+    assert ck.decrypt_char(sk.contains(e("ab", 0), p("abcd"))) == 0  # needle longer (mod.rs:180)
+    assert ck.decrypt_char(sk.find(e("ab", 0), p("abcd"))) == 255    # mod.rs:1051
+    assert ck.decrypt_char(sk.len(e("", 3))) == 0
+    assert ck.decrypt_char(sk.eq(e("abc", 1), e("abc", 5))) == 1     # different paddings (main.rs:637)
+    assert ck.decrypt_char(sk.eq(e("abc", 1), e("abd", 1))) == 0
+    assert ck.decrypt_char(sk.ne(e("abc", 1), e("ab", 2))) == 1
+    with pytest.raises(OverflowError):
+        sk.find(e("a" * 257, 1), p("abc"))                            # mod.rs:1025-1027

@@ -1,0 +1,25 @@
+"""Quick kernel timing: python tools/time_pbs.py [B ...] (GPU box)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+import fhestring_amd
+from oracle import core, radix   # keys/LUTs only (this is a dev tool, not the product path)
+
+K = core.Keys(0xF5E57121)
+ctx = fhestring_amd.Context(0)
+t = time.time(); ctx.load_server_key(K.bsk, K.ksk); print("key load %.2fs" % (time.time() - t))
+luts = np.stack([radix.lut_poly("msg"), radix.lut_poly("eq_biv")])
+rng = np.random.default_rng(0)
+for B in [int(a) for a in sys.argv[1:]] or [64, 512, 1024, 2048]:
+    cts = rng.integers(0, 2**64, (B, core.BIG_CT), dtype=np.uint64)
+    idx = (np.arange(B) % 2).astype(np.uint32)
+    ctx.pbs_batch(cts, idx, luts)
+    ctx.kernel_timing(reset=True)
+    t = time.time()
+    for _ in range(3):
+        ctx.pbs_batch(cts, idx, luts)
+    wall = (time.time() - t) / 3
+    kt = ctx.kernel_timing(reset=True)
+    print("B=%5d  blind_rotate %.2f ms  keyswitch %.3f ms  wall %.1f ms  -> %.0f PBS/s (kernels)" % (
+        B, kt["blind_rotate_ms"], kt["keyswitch_ms"], wall * 1e3,
+        B / ((kt["blind_rotate_ms"] + kt["keyswitch_ms"]) * 1e-3)))
