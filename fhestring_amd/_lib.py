@@ -115,6 +115,10 @@ def _declare(L):
         f = getattr(L, "fhs_str_" + name)
         f.argtypes = [vp, hp, sz, hp, sz, hp, hp]
         f.restype = i
+    for name in ("fhs_flags_or", "fhs_flags_and"):
+        f = getattr(L, name)
+        f.argtypes = [vp, hp, sz, hp]
+        f.restype = i
     L.fhs_get_stats.argtypes = [vp, vp]
     L.fhs_get_stats.restype = i
     L.fhs_reset_stats.argtypes = [vp]

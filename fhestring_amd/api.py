@@ -264,6 +264,8 @@ def _harr(chars):
 class MyServerKey:
     """MyServerKey (src/server_key/mod.rs:13-16) on one MI355X."""
 
+    device_resident = True   # ciphertexts live in HBM; export/import take device pointers
+
     def __init__(self, ctx):
         self.ctx = ctx
         self._stats = None
@@ -306,6 +308,15 @@ class MyServerKey:
 
     def flush(self):
         self.ctx._check(self.ctx._L.fhs_flush(self.ctx._h))
+
+    def _flags(self, name, flags):
+        flags = self._chars(flags)
+        out = C.c_uint64()
+        self.ctx._check(getattr(self.ctx._L, name)(self.ctx._h, _harr(flags), len(flags), C.byref(out)))
+        return FheAsciiChar(self, out.value)
+
+    def flags_or(self, flags): return self._flags("fhs_flags_or", flags)
+    def flags_and(self, flags): return self._flags("fhs_flags_and", flags)
 
     def stats(self, reset=False):
         from ._lib import Stats

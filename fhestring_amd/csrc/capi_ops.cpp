@@ -290,6 +290,21 @@ int fhs_str_strip_suffix(fhs_ctx *c, const fhs_char_t *s, size_t n, const fhs_ch
     return FHS_OK;
 }
 
+int fhs_flags_or(fhs_ctx *c, const fhs_char_t *flags, size_t n, fhs_char_t *out) {
+    if (!ok_all(c, flags, n) || !out) return bad(c);
+    Strings S(&c->eng);
+    FChar r = S.flags_or(load_str(c->eng, flags, n));
+    *out = store(c->eng, r);
+    return FHS_OK;
+}
+int fhs_flags_and(fhs_ctx *c, const fhs_char_t *flags, size_t n, fhs_char_t *out) {
+    if (!ok_all(c, flags, n) || !out) return bad(c);
+    Strings S(&c->eng);
+    FChar r = S.flags_and(load_str(c->eng, flags, n));
+    *out = store(c->eng, r);
+    return FHS_OK;
+}
+
 int fhs_get_stats(fhs_ctx *c, fhs_stats *out) {
     if (!c || !out) return bad(c);
     out->pbs_executed = c->eng.stats.pbs_executed;

@@ -423,6 +423,17 @@ Ref Strings::or_tree(std::vector<Ref> f) {
     return cur[0];
 }
 
+FChar Strings::flags_or(const FStr &flags) {
+    std::vector<Ref> f;
+    for (const FChar &c : flags) f.push_back(c.b[0]);
+    return ch_flag(e_, or_tree(f));
+}
+FChar Strings::flags_and(const FStr &flags) {
+    std::vector<Ref> f;
+    for (const FChar &c : flags) f.push_back(c.b[0]);
+    return ch_flag(e_, and_tree(f));
+}
+
 std::vector<Ref> Strings::block_eq_flags(const FChar &a, const FChar &b) {
     std::vector<Ref> f;
     for (int i = 0; i < 4; i++) {

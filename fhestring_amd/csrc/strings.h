@@ -44,6 +44,8 @@ class Strings {
     FStr trim_start(const FStr &s);
     FStr trim(const FStr &s);
     FStr bubble_zeroes_right(const FStr &s);
+    FChar flags_or(const FStr &flags);
+    FChar flags_and(const FStr &flags);
 
   private:
     Engine *e_;

@@ -1,0 +1,65 @@
+"""Multi-GPU sharding of one string operation (one process per GPU, RCCL via torch.distributed).
+
+contains(): the match windows of a string are independent (src/server_key/mod.rs:170-177), so
+they are split into `world` contiguous ranges; a rank only ever holds the characters its windows
+touch (its slice plus an (m-1)-character halo).  The only exchange is one all-gather of one
+FheAsciiChar (the partial flag, 65 568 B) per rank, followed by one OR level that every rank
+evaluates redundantly (so every rank ends with the result, like the reference's return value).
+"""
+import numpy as np
+
+CHAR_WORDS = 4 * 2049
+
+
+def plan_windows(n_chars, m, world):
+    """Split windows 0..n_chars-m over `world` ranks.
+
+    Returns a list of (w0, w1, c0, c1): rank r evaluates windows [w0, w1) and needs characters
+    [c0, c1).  Ranks beyond the number of windows get an empty range.  n_chars includes padding.
+    """
+    n_win = max(0, n_chars - m + 1) if m <= n_chars else 0
+    base, extra = divmod(n_win, world)
+    out, w = [], 0
+    for r in range(world):
+        cnt = base + (1 if r < extra else 0)
+        w0, w1 = w, w + cnt
+        c0, c1 = (w0, w1 + m - 1) if cnt else (0, 0)
+        out.append((w0, w1, c0, min(c1, n_chars)))
+        w = w1
+    return out
+
+
+class ShardedContains:
+    def __init__(self, sk, rank, world, dist, torch):
+        self.sk, self.rank, self.world, self.dist, self.torch = sk, rank, world, dist, torch
+
+    def upload_shard(self, ck, full_string, chars_per_rank, m, padding=1):
+        """Encrypt and upload only this rank's slice (+halo) of `full_string` + padding NULs."""
+        n_chars = len(full_string) + padding
+        w0, w1, c0, c1 = plan_windows(n_chars, m, self.world)[self.rank]
+        text = full_string[c0:min(c1, len(full_string))]
+        pad_here = max(0, c1 - max(c0, len(full_string)))
+        return ck.encrypt(text, pad_here, None, self.sk)
+
+    def run(self, shard, clear_pattern, op="contains"):
+        sk = self.sk
+        if op == "find":
+            if self.world != 1:
+                raise NotImplementedError("find is single-GPU in this round")
+            return sk.find_clear(shard, clear_pattern)
+        if len(shard) >= len(clear_pattern):
+            local = sk.contains_clear(shard, clear_pattern)
+        else:
+            local = sk.trivial(0)      # this rank owns no window
+        if self.world == 1:
+            return local
+        torch = self.torch
+        dev = "cuda" if torch.cuda.is_available() and sk.device_resident else "cpu"
+        mine = torch.empty(CHAR_WORDS, dtype=torch.int64, device=dev)
+        sk.export_device(local, mine.data_ptr())          # flushes this rank's DAG
+        allp = torch.empty(self.world * CHAR_WORDS, dtype=torch.int64, device=dev)
+        self.dist.all_gather_into_tensor(allp, mine)
+        if dev == "cuda":
+            torch.cuda.current_stream().synchronize()
+        parts = [sk.import_device(allp.data_ptr() + 8 * CHAR_WORDS * r) for r in range(self.world)]
+        return sk.flags_or(parts)

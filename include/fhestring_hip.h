@@ -139,6 +139,10 @@ int fhs_str_trim_end(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out 
 int fhs_str_trim_start(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out /*[n]*/);                             /* trim.rs:86 */
 int fhs_str_trim(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out /*[n]*/);                                   /* trim.rs:146 */
 int fhs_bubble_zeroes_right(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out /*[n]*/);                        /* utils.rs:28 */
+/* OR / AND of n 0/1 flag chars in log_15(n) levels (chains of bitor/bitand :65-81 re-associated);
+ * used to combine per-GPU partial results after the gather. */
+int fhs_flags_or(fhs_ctx *c, const fhs_char_t *flags, size_t n, fhs_char_t *out);
+int fhs_flags_and(fhs_ctx *c, const fhs_char_t *flags, size_t n, fhs_char_t *out);
 
 /* ---- statistics ---------------------------------------------------------------- */
 typedef struct {

@@ -1,0 +1,74 @@
+"""Sharding logic of the multi-GPU path, on CPU: window plan properties and a world_size-2 gloo
+run of fhestring_amd.parallel.ShardedContains against a clear-text stand-in for the server key."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plan_windows_partitions_all_windows():
+    from fhestring_amd.parallel import plan_windows
+    for n in (1, 5, 65, 257, 513):
+        for m in (1, 3, 4, 8):
+            for world in (1, 2, 3, 8):
+                plan = plan_windows(n, m, world)
+                assert len(plan) == world
+                wins = [w for (w0, w1, _, _) in plan for w in range(w0, w1)]
+                assert wins == list(range(max(0, n - m + 1) if m <= n else 0))
+                for (w0, w1, c0, c1) in plan:
+                    if w1 > w0:
+                        assert c0 == w0 and c1 == w1 + m - 1 <= n     # slice + (m-1) halo
+
+
+WORKER = r'''
+import ctypes, os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["FHS_ROOT"])
+from fhestring_amd.parallel import ShardedContains, CHAR_WORDS
+
+class ClearChar:
+    def __init__(self, v): self.v = v
+class ClearKey:                       # stands in for MyClientKey: "encrypts" to clear chars
+    def encrypt(self, text, pad, pp, sk): return [ClearChar(b) for b in text.encode()] + [ClearChar(0)] * pad
+class ClearServerKey:                 # stands in for MyServerKey (same method names)
+    device_resident = False
+    def contains_clear(self, chars, pat):
+        s = bytes(c.v for c in chars)
+        return ClearChar(int(pat.encode() in s))
+    def trivial(self, v): return ClearChar(v)
+    def export_device(self, ch, ptr):
+        buf = np.zeros(CHAR_WORDS, np.int64); buf[2048] = ch.v
+        ctypes.memmove(ptr, buf.ctypes.data, buf.nbytes)
+    def import_device(self, ptr):
+        buf = np.zeros(CHAR_WORDS, np.int64)
+        ctypes.memmove(buf.ctypes.data, ptr, buf.nbytes)
+        return ClearChar(int(buf[2048]))
+    def flags_or(self, parts): return ClearChar(int(any(p.v for p in parts)))
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+job = ShardedContains(ClearServerKey(), rank, world, dist, torch)
+ok = True
+cases = [("abcdefghij" * 3, "jab"), ("abcdefghij" * 3, "xyz"), ("aaaaab", "ab"), ("ab", "abc"), ("hello world", "o w")]
+for s, p in cases:
+    shard = job.upload_shard(ClearKey(), s, len(s) // world, len(p))
+    got = job.run(shard, p).v
+    ok &= (got == int(p in s))
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+'''
+
+
+def test_sharded_contains_world2_gloo(tmp_path):
+    import subprocess
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, FHS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    rcs = [p.wait(timeout=240) for p in procs]
+    assert rcs == [0, 0]
