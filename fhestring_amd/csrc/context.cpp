@@ -144,6 +144,13 @@ int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
     HIP_TRY(up(ht.inv_uni, tw.inv_uni), "copy tables");
     HIP_TRY(up(ht.inv_lane, tw.inv_lane), "copy tables");
     crt_c = ht.crt_c;
+    {   // the kernel's baked-in uniform twiddles must equal the exactly derived ones
+        std::vector<double> fu(64), iu(128);
+        double c = 0;
+        HIP_TRY(read_device_ntt_consts(fu.data(), iu.data(), &c), "read device constants");
+        if (fu != ht.fwd_uni || iu != ht.inv_uni || c != ht.crt_c)
+            return fail(-3, "ntt_consts.inc does not match the derived twiddle tables (regenerate it)");
+    }
     key_loaded = true;
     return 0;
 }

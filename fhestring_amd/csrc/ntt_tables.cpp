@@ -77,8 +77,8 @@ void build_ntt_tables(HostNttTables &t) {
     t.inv_lane.assign(2 * 32 * 64, 0.0);
     for (int q = 0; q < 2; q++) {
         const PrimeTables &pt = prime(q);
-        for (int k = 1; k < 32; k++) t.fwd_uni[q * 32 + k] = centred(pt.psi_br[k], pt.p);
-        for (int k = 1; k < 64; k++) t.inv_uni[q * 64 + k] = centred(pt.ipsi_br[k], pt.p);
+        for (int k = 0; k < 32; k++) t.fwd_uni[q * 32 + k] = centred(pt.psi_br[k], pt.p);
+        for (int k = 0; k < 64; k++) t.inv_uni[q * 64 + k] = centred(pt.ipsi_br[k], pt.p);
         for (int lane = 0; lane < 64; lane++) {
             t.fwd_lane[(q * 32 + 0) * 64 + lane] = centred(pt.psi_br[32 + lane / 2], pt.p);
             for (int e = 1; e < 32; e++) {
@@ -114,7 +114,7 @@ void convert_bsk_to_ntt(const uint64_t *bsk_std, double *out, int nthreads) {
                 double *dst = out + (pi * 2 + q) * POLY_N;
                 for (int idx = 0; idx < POLY_N; idx++) {
                     const int lane = idx >> 5, c = idx & 31;
-                    dst[c * 64 + lane] = centred(mulm(a[idx], pt.ninv, pt.p), pt.p);
+                    dst[((c >> 1) * 64 + lane) * 2 + (c & 1)] = centred(mulm(a[idx], pt.ninv, pt.p), pt.p);
                 }
             }
         }

@@ -37,7 +37,7 @@ struct BlindRotateParams {
     const uint32_t *ms;       // [B][743] mod-switched small LWE, values in [0,4096)
     const uint32_t *lut_idx;  // [B]
     const uint64_t *luts;     // [L][2048]
-    const double *bsk_ntt;    // [742][row 2][col 2][prime 2][32][64], pre-scaled by N^-1
+    const double *bsk_ntt;    // [742][row 2][col 2][prime 2][16][64 lanes][2], pre-scaled by N^-1
     NttTables tw;
     double crt_c;             // p0^-1 mod p1, centred
     uint64_t *out;            // [B][2049] dense output, or
@@ -57,6 +57,7 @@ struct LinTerm {
 };
 
 size_t blind_rotate_lds_bytes();
+hipError_t read_device_ntt_consts(double *fwd_uni /*[64]*/, double *inv_uni /*[128]*/, double *crt);
 hipError_t launch_blind_rotate(const BlindRotateParams &p, hipStream_t s);
 hipError_t launch_keyswitch_modswitch(const uint64_t *d_in /*[B][2049]*/, const uint64_t *d_ksk,
                                       uint32_t *d_ms /*[B][743]*/, int B, hipStream_t s);

@@ -19,6 +19,21 @@ namespace fhs {
 
 #pragma clang fp contract(off)
 
+#include "ntt_consts.inc"   // C_FWD_UNI, C_INV_UNI (constant address space -> scalar loads), C_CRT
+
+// The ~96 lane-uniform twiddles of one prime live distributed over the 64 lanes of two resident
+// registers (lane k holds constant k) and are broadcast with v_readlane: no memory traffic, no waits.
+//   twA: lanes 0..31 = Psi[0..31],  lanes 32..63 = PsiInv[32..63]
+//   twB: lanes 0..31 = PsiInv[0..31]
+__device__ __forceinline__ double bcast_lane(double v, int k) {
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)b, k);
+    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), k);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+#define FWD_UNI(k) bcast_lane(twA, (k))
+#define INV_UNI(k) ((k) >= 32 ? bcast_lane(twA, (k)) : bcast_lane(twB, (k)))
+
 // ------------------------------------------------------------------------------------------
 // exact modular arithmetic in FP64 (all values are integers with |x| < 2^52)
 // ------------------------------------------------------------------------------------------
@@ -43,17 +58,24 @@ constexpr int LDS_WAVE_SLOTS = POLY_N + 2 * (POLY_N / 32);   // 2176 doubles = 1
 // ---- forward negacyclic NTT (Cooley-Tukey, merged psi powers, bit-reversed twiddle table) ----
 // in : x[r] = coefficient (lane + 64 r)              (strided layout, natural order)
 // out: x[c] = transform value at array index 32*lane + c (contiguous layout, CT output order)
+// Per-lane twiddles factor as Psi[64G + G*lane + g] = Psi[64G + G*lane] * Psi[g] (disjoint bits
+// under the bit reversal), so a lane keeps only 6 resident bases; everything else is lane-uniform.
 __device__ __forceinline__ void ntt_forward(double (&x)[32], double *lds, int lane,
-                                            const double *__restrict__ uni,   // uniform: Psi[1..31]
-                                            const double *__restrict__ lanetw, // [32][64]
+                                            const double twA,                 // lane-distributed uniform twiddles
+                                            const double *__restrict__ lanetw, // [32][64] per-lane table of this prime
                                             double p, double pinv) {
+    // per-lane bases Psi[32 + lane/2], Psi[64G + G*lane]: L1-resident table, loads overlap the first stages
+    double base[6];
+    base[0] = lanetw[lane];
+#pragma unroll
+    for (int k = 0; k < 5; k++) base[1 + k] = lanetw[(1 << k) * 64 + lane];
     // stages t = 1024..64: a 32-point CT on the register index, lane-uniform twiddles
 #pragma unroll
     for (int T = 16; T >= 1; T >>= 1) {
         const int m = 16 / T;
 #pragma unroll
         for (int i = 0; i < m; i++) {
-            const double w = uni[m + i];
+            const double w = FWD_UNI(m + i);
 #pragma unroll
             for (int r = 2 * i * T; r < 2 * i * T + T; r++) {
                 double v = mulmod(x[r + T], w, p, pinv);
@@ -63,15 +85,18 @@ __device__ __forceinline__ void ntt_forward(double (&x)[32], double *lds, int la
         }
     }
     // transpose strided -> contiguous through LDS
+    {   // pad_slot(lane + 64 r) == (lane + 2*(lane>>5)) + 68 r: one address register, immediate offsets
+        double *wr = lds + (lane + 2 * (lane >> 5));
 #pragma unroll
-    for (int r = 0; r < 32; r++) lds[pad_slot(lane + 64 * r)] = x[r];
+        for (int r = 0; r < 32; r++) wr[68 * r] = x[r];
+    }
     __builtin_amdgcn_wave_barrier();
     // stage t = 32 fused into the read: lanes (2k, 2k+1) share one 64-coefficient group
     {
-        const double w = lanetw[0 * 64 + lane];           // Psi[32 + lane/2]
+        const double w = base[0];                          // Psi[32 + lane/2]
         const double sgn = (lane & 1) ? -1.0 : 1.0;
-        const double *lo = lds + pad_slot(32 * (lane & ~1));
-        const double *hi = lds + pad_slot(32 * (lane | 1));
+        const double *lo = lds + 34 * (lane & ~1);   // pad_slot(32 L + c) == 34 L + c
+        const double *hi = lds + 34 * (lane | 1);
 #pragma unroll
         for (int c = 0; c < 32; c++) {
             double v = mulmod(hi[c], w, p, pinv);
@@ -79,13 +104,14 @@ __device__ __forceinline__ void ntt_forward(double (&x)[32], double *lds, int la
         }
     }
     __builtin_amdgcn_wave_barrier();
-    // stages t = 16..1: in-lane, per-lane twiddles
+    // stages t = 16..1: in-lane, twiddle = base[stage] * Psi[g]
+    int lg = 0;
 #pragma unroll
-    for (int t = 16; t >= 1; t >>= 1) {
+    for (int t = 16; t >= 1; t >>= 1, lg++) {
         const int G = 16 / t;
 #pragma unroll
         for (int g = 0; g < G; g++) {
-            const double w = lanetw[(G + g) * 64 + lane];   // Psi[64G + G*lane + g]
+            const double w = g == 0 ? base[1 + lg] : mulmod(base[1 + lg], FWD_UNI(g), p, pinv);
 #pragma unroll
             for (int c = 2 * g * t; c < 2 * g * t + t; c++) {
                 double v = mulmod(x[c + t], w, p, pinv);
@@ -100,15 +126,19 @@ __device__ __forceinline__ void ntt_forward(double (&x)[32], double *lds, int la
 // in : x[c] at array index 32*lane + c (contiguous layout), |x| <= 1.5 p
 // out: x[r] = coefficient (lane + 64 r) (strided layout), |x| <= 4.1 p, congruent mod p
 __device__ __forceinline__ void ntt_inverse(double (&x)[32], double *lds, int lane,
-                                            const double *__restrict__ uni,    // PsiInv[1..63]
-                                            const double *__restrict__ lanetw,  // [32][64]
+                                            const double twA, const double twB, // lane-distributed uniform twiddles
+                                            const double *__restrict__ lanetw,  // [32][64] per-lane table of this prime
                                             double p, double pinv) {
+    double base[5];
 #pragma unroll
-    for (int t = 1; t <= 16; t <<= 1) {
+    for (int k = 0; k < 5; k++) base[k] = lanetw[(1 << k) * 64 + lane];
+    int lg = 4;
+#pragma unroll
+    for (int t = 1; t <= 16; t <<= 1, lg--) {
         const int G = 16 / t;
 #pragma unroll
         for (int g = 0; g < G; g++) {
-            const double w = lanetw[(G + g) * 64 + lane];
+            const double w = g == 0 ? base[lg] : mulmod(base[lg], INV_UNI(g), p, pinv);
 #pragma unroll
             for (int c = 2 * g * t; c < 2 * g * t + t; c++) {
                 double u = x[c], v = x[c + t];
@@ -122,18 +152,21 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[32], double *lds, int la
         }
     }
     // transpose contiguous -> strided, stage t = 32 fused into the read
+    {
+        double *wr = lds + 34 * lane;
 #pragma unroll
-    for (int c = 0; c < 32; c++) lds[pad_slot(32 * lane) + c] = x[c];
+        for (int c = 0; c < 32; c++) wr[c] = x[c];
+    }
     __builtin_amdgcn_wave_barrier();
     {
         const bool upper = lane >= 32;
-        const int l5 = lane & 31;
+        const double *rd = lds + (lane & 31);      // pad_slot(l5 + 64 r) == l5 + 68 r, +34 for the partner
 #pragma unroll
         for (int r = 0; r < 32; r++) {
-            double a = lds[pad_slot(l5 + 64 * r)];
-            double b = lds[pad_slot(l5 + 32 + 64 * r)];
+            double a = rd[68 * r];
+            double b = rd[68 * r + 34];
             double s = a + b;
-            double d = mulmod(a - b, uni[32 + r], p, pinv);
+            double d = mulmod(a - b, INV_UNI(32 + r), p, pinv);
             x[r] = upper ? d : s;
         }
     }
@@ -144,7 +177,7 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[32], double *lds, int la
         const int h = 16 / T;
 #pragma unroll
         for (int i = 0; i < h; i++) {
-            const double w = uni[h + i];
+            const double w = INV_UNI(h + i);
 #pragma unroll
             for (int r = 2 * i * T; r < 2 * i * T + T; r++) {
                 double u = x[r], v = x[r + T];
@@ -182,13 +215,13 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
     const double p = q ? (double)NTT_P1 : (double)NTT_P0;
     const double pinv = 1.0 / p;
     const double p1 = (double)NTT_P1, p1inv = 1.0 / p1;
-    const double crt_c = P.crt_c;                     // p0^-1 mod p1, centred
+    const double crt_c = C_CRT;                       // p0^-1 mod p1, centred
 
     const uint32_t *ms = P.ms + (size_t)ct * SMALL_CT;
-    const double *fwd_uni = P.tw.fwd_uni + q * 32;
     const double *fwd_lane = P.tw.fwd_lane + q * 32 * 64;
-    const double *inv_uni = P.tw.inv_uni + q * 64;
     const double *inv_lane = P.tw.inv_lane + q * 32 * 64;
+    const double twA = lane < 32 ? C_FWD_UNI[q][lane] : C_INV_UNI[q][lane];
+    const double twB = C_INV_UNI[q][lane & 31];
 
     // acc[r] = coefficient (lane + 64 r) of GLWE polynomial j, u64 torus
     uint64_t acc[32];
@@ -233,25 +266,47 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
         }
         __builtin_amdgcn_wave_barrier();
 
-        ntt_forward(x, my, lane, fwd_uni, fwd_lane, p, pinv);
+        ntt_forward(x, my, lane, twA, fwd_lane, p, pinv);
 
         // ---- publish, pointwise multiply-accumulate with GGSW_i ----
+        // key layout [32/2][64 lanes][2]: one 16-byte load per lane covers coefficients (c, c+1)
+        typedef double __attribute__((ext_vector_type(2))) double2_t;
+        const double2_t *b_own = reinterpret_cast<const double2_t *>(
+            P.bsk_ntt + ((((size_t)i * 2 + j) * 2 + j) * 2 + q) * POLY_N) + lane;
+        const double2_t *b_par = reinterpret_cast<const double2_t *>(
+            P.bsk_ntt + ((((size_t)i * 2 + (1 - j)) * 2 + j) * 2 + q) * POLY_N) + lane;
+        constexpr int CH = 4;   // pairs per chunk -> 8 coefficients
+        double2_t bo[CH], bp[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) { bo[k] = b_own[k * 64]; bp[k] = b_par[k * 64]; }   // in flight over the barrier
 #pragma unroll
         for (int c = 0; c < 32; c++) my[c * 64 + lane] = x[c];
         __syncthreads();
-        {
-            // rows: 0 multiplies the mask digit polynomial, 1 the body digit polynomial
-            const double *b_own = P.bsk_ntt + ((((size_t)i * 2 + j) * 2 + j) * 2 + q) * POLY_N + lane;
-            const double *b_par = P.bsk_ntt + ((((size_t)i * 2 + (1 - j)) * 2 + j) * 2 + q) * POLY_N + lane;
 #pragma unroll
-            for (int c = 0; c < 32; c++) {
-                const double o = partner[c * 64 + lane];
-                x[c] = mulmod(x[c], b_own[c * 64], p, pinv) + mulmod(o, b_par[c * 64], p, pinv);
+        for (int ch = 0; ch < 16 / CH; ch++) {
+            double2_t no[CH], np[CH];
+            if (ch + 1 < 16 / CH) {
+#pragma unroll
+                for (int k = 0; k < CH; k++) {
+                    no[k] = b_own[((ch + 1) * CH + k) * 64];
+                    np[k] = b_par[((ch + 1) * CH + k) * 64];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const int c = 2 * (ch * CH + k);
+                const double o0 = partner[c * 64 + lane], o1 = partner[(c + 1) * 64 + lane];
+                x[c] = mulmod(x[c], bo[k].x, p, pinv) + mulmod(o0, bp[k].x, p, pinv);
+                x[c + 1] = mulmod(x[c + 1], bo[k].y, p, pinv) + mulmod(o1, bp[k].y, p, pinv);
+            }
+            if (ch + 1 < 16 / CH) {
+#pragma unroll
+                for (int k = 0; k < CH; k++) { bo[k] = no[k]; bp[k] = np[k]; }
             }
         }
         __syncthreads();
 
-        ntt_inverse(x, my, lane, inv_uni, inv_lane, p, pinv);
+        ntt_inverse(x, my, lane, twA, twB, inv_lane, p, pinv);
 
         // ---- CRT of the two residues, accumulate ----
 #pragma unroll
@@ -283,6 +338,14 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
             out[BIG_N] = acc[0];
         }
     }
+}
+
+hipError_t read_device_ntt_consts(double *fwd_uni /*[64]*/, double *inv_uni /*[128]*/, double *crt) {
+    hipError_t e = hipMemcpyFromSymbol(fwd_uni, HIP_SYMBOL(C_FWD_UNI), sizeof(double) * 64);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyFromSymbol(inv_uni, HIP_SYMBOL(C_INV_UNI), sizeof(double) * 128);
+    *crt = C_CRT;
+    return e;
 }
 
 size_t blind_rotate_lds_bytes() { return (size_t)4 * LDS_WAVE_SLOTS * sizeof(double); }
