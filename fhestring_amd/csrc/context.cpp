@@ -99,11 +99,14 @@ void Context::shutdown() {
     if (stream) (void)hipStreamSynchronize(stream);
     timer.destroy();
     ms_buf.release();
+    ks_buf.release();
     in_buf.release();
     out_buf.release();
     lutidx_buf.release();
     luts_buf.release();
     if (d_ksk) (void)hipFree(d_ksk);
+    if (d_colsum4) (void)hipFree(d_colsum4);
+    d_colsum4 = nullptr;
     if (d_bsk_ntt) (void)hipFree(d_bsk_ntt);
     if (d_tables) (void)hipFree(d_tables);
     d_ksk = nullptr;
@@ -121,6 +124,9 @@ int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
     if (!d_ksk) HIP_TRY(hipMalloc(&d_ksk, ksk_bytes), "hipMalloc ksk");
     if (!d_bsk_ntt) HIP_TRY(hipMalloc(&d_bsk_ntt, bsk_ntt_doubles * sizeof(double)), "hipMalloc bsk");
     HIP_TRY(hipMemcpy(d_ksk, ksk, ksk_bytes, hipMemcpyHostToDevice), "copy ksk");
+    if (!d_colsum4) HIP_TRY(hipMalloc(&d_colsum4, SMALL_CT * sizeof(uint64_t)), "hipMalloc colsum");
+    HIP_TRY(launch_ksk_colsum(d_ksk, d_colsum4, stream), "ksk colsum launch");
+    HIP_TRY(hipStreamSynchronize(stream), "ksk colsum");
     {
         std::vector<double> host(bsk_ntt_doubles);
         unsigned hc = std::thread::hardware_concurrency();
@@ -160,12 +166,12 @@ int Context::pbs_batch_device(const uint64_t *d_in, const uint32_t *d_lut_idx, c
     if (!key_loaded) return fail(-3, "server key not loaded");
     if (B == 0) return 0;
     if (B > (size_t)1 << 24) return fail(-1, "batch too large");
-    HIP_TRY(ms_buf.reserve(B * SMALL_CT * sizeof(uint32_t)), "hipMalloc ms");
+    HIP_TRY(ks_buf.reserve(B * SMALL_CT * sizeof(uint64_t)), "hipMalloc ks");
     timer.begin(1, B, s);
-    HIP_TRY(launch_keyswitch_modswitch(d_in, d_ksk, ms_buf.as<uint32_t>(), (int)B, s), "keyswitch launch");
+    HIP_TRY(launch_keyswitch(d_in, d_ksk, d_colsum4, ks_buf.as<uint64_t>(), (int)B, s), "keyswitch launch");
     timer.end(s);
     BlindRotateParams p{};
-    p.ms = ms_buf.as<uint32_t>();
+    p.ks = ks_buf.as<uint64_t>();
     p.lut_idx = d_lut_idx;
     p.luts = d_luts;
     p.bsk_ntt = d_bsk_ntt;
@@ -208,9 +214,11 @@ int Context::ks_ms_batch_host(const uint64_t *in, uint32_t *ms_out, size_t B) {
     HIP_TRY(hipSetDevice(device), "hipSetDevice");
     HIP_TRY(in_buf.reserve(B * BIG_CT * 8), "hipMalloc");
     HIP_TRY(ms_buf.reserve(B * SMALL_CT * 4), "hipMalloc");
+    HIP_TRY(ks_buf.reserve(B * SMALL_CT * 8), "hipMalloc");
     HIP_TRY(hipMemcpyAsync(in_buf.ptr, in, B * BIG_CT * 8, hipMemcpyHostToDevice, stream), "H2D");
-    HIP_TRY(launch_keyswitch_modswitch(in_buf.as<uint64_t>(), d_ksk, ms_buf.as<uint32_t>(), (int)B, stream),
+    HIP_TRY(launch_keyswitch(in_buf.as<uint64_t>(), d_ksk, d_colsum4, ks_buf.as<uint64_t>(), (int)B, stream),
             "keyswitch launch");
+    HIP_TRY(launch_modswitch(ks_buf.as<uint64_t>(), ms_buf.as<uint32_t>(), (int)B, stream), "modswitch launch");
     HIP_TRY(hipMemcpyAsync(ms_out, ms_buf.ptr, B * SMALL_CT * 4, hipMemcpyDeviceToHost, stream), "D2H");
     HIP_TRY(hipStreamSynchronize(stream), "sync");
     return 0;

@@ -46,13 +46,14 @@ class Context {
 
     // key material on device
     uint64_t *d_ksk = nullptr;
+    uint64_t *d_colsum4 = nullptr;   // 4 * column sums of the KSK (biased-digit correction)
     double *d_bsk_ntt = nullptr;
     double *d_tables = nullptr;   // fwd_uni | fwd_lane | inv_uni | inv_lane
     NttTables tw{};
     double crt_c = 0;
 
     // scratch
-    DevBuf ms_buf, in_buf, out_buf, lutidx_buf, luts_buf;
+    DevBuf ks_buf, ms_buf, in_buf, out_buf, lutidx_buf, luts_buf;
     KernelTimer timer;
 
     int init(int device_id);

@@ -271,10 +271,10 @@ int Engine::flush() {
         if (e == hipSuccess) e = batch_in_.reserve(max_width * BIG_CT * 8);
         if (e != hipSuccess) return ctx.hip_fail(e, "batch buffer");
     }
-    if (ctx.ms_buf.cap < max_width * SMALL_CT * 4) {
+    if (ctx.ks_buf.cap < max_width * SMALL_CT * 8) {
         e = hipStreamSynchronize(ctx.stream);
-        if (e == hipSuccess) e = ctx.ms_buf.reserve(max_width * SMALL_CT * 4);
-        if (e != hipSuccess) return ctx.hip_fail(e, "ms buffer");
+        if (e == hipSuccess) e = ctx.ks_buf.reserve(max_width * SMALL_CT * 8);
+        if (e != hipSuccess) return ctx.hip_fail(e, "ks buffer");
     }
     // pageable host memory: hipMemcpyAsync has consumed `host` when it returns
 
@@ -287,12 +287,12 @@ int Engine::flush() {
         e = launch_lincomb(d_desc, d_terms, batch_in_.as<uint64_t>(), (int)lp.count, ctx.stream);
         if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
         ctx.timer.begin(1, lp.count, ctx.stream);
-        e = launch_keyswitch_modswitch(batch_in_.as<uint64_t>(), ctx.d_ksk, ctx.ms_buf.as<uint32_t>(),
-                                       (int)lp.count, ctx.stream);
+        e = launch_keyswitch(batch_in_.as<uint64_t>(), ctx.d_ksk, ctx.d_colsum4, ctx.ks_buf.as<uint64_t>(),
+                             (int)lp.count, ctx.stream);
         ctx.timer.end(ctx.stream);
         if (e != hipSuccess) return ctx.hip_fail(e, "keyswitch launch");
         BlindRotateParams p{};
-        p.ms = ctx.ms_buf.as<uint32_t>();
+        p.ks = ctx.ks_buf.as<uint64_t>();
         p.lut_idx = d_lut;
         p.luts = d_luts_;
         p.bsk_ntt = ctx.d_bsk_ntt;

@@ -34,7 +34,7 @@ struct NttTables {
 };
 
 struct BlindRotateParams {
-    const uint32_t *ms;       // [B][743] mod-switched small LWE, values in [0,4096)
+    const uint64_t *ks;       // [B][743] keyswitched small LWE (u64 torus), mod-switched in-kernel
     const uint32_t *lut_idx;  // [B]
     const uint64_t *luts;     // [L][2048]
     const double *bsk_ntt;    // [742][row 2][col 2][prime 2][16][64 lanes][2], pre-scaled by N^-1
@@ -59,8 +59,10 @@ struct LinTerm {
 size_t blind_rotate_lds_bytes();
 hipError_t read_device_ntt_consts(double *fwd_uni /*[64]*/, double *inv_uni /*[128]*/, double *crt);
 hipError_t launch_blind_rotate(const BlindRotateParams &p, hipStream_t s);
-hipError_t launch_keyswitch_modswitch(const uint64_t *d_in /*[B][2049]*/, const uint64_t *d_ksk,
-                                      uint32_t *d_ms /*[B][743]*/, int B, hipStream_t s);
+hipError_t launch_ksk_colsum(const uint64_t *d_ksk, uint64_t *d_colsum4 /*[743]*/, hipStream_t s);
+hipError_t launch_keyswitch(const uint64_t *d_in /*[B][2049]*/, const uint64_t *d_ksk, const uint64_t *d_colsum4,
+                            uint64_t *d_ks_out /*[B][743]*/, int B, hipStream_t s);
+hipError_t launch_modswitch(const uint64_t *d_ks, uint32_t *d_ms /*[B][743]*/, int B, hipStream_t s);
 hipError_t launch_lincomb(const LinDesc *d_desc, const LinTerm *d_terms, uint64_t *d_out /*[n][2049]*/,
                           int n, hipStream_t s);
 // gathers scattered blocks into a dense batch: out[i] = *src[i]

@@ -124,7 +124,7 @@ __device__ __forceinline__ void ntt_forward(double (&x)[32], double *lds, int la
 
 // ---- inverse negacyclic NTT (Gentleman-Sande), 1/N folded into the key ----
 // in : x[c] at array index 32*lane + c (contiguous layout), |x| <= 1.5 p
-// out: x[r] = coefficient (lane + 64 r) (strided layout), |x| <= 4.1 p, congruent mod p
+// out: x[r] = coefficient (lane + 64 r) (strided layout), |x| <= 11.1 p, congruent mod p
 __device__ __forceinline__ void ntt_inverse(double (&x)[32], double *lds, int lane,
                                             const double twA, const double twB, // lane-distributed uniform twiddles
                                             const double *__restrict__ lanetw,  // [32][64] per-lane table of this prime
@@ -132,10 +132,14 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[32], double *lds, int la
     double base[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) base[k] = lanetw[(1 << k) * 64 + lane];
+    // Lazy ranges: magnitudes are tracked statically per register (in units of p: pointwise output
+    // 1.3, a sum adds its operands, a mulmod/reduce output is 0.5 + input/60) and only the 13
+    // registers that would push a mulmod input past 24 p are reset -- see DESIGN.md section 2.
     int lg = 4;
 #pragma unroll
     for (int t = 1; t <= 16; t <<= 1, lg--) {
         const int G = 16 / t;
+        if (t == 16) x[0] = reduce_once(x[0], p, pinv);
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const double w = g == 0 ? base[lg] : mulmod(base[lg], INV_UNI(g), p, pinv);
@@ -146,11 +150,9 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[32], double *lds, int la
                 x[c + t] = mulmod(u - v, w, p, pinv);
             }
         }
-        if (t == 8) {   // magnitudes reached 24 p: bring everything back below p
-#pragma unroll
-            for (int c = 0; c < 32; c++) x[c] = reduce_once(x[c], p, pinv);
-        }
     }
+#pragma unroll
+    for (int c = 0; c < 4; c++) x[c] = reduce_once(x[c], p, pinv);   // the only registers above 3 p
     // transpose contiguous -> strided, stage t = 32 fused into the read
     {
         double *wr = lds + 34 * lane;
@@ -175,6 +177,10 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[32], double *lds, int la
 #pragma unroll
     for (int T = 1; T <= 16; T <<= 1) {
         const int h = 16 / T;
+        const unsigned reset = T == 4 ? 0x01010101u : (T >= 8 ? 0x00010001u : 0u);
+#pragma unroll
+        for (int r = 0; r < 32; r++)
+            if ((reset >> r) & 1u) x[r] = reduce_once(x[r], p, pinv);
 #pragma unroll
         for (int i = 0; i < h; i++) {
             const double w = INV_UNI(h + i);
@@ -185,11 +191,11 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[32], double *lds, int la
                 x[r + T] = mulmod(u - v, w, p, pinv);
             }
         }
-        if (T == 2) {   // second range reset (8 stages since the first)
-#pragma unroll
-            for (int r = 0; r < 32; r++) x[r] = reduce_once(x[r], p, pinv);
-        }
     }
+}
+
+__device__ __forceinline__ uint32_t mod_switch(uint64_t x) {      // round to Z_4096 (2N)
+    return (uint32_t)(((x + (1ull << 51)) >> 52) & 4095u);
 }
 
 __device__ __forceinline__ int64_t f64_to_i64_exact(double v) {   // |v| < 2^51, integral
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
     const double p1 = (double)NTT_P1, p1inv = 1.0 / p1;
     const double crt_c = C_CRT;                       // p0^-1 mod p1, centred
 
-    const uint32_t *ms = P.ms + (size_t)ct * SMALL_CT;
+    const uint64_t *ks = P.ks + (size_t)ct * SMALL_CT;   // keyswitched small LWE, mod-switched on use
     const double *fwd_lane = P.tw.fwd_lane + q * 32 * 64;
     const double *inv_lane = P.tw.inv_lane + q * 32 * 64;
     const double twA = lane < 32 ? C_FWD_UNI[q][lane] : C_INV_UNI[q][lane];
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
     // acc[r] = coefficient (lane + 64 r) of GLWE polynomial j, u64 torus
     uint64_t acc[32];
     {
-        const uint32_t b = ms[LWE_N];
+        const uint32_t b = mod_switch(ks[LWE_N]);
         const uint32_t a = (2 * POLY_N - b) & (2 * POLY_N - 1);     // X^{-b} = X^{2N-b}
         const uint32_t s = a & (POLY_N - 1);
         const bool neg = a >= POLY_N;
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
     }
 
     for (int i = 0; i < LWE_N; i++) {
-        const uint32_t a = ms[i];
+        const uint32_t a = mod_switch(ks[i]);
         if (a == 0) continue;   // X^0*acc - acc == 0: exact no-op (uniform for the workgroup)
         const uint32_t s = a & (POLY_N - 1);
         const bool neg = a >= POLY_N;
@@ -312,14 +318,22 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
 #pragma unroll
         for (int r = 0; r < 32; r++) my[r * 64 + lane] = x[r];
         __syncthreads();
+        if (q == 0) {
 #pragma unroll
-        for (int r = 0; r < 32; r++) {
-            const double o = sibling[r * 64 + lane];
-            const double r0 = q ? o : x[r];
-            const double r1 = q ? x[r] : o;
-            const double t = mulmod(r1 - r0, crt_c, p1, p1inv);
-            const uint64_t v = (uint64_t)f64_to_i64_exact(r0) + NTT_P0 * (uint64_t)f64_to_i64_exact(t);
-            acc[r] += v << BSK_QUANT_BITS;
+            for (int r = 0; r < 32; r++) {
+                const double r0 = x[r], r1 = sibling[r * 64 + lane];
+                const double t = mulmod(r1 - r0, crt_c, p1, p1inv);
+                const uint64_t v = (uint64_t)f64_to_i64_exact(r0) + NTT_P0 * (uint64_t)f64_to_i64_exact(t);
+                acc[r] += v << BSK_QUANT_BITS;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 32; r++) {
+                const double r0 = sibling[r * 64 + lane], r1 = x[r];
+                const double t = mulmod(r1 - r0, crt_c, p1, p1inv);
+                const uint64_t v = (uint64_t)f64_to_i64_exact(r0) + NTT_P0 * (uint64_t)f64_to_i64_exact(t);
+                acc[r] += v << BSK_QUANT_BITS;
+            }
         }
         __syncthreads();
     }
@@ -365,27 +379,37 @@ hipError_t launch_blind_rotate(const BlindRotateParams &p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
-// keyswitch (big key -> small key) + modulus switch to Z_4096
-// out[ct][j] = round_12( b*[j==742] - sum_{i,l} d(ct,i,l) * KSK[i][l][j] )
-// block = 256 threads: one output column per thread, KS_CT_TILE ciphertexts per workgroup so a
-// KSK row streamed from L2/HBM is reused KS_CT_TILE times; digits staged in LDS.
+// keyswitch (big key -> small key):  ks[ct][j] = b*[j==742] - sum_{i,l} d(ct,i,l) * KSK[i][l][j]
+// A (B x 10240) x (10240 x 743) product with 3-bit digits and u64 wrapping accumulation.
+//  * digits are used biased, d' = d + 4 in [0,8): ks = b + 4*colsum[j] - sum d' * KSK, so the MAC is
+//    an unsigned 3-bit x 64-bit multiply-add with a wave-uniform (SGPR) multiplier;
+//  * one thread owns one output column for a tile of KS_CT_TILE ciphertexts (a streamed KSK row is
+//    reused 16x from registers), the digit tile is staged in LDS;
+//  * the 2048 mask coefficients are split over gridDim.z workgroups (split-K) whose partial sums
+//    are combined with 64-bit atomics, so small batches still fill the GPU.
+// The modulus switch to Z_4096 happens where the value is consumed (blind_rotate_kernel).
 // ------------------------------------------------------------------------------------------
-constexpr int KS_CT_TILE = 8;
+constexpr int KS_CT_TILE = 16;
 constexpr int KS_COLS = 256;
+constexpr int KS_MAX_ROWS = 512;   // rows of the mask handled by one workgroup (<= 2048 / splits)
 
-__global__ __launch_bounds__(256) void keyswitch_modswitch_kernel(const uint64_t *__restrict__ in,
-                                                                  const uint64_t *__restrict__ ksk,
-                                                                  uint32_t *__restrict__ ms, int B) {
-    __shared__ uint16_t digs[KS_CT_TILE][BIG_N];   // 5 balanced base-8 digits, 3 bits each (biased +4)
+__global__ __launch_bounds__(256) void keyswitch_kernel(const uint64_t *__restrict__ in,
+                                                        const uint64_t *__restrict__ ksk,
+                                                        const uint64_t *__restrict__ colsum4,   // 4 * sum_{i,l} KSK[i][l][j]
+                                                        uint64_t *__restrict__ ks_out,          // [B][743], zeroed
+                                                        int B, int rows_per_split) {
+    __shared__ uint16_t digs[KS_CT_TILE][KS_MAX_ROWS];   // 5 biased base-8 digits, 3 bits each
     const int ct0 = blockIdx.x * KS_CT_TILE;
     const int col = blockIdx.y * KS_COLS + threadIdx.x;
+    const int row0 = blockIdx.z * rows_per_split;
     const int nct = min(KS_CT_TILE, B - ct0);
-    for (int e = threadIdx.x; e < KS_CT_TILE * BIG_N; e += 256) {
-        const int c = e / BIG_N, i = e % BIG_N;
-        uint16_t packed = 0;
+    for (int e = threadIdx.x; e < KS_CT_TILE * rows_per_split; e += 256) {
+        const int c = e / rows_per_split, i = e % rows_per_split;
+        uint16_t packed = 0x4924;   // all digits zero (biased 4 in each 3-bit field)
         if (c < nct) {
-            const uint64_t a = in[(size_t)(ct0 + c) * BIG_CT + i];
+            const uint64_t a = in[(size_t)(ct0 + c) * BIG_CT + row0 + i];
             uint32_t v = (uint32_t)((a + (1ull << 48)) >> 49);   // closest representable on 15 bits
+            packed = 0;
 #pragma unroll
             for (int l = KS_LEVEL - 1; l >= 0; l--) {            // least significant level first
                 int d = (int)(v & 7u);
@@ -393,46 +417,77 @@ __global__ __launch_bounds__(256) void keyswitch_modswitch_kernel(const uint64_t
                 if (d >= 4) { d -= 8; v += 1; }
                 packed |= (uint16_t)((d + 4) << (3 * l));
             }
-        } else {
-            packed = 0x4924;   // all digits zero (biased 4 in each 3-bit field)
         }
         digs[c][i] = packed;
     }
     __syncthreads();
+    if (col >= SMALL_CT) return;
     uint64_t acc[KS_CT_TILE];
 #pragma unroll
     for (int c = 0; c < KS_CT_TILE; c++) acc[c] = 0;
-    if (col < SMALL_CT) {
-        for (int i = 0; i < BIG_N; i++) {
-            uint64_t k[KS_LEVEL];
+    const uint64_t *kp = ksk + ((size_t)row0 * KS_LEVEL) * SMALL_CT + col;
+    for (int i = 0; i < rows_per_split; i++) {
+        uint64_t k[KS_LEVEL];
 #pragma unroll
-            for (int l = 0; l < KS_LEVEL; l++) k[l] = ksk[((size_t)i * KS_LEVEL + l) * SMALL_CT + col];
-#pragma unroll
-            for (int c = 0; c < KS_CT_TILE; c++) {
-                const uint32_t pk = __builtin_amdgcn_readfirstlane((uint32_t)digs[c][i]);
-#pragma unroll
-                for (int l = 0; l < KS_LEVEL; l++) {
-                    const int64_t d = (int64_t)((pk >> (3 * l)) & 7u) - 4;
-                    acc[c] -= (uint64_t)d * k[l];
-                }
-            }
-        }
+        for (int l = 0; l < KS_LEVEL; l++) k[l] = kp[((size_t)i * KS_LEVEL + l) * SMALL_CT];
 #pragma unroll
         for (int c = 0; c < KS_CT_TILE; c++) {
-            if (c < nct) {
-                uint64_t v = acc[c];
+            const uint32_t pk = __builtin_amdgcn_readfirstlane((uint32_t)digs[c][i]);
+#pragma unroll
+            for (int l = 0; l < KS_LEVEL; l++) acc[c] += (uint64_t)((pk >> (3 * l)) & 7u) * k[l];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < KS_CT_TILE; c++) {
+        if (c < nct) {
+            uint64_t v = (uint64_t)0 - acc[c];
+            if (blockIdx.z == 0) {
+                v += colsum4[col];
                 if (col == LWE_N) v += in[(size_t)(ct0 + c) * BIG_CT + BIG_N];
-                ms[(size_t)(ct0 + c) * SMALL_CT + col] = (uint32_t)(((v + (1ull << 51)) >> 52) & 4095u);
             }
+            atomicAdd(reinterpret_cast<unsigned long long *>(ks_out + (size_t)(ct0 + c) * SMALL_CT + col),
+                      (unsigned long long)v);
         }
     }
 }
 
-hipError_t launch_keyswitch_modswitch(const uint64_t *d_in, const uint64_t *d_ksk, uint32_t *d_ms, int B,
-                                      hipStream_t s) {
+__global__ __launch_bounds__(256) void ksk_colsum_kernel(const uint64_t *__restrict__ ksk,
+                                                         uint64_t *__restrict__ colsum4) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= SMALL_CT) return;
+    uint64_t s = 0;
+    for (int r = 0; r < BIG_N * KS_LEVEL; r++) s += ksk[(size_t)r * SMALL_CT + col];
+    colsum4[col] = s * 4;
+}
+hipError_t launch_ksk_colsum(const uint64_t *d_ksk, uint64_t *d_colsum4, hipStream_t s) {
+    hipLaunchKernelGGL(ksk_colsum_kernel, dim3((SMALL_CT + 255) / 256), dim3(256), 0, s, d_ksk, d_colsum4);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void modswitch_kernel(const uint64_t *__restrict__ ks, uint32_t *__restrict__ ms,
+                                                        size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) ms[i] = mod_switch(ks[i]);
+}
+hipError_t launch_modswitch(const uint64_t *d_ks, uint32_t *d_ms, int B, hipStream_t s) {
+    const size_t n = (size_t)B * SMALL_CT;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(modswitch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_ks, d_ms, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_keyswitch(const uint64_t *d_in, const uint64_t *d_ksk, const uint64_t *d_colsum4,
+                            uint64_t *d_ks_out, int B, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    dim3 grid((B + KS_CT_TILE - 1) / KS_CT_TILE, (SMALL_CT + KS_COLS - 1) / KS_COLS);
-    hipLaunchKernelGGL(keyswitch_modswitch_kernel, grid, dim3(256), 0, s, d_in, d_ksk, d_ms, B);
+    hipError_t e = hipMemsetAsync(d_ks_out, 0, (size_t)B * SMALL_CT * 8, s);
+    if (e != hipSuccess) return e;
+    const int tiles = (B + KS_CT_TILE - 1) / KS_CT_TILE;
+    const int colb = (SMALL_CT + KS_COLS - 1) / KS_COLS;
+    int splits = 4;                                   // rows_per_split <= KS_MAX_ROWS
+    while (splits < 64 && tiles * colb * splits < 768) splits *= 2;
+    dim3 grid(tiles, colb, splits);
+    hipLaunchKernelGGL(keyswitch_kernel, grid, dim3(256), 0, s, d_in, d_ksk, d_colsum4, d_ks_out, B,
+                       BIG_N / splits);
     return hipGetLastError();
 }
 
