@@ -36,7 +36,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--chars", type=int, default=64, help="plaintext characters per rank")
     ap.add_argument("--pattern-len", type=int, default=4)
-    ap.add_argument("--strings", type=int, default=1, help="independent strings per step (batch)")
+    ap.add_argument("--strings", type=int, default=8,
+                    help="independent FheStrings per step: one 64-char contains() has ~560 PBS in 4 dependent "
+                         "levels and cannot fill 256 CUs, so a step is a batch (single-op latency is reported too)")
     ap.add_argument("--mode", choices=["fused", "as_written"], default="fused")
     ap.add_argument("--op", choices=["contains", "find"], default="contains")
     ap.add_argument("--cpu-pbs", type=int, default=-1, help="PBS in the CPU-baseline sample (0 = skip)")
@@ -145,6 +147,20 @@ def main():
     st = sk.stats()
     kt = sk.ctx.kernel_timing()
 
+    # latency of ONE op on one string (same workload, batch of 1), outside the timed region above
+    single_ms = None
+    if args.strings > 1:
+        keep = job.run(shards[0], pattern, op=args.op)   # an unreferenced result is dead code: keep it
+        sk.flush()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            keep = job.run(shards[0], pattern, op=args.op)
+            sk.flush()
+        sync()
+        del keep
+        single_ms = (time.perf_counter() - t1) / 3 * 1e3
+
     # correctness of what was timed (decrypt-level, against python str semantics)
     for s, o in zip(strings, outs):
         got = ck.decrypt_char(o)
@@ -191,6 +207,7 @@ def main():
                                    "%d string(s)/step, %s DAG" % (args.op, args.chars, m, args.strings, args.mode),
                        "parallelism": "windows sharded over %d GPU(s), 1 all-gather" % world},
             "ms_per_op": dt / args.steps / args.strings * 1e3,
+            "single_op_latency_ms": single_ms if single_ms is not None else dt / args.steps * 1e3,
             "pbs_per_op": pbs_total / args.steps / args.strings,
             "levels_per_op": st["levels"] / args.steps,
             "max_level_width": st["max_level_width"],

@@ -227,13 +227,10 @@ FChar Strings::find(const FStr &s, const FStr &pat) {        // mod.rs:1010-1053
         return t(0);
     }
     if (pat.size() > s.size()) return t(255);
+    if (fused()) return f_find(s, pat);
     for (size_t i = s.size() - pat.size() + 1; i-- > 0;) {
         FChar flag = one;
-        if (fused()) {
-            flag = pat.empty() ? one : ch_flag(e_, window_match(s, i, pat));
-        } else {
-            for (size_t j = pat.size(); j-- > 0;) flag = ch_bitand(flag, ch_eq(pat[j], s[i + j]));
-        }
+        for (size_t j = pat.size(); j-- > 0;) flag = ch_bitand(flag, ch_eq(pat[j], s[i + j]));
         pos = ch_ite(flag, t((uint8_t)i), pos);
     }
     return pos;
@@ -434,13 +431,14 @@ FChar Strings::flags_and(const FStr &flags) {
     return ch_flag(e_, and_tree(f));
 }
 
+// Equality of two chars as the AND of 2 flags: nibbles (x0 + 4 x1, x2 + 4 x3) are packed linearly,
+// and (a_nib - b_nib) in [-15, 15] is tested with the `is0` LUT.  That LUT is safe under the
+// padding-bit rule: a negative difference lands on 32-k, whose PBS value is -f(16-k) = -0 = 0.
 std::vector<Ref> Strings::block_eq_flags(const FChar &a, const FChar &b) {
     std::vector<Ref> f;
-    for (int i = 0; i < 4; i++) {
-        const Ref &x = a.b[i], &y = b.b[i];
-        if (e_->is_triv(y.id())) f.push_back(pbs(x, LUT_EQ_C0 + (e_->triv_val(y.id()) & 3)));
-        else if (e_->is_triv(x.id())) f.push_back(pbs(y, LUT_EQ_C0 + (e_->triv_val(x.id()) & 3)));
-        else f.push_back(pbs(lin(e_, {{4, &x}, {1, &y}}), LUT_EQ_BIV));
+    for (int h = 0; h < 2; h++) {
+        Ref d = lin(e_, {{1, &a.b[2 * h]}, {4, &a.b[2 * h + 1]}, {-1, &b.b[2 * h]}, {-4, &b.b[2 * h + 1]}});
+        f.push_back(pbs(d, LUT_IS0));
     }
     return f;
 }
@@ -457,6 +455,75 @@ FChar Strings::f_contains(const FStr &s, const FStr &needle) {
     std::vector<Ref> w;
     for (size_t i = 0; i + needle.size() <= s.size(); i++) w.push_back(window_match(s, i, needle));
     return ch_flag(e_, or_tree(w));
+}
+
+// exclusive prefix OR of flags in log_15 depth: p[i] = OR_{k<i} f[k]
+std::vector<Ref> Strings::prefix_or(const std::vector<Ref> &f) {
+    const size_t n = f.size();
+    std::vector<Ref> p(n);
+    if (n == 0) return p;
+    const size_t nchunks = (n + 14) / 15;
+    std::vector<Ref> q;                      // exclusive prefix OR over whole chunks
+    if (nchunks > 1) {
+        std::vector<Ref> any(nchunks - 1);   // the last chunk's total is never needed
+        for (size_t j = 0; j + 1 < nchunks; j++) any[j] = pbs(sum_refs(e_, &f[15 * j], 15), LUT_NZ);
+        any.push_back(trivial_block(e_, 0));
+        q = prefix_or(any);
+    } else {
+        q.push_back(trivial_block(e_, 0));
+    }
+    for (size_t i = 0; i < n; i++) {
+        const size_t j = i / 15, k = i % 15;
+        Term tt[16];
+        size_t m = 0;
+        for (size_t u = 0; u < k; u++) tt[m++] = {1, f[15 * j + u].id()};
+        tt[m++] = {1, q[j].id()};
+        Ref sm(e_, e_->lin(tt, m, 0));       // <= 14 + 1
+        p[i] = pbs(sm, LUT_NZ);              // folds to a constant when everything is trivial
+    }
+    return p;
+}
+
+// find (mod.rs:1010-1053) re-associated: window flags, exclusive prefix OR, first = f & !prefix,
+// position digits as sums of first_i * digit(i) (at most one term is non-zero), 255 when absent.
+FChar Strings::f_find(const FStr &s, const FStr &pat) {
+    const size_t W = s.size() - pat.size() + 1;
+    std::vector<Ref> f(W);
+    for (size_t i = 0; i < W; i++) f[i] = pat.empty() ? trivial_block(e_, 1) : window_match(s, i, pat);
+    std::vector<Ref> p = prefix_or(f);
+    std::vector<Ref> first(W);
+    for (size_t i = 0; i < W; i++) first[i] = pbs(lin(e_, {{2, &f[i]}, {1, &p[i]}}), LUT_IS2);
+    Ref found = or_tree(f);
+    Ref one = trivial_block(e_, 1);
+    Ref nf = lin(e_, {{1, &one}, {-1, &found}});
+    FChar r;
+    for (int blk = 0; blk < 4; blk++) {
+        // level 0: groups of <= 15 windows, each group sum is in [0,3]
+        std::vector<Ref> cur;
+        for (size_t g = 0; g < W; g += 15) {
+            Term tt[16];
+            size_t m = 0;
+            for (size_t i = g; i < std::min(W, g + 15); i++) {
+                const int dig = (int)((i >> (2 * blk)) & 3);
+                if (dig) tt[m++] = {dig, first[i].id()};
+            }
+            cur.push_back(Ref(e_, e_->lin(tt, m, 0)));
+        }
+        while (cur.size() > 15) {            // refresh noise, regroup
+            std::vector<Ref> nxt;
+            for (size_t g = 0; g < cur.size(); g += 15) {
+                std::vector<Ref> fresh;
+                for (size_t i = g; i < std::min(cur.size(), g + 15); i++) fresh.push_back(pbs(cur[i], LUT_MSG));
+                nxt.push_back(sum_refs(e_, fresh.data(), fresh.size()));
+            }
+            cur.swap(nxt);
+        }
+        std::vector<Ref> fresh;
+        for (Ref &c : cur) fresh.push_back(cur.size() > 1 ? pbs(c, LUT_MSG) : c);
+        Ref digit = fresh.size() == 1 ? fresh[0] : sum_refs(e_, fresh.data(), fresh.size());
+        r.b[blk] = lin(e_, {{1, &digit}, {3, &nf}});   // 255 = 3,3,3,3 when absent
+    }
+    return r;
 }
 
 // sum of 0/1 flags mod 256: groups of 15 -> (low, high) digit pair, then 4-operand radix adds

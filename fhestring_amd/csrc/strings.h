@@ -61,6 +61,8 @@ class Strings {
     Ref window_match(const FStr &s, size_t at, const FStr &pat);
     FChar count_flags(std::vector<Ref> flags);   // sum of 0/1 flags mod 256 as a 4-block char
     Ref is_upper_flag(const FChar &c, bool lower);
+    std::vector<Ref> prefix_or(const std::vector<Ref> &f);
+    FChar f_find(const FStr &s, const FStr &pat);
     FChar f_contains(const FStr &s, const FStr &needle);
     FChar f_len(const FStr &s);
     FChar f_eq(const FStr &a, const FStr &b);
