@@ -58,8 +58,14 @@ class ShardedContains:
         mine = torch.empty(CHAR_WORDS, dtype=torch.int64, device=dev)
         sk.export_device(local, mine.data_ptr())          # flushes this rank's DAG
         allp = torch.empty(self.world * CHAR_WORDS, dtype=torch.int64, device=dev)
-        self.dist.all_gather_into_tensor(allp, mine)
+        if dev == "cuda" and self.dist.get_backend() != "nccl":
+            # CPU-side process group (tests: several ranks sharing one GPU): stage through the host
+            parts_cpu = [torch.empty(CHAR_WORDS, dtype=torch.int64) for _ in range(self.world)]
+            self.dist.all_gather(parts_cpu, mine.cpu())
+            allp.copy_(torch.cat(parts_cpu))
+        else:
+            self.dist.all_gather_into_tensor(allp, mine)   # RCCL over xGMI: world x 65 568 B
         if dev == "cuda":
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.synchronize()
         parts = [sk.import_device(allp.data_ptr() + 8 * CHAR_WORDS * r) for r in range(self.world)]
         return sk.flags_or(parts)

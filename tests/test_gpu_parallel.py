@@ -1,0 +1,44 @@
+"""Two ranks on one MI355X (gloo group, both contexts on GPU 0): the real sharded contains() --
+window plan, per-rank DAG, export, all-gather, import, final OR level -- against python `in`."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["FHS_ROOT"])
+from fhestring_amd.api import MyClientKey, MyServerKey
+from fhestring_amd.parallel import ShardedContains
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ck = MyClientKey(0xF5E57121)                 # same seed -> same keys on every rank
+sk = MyServerKey.from_client_key(ck, 0)
+sk.set_mode(1)
+job = ShardedContains(sk, rank, world, dist, torch)
+ok = True
+for s, p in [("the quick brown fox jumps over", "n fo"), ("the quick brown fox jumps over", "zama"),
+             ("abcabcabcabd", "cabd")]:
+    shard = job.upload_shard(ck, s, len(s) // world, len(p))
+    got = ck.decrypt_char(job.run(shard, p))
+    ok &= (got == int(p in s))
+dist.barrier()
+dist.destroy_process_group()
+sk.close()
+sys.exit(0 if ok else 3)
+'''
+
+
+def test_sharded_contains_two_ranks_one_gpu(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, FHS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    rcs = [p.wait(timeout=500) for p in procs]
+    assert rcs == [0, 0]
