@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--mode", choices=["fused", "as_written"], default="fused")
     ap.add_argument("--op", choices=["contains", "find"], default="contains")
     ap.add_argument("--cpu-pbs", type=int, default=-1, help="PBS in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--skip-single-op", action="store_true",
+                    help="do not run the extra single-op latency section (profiling: every launch is then timed)")
     return ap.parse_args()
 
 
@@ -149,7 +151,7 @@ def main():
 
     # latency of ONE op on one string (same workload, batch of 1), outside the timed region above
     single_ms = None
-    if args.strings > 1:
+    if args.strings > 1 and not args.skip_single_op:
         keep = job.run(shards[0], pattern, op=args.op)   # an unreferenced result is dead code: keep it
         sk.flush()
         sync()
