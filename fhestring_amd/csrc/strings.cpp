@@ -303,6 +303,7 @@ FStr Strings::strip_suffix(const FStr &s_in, const FStr &needle, FChar *found) {
 }
 
 FChar Strings::comparison(const FStr &a_in, const FStr &b_in, int cmp) {   // mod.rs:1470-1541
+    if (fused()) return f_comparison(a_in, b_in, cmp);
     const FChar zero = t(0), t255 = t(255);
     FStr a = a_in, b = b_in;
     size_t min_len = std::min(a.size(), b.size());
@@ -524,6 +525,45 @@ FChar Strings::f_find(const FStr &s, const FStr &pat) {
         r.b[blk] = lin(e_, {{1, &digit}, {3, &nf}});   // 255 = 3,3,3,3 when absent
     }
     return r;
+}
+
+// comparison (mod.rs:1470-1541) re-associated.  The reference's 4-op state machine per character
+// (:1504-1513) selects the comparison result at the FIRST differing position; there `le` equals `lt`
+// and `ge` equals `gt`, so: pick_i = X_i & !prefix_or(differs)_i with X = lt (lt, le) or gt (gt, ge),
+// ret = OR pick_i.  When no position differs (the reference's 255 sentinel, :1483,1518) the result is
+// the length-based comparison (:1520-1538).
+FChar Strings::f_comparison(const FStr &a_in, const FStr &b_in, int cmp) {
+    FStr a = a_in, b = b_in;
+    size_t min_len = std::min(a.size(), b.size());
+    if (min_len == 0) {                                      // :1490-1494
+        a.push_back(t(0));
+        b.push_back(t(0));
+        min_len = 1;
+    }
+    Ref one = trivial_block(e_, 1);
+    std::vector<Ref> differs(min_len), x(min_len);
+    const int xl = (cmp == 0 || cmp == 1) ? LUT_CMP_LT : LUT_CMP_GT;
+    for (size_t i = 0; i < min_len; i++) {
+        Ref eq = and_tree(block_eq_flags(a[i], b[i]));
+        differs[i] = lin(e_, {{1, &one}, {-1, &eq}});
+        x[i] = blk_cmp_flag(a[i], b[i], xl);
+    }
+    std::vector<Ref> before = prefix_or(differs);
+    std::vector<Ref> pick(min_len);
+    for (size_t i = 0; i < min_len; i++) pick[i] = pbs(lin(e_, {{2, &x[i]}, {1, &before[i]}}), LUT_IS2);
+    Ref ret = or_tree(pick);                                 // at most one pick is set
+    Ref any_diff = or_tree(differs);
+    FChar l1 = f_len(a), l2 = f_len(b);                      // :1520-1521 (after the padding push, like the reference)
+    Ref by_len;
+    switch (cmp) {
+        case 0: by_len = blk_cmp_flag(l1, l2, LUT_CMP_LT); break;
+        case 1: by_len = blk_cmp_flag(l1, l2, LUT_CMP_LE); break;   // eq | lt (:1528)
+        case 2: by_len = blk_cmp_flag(l1, l2, LUT_CMP_GT); break;
+        default: by_len = blk_cmp_flag(l1, l2, LUT_CMP_GE); break;  // eq | gt (:1527)
+    }
+    // result = any_diff ? ret : by_len; ret is 0 whenever nothing differs
+    Ref sel = pbs(lin(e_, {{2, &by_len}, {1, &any_diff}}), LUT_IS2);   // by_len & !any_diff
+    return ch_flag(e_, lin(e_, {{1, &sel}, {1, &ret}}));
 }
 
 // sum of 0/1 flags mod 256: groups of 15 -> (low, high) digit pair, then 4-operand radix adds

@@ -63,6 +63,7 @@ class Strings {
     Ref is_upper_flag(const FChar &c, bool lower);
     std::vector<Ref> prefix_or(const std::vector<Ref> &f);
     FChar f_find(const FStr &s, const FStr &pat);
+    FChar f_comparison(const FStr &a, const FStr &b, int cmp);
     FChar f_contains(const FStr &s, const FStr &needle);
     FChar f_len(const FStr &s);
     FChar f_eq(const FStr &a, const FStr &b);

@@ -1,0 +1,67 @@
+"""BASELINE.json configs at full size on the GPU, checked through size-independent properties
+(decrypt-level against python str semantics on the same synthetic strings)."""
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = 0xF5E57121
+
+
+@pytest.fixture(scope="module")
+def product():
+    from fhestring_amd.api import MyClientKey
+    ck = MyClientKey(SEED)
+    sk = ck.get_server_key()
+    sk.set_mode(1)
+    yield ck, sk
+    sk.close()
+    ck.close()
+
+
+def _rand(rnd, n):
+    return "".join(chr(rnd.randint(0x20, 0x7E)) for _ in range(n))
+
+
+def test_config2_contains_64_hit_and_miss(product):
+    ck, sk = product
+    rnd = random.Random(SEED)
+    s = _rand(rnd, 64)
+    es = ck.encrypt(s, 1, None, sk)
+    for m in (4, 8):
+        off = rnd.randint(0, 64 - m)
+        hit = s[off:off + m]
+        miss = hit[:-1] + ("~" if hit[-1] != "~" else "}")
+        assert ck.decrypt_char(sk.contains_clear(es, hit)) == 1
+        assert ck.decrypt_char(sk.contains_clear(es, miss)) == int(miss in s)
+
+
+def test_config3_find_256_encrypted_pattern(product):
+    ck, sk = product
+    rnd = random.Random(SEED + 1)
+    s = list(_rand(rnd, 256))
+    pat = "Qz7#"
+    s[200:204] = pat                     # planted at offset 200
+    s = "".join(s)
+    es = ck.encrypt(s, 1, None, sk)
+    assert ck.decrypt_char(sk.find(es, ck.encrypt_no_padding(pat, sk))) == s.find(pat)
+    assert ck.decrypt_char(sk.find(es, ck.encrypt_no_padding("\x7f\x7f\x7f", sk))) == 255   # miss -> 255
+
+
+def test_config5_eq_ignore_case_and_le_4096(product):
+    ck, sk = product
+    rnd = random.Random(SEED + 2)
+    a = _rand(rnd, 4096)
+    b = list(a.swapcase())
+    ea = ck.encrypt(a, 1, None, sk)
+    eb = ck.encrypt("".join(b), 1, None, sk)
+    assert ck.decrypt_char(sk.eq_ignore_case(ea, eb)) == 1
+    b[4000] = "a" if a[4000].lower() != "a" else "b"      # equal up to case except position 4000
+    b = "".join(b)
+    eb2 = ck.encrypt(b, 1, None, sk)
+    assert ck.decrypt_char(sk.eq_ignore_case(ea, eb2)) == 0
+    assert ck.decrypt_char(sk.le(ea, eb2)) == int(a <= b)
+    assert ck.decrypt_char(sk.le(eb2, ea)) == int(b <= a)
+    assert ck.decrypt_char(sk.len(ea)) == 4096 % 256      # u8 wrap, like the reference (G10)
+    st = sk.stats()
+    assert st["levels"] < 400                              # the as-written DAGs are 16k-24k levels deep
