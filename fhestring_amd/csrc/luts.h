@@ -19,6 +19,8 @@ enum LutId : uint16_t {
     LUT_MUX2,          // 2*cond + x (x in {0,1}) helper: v -> (v>>1) ? (v&1) : 0
     LUT_LE10,          // v <= 10 (low nibble of 'P'..'Z' / 'p'..'z')
     LUT_CASEFLAG,      // v = (h_a + lo_nz) + 4*(h_b + lo_le10) -> letter-of-that-case flag
+    LUT_BIT0_UNLESS,   // v = digit + 4*mask -> mask ? 0 : digit & 1
+    LUT_BIT1_UNLESS,   // v = digit + 4*mask -> mask ? 0 : (digit >> 1) & 1
     LUT_COUNT
 };
 
@@ -50,6 +52,8 @@ inline int lut_function(int id, int v) {
         case LUT_MUX2: return (v >> 1) ? (v & 1) : 0;
         case LUT_LE10: return v <= 10;
         case LUT_CASEFLAG: return ((v & 3) == 2) || ((v >> 2) == 2);
+        case LUT_BIT0_UNLESS: return (v >> 2) ? 0 : (v & 1);
+        case LUT_BIT1_UNLESS: return (v >> 2) ? 0 : ((v >> 1) & 1);
         default: break;
     }
     if (id >= LUT_EQ_C0 && id <= LUT_EQ_C3) return v == id - LUT_EQ_C0;

@@ -18,6 +18,7 @@ FStr Strings::clear(const char *s, size_t n) const {
 // as written (same op sequence as the reference; cf. oracle/strings.py)
 // ---------------------------------------------------------------------------------------------
 FStr Strings::bubble_zeroes_right(const FStr &in) {          // utils.rs:28-46
+    if (fused()) return f_compact(in);
     FStr s = in;
     const FChar zero = t(0);
     for (size_t pass = 0; pass < s.size(); pass++)
@@ -149,12 +150,14 @@ FStr Strings::longer_from(const FStr &s, const FStr &from, FStr to, const FChar 
         const size_t end = adjust_end_of_pattern(result.size() - from.size());
         for (size_t i = 0; i < end; i++) {
             FChar flag = one;
-            for (size_t j = 0; j < from.size(); j++) flag = ch_bitand(flag, ch_eq(from[j], data[i + j]));
+            if (fused() && !from.empty()) flag = ch_flag(e_, window_match(data, i, from));
+            else for (size_t j = 0; j < from.size(); j++) flag = ch_bitand(flag, ch_eq(from[j], data[i + j]));
             if (use_counter) {                              // :868-872
                 counter = ch_add(counter, flag);
                 flag = ch_bitand(flag, ch_ge(n, counter));
             }
-            for (size_t k = 0; k < to.size(); k++) result[i + k] = ch_ite(flag, to[k], result[i + k]);
+            for (size_t k = 0; k < to.size(); k++)
+                result[i + k] = fused() ? ite_flag(flag.b[0], to[k], result[i + k]) : ch_ite(flag, to[k], result[i + k]);
         }
     }
     return bubble_zeroes_right(result);                     // :881
@@ -564,6 +567,124 @@ FChar Strings::f_comparison(const FStr &a_in, const FStr &b_in, int cmp) {
     // result = any_diff ? ret : by_len; ret is 0 whenever nothing differs
     Ref sel = pbs(lin(e_, {{2, &by_len}, {1, &any_diff}}), LUT_IS2);   // by_len & !any_diff
     return ch_flag(e_, lin(e_, {{1, &sel}, {1, &ret}}));
+}
+
+// cond ? t : f with cond a clean single-block 0/1 flag (no scalar_ne needed)
+FChar Strings::ite_flag(const Ref &flag, const FChar &tv, const FChar &fv) {
+    FChar r;
+    for (int i = 0; i < 4; i++) {
+        Ref a = pbs(lin(e_, {{4, &flag}, {1, &tv.b[i]}}), LUT_SEL_T);
+        Ref b = pbs(lin(e_, {{4, &flag}, {1, &fv.b[i]}}), LUT_SEL_F);
+        r.b[i] = lin(e_, {{1, &a}, {1, &b}});
+    }
+    return r;
+}
+
+// sum of up to 4 base-4 numbers (+ carry) with a sequential carry chain; result has `digits` digits
+Strings::Num Strings::num_add(const std::vector<const Num *> &ops, size_t digits) {
+    Num r(digits);
+    Ref carry;
+    for (size_t d = 0; d < digits; d++) {
+        Term tt[8];
+        size_t k = 0;
+        for (const Num *o : ops)
+            if (d < o->size()) tt[k++] = {1, (*o)[d].id()};
+        if (carry) tt[k++] = {1, carry.id()};
+        Ref sm(e_, e_->lin(tt, k, 0));                      // <= 4*3 + 3
+        r[d] = pbs(sm, LUT_MSG);
+        if (d + 1 < digits) carry = pbs(sm, LUT_CARRY);
+    }
+    return r;
+}
+
+// exclusive prefix sums of numbers, 4-ary recursion (depth log4(n) x 2 adds)
+std::vector<Strings::Num> Strings::num_exclusive_scan(const std::vector<Num> &x, size_t digits) {
+    const size_t n = x.size();
+    std::vector<Num> out(n);
+    Num zero(digits);
+    for (auto &d : zero) d = trivial_block(e_, 0);
+    if (n == 0) return out;
+    if (n == 1) { out[0] = zero; return out; }
+    const size_t ng = (n + 3) / 4;
+    std::vector<Num> local(n), totals(ng);
+    for (size_t g = 0; g < ng; g++) {
+        const size_t lo = 4 * g, hi = std::min(n, lo + 4);
+        std::vector<const Num *> ops;
+        for (size_t i = lo; i < hi; i++) {
+            local[i] = ops.empty() ? zero : (ops.size() == 1 ? *ops[0] : num_add(ops, digits));
+            ops.push_back(&x[i]);
+        }
+        totals[g] = ops.size() == 1 ? *ops[0] : num_add(ops, digits);
+    }
+    std::vector<Num> offs = num_exclusive_scan(totals, digits);
+    for (size_t i = 0; i < n; i++) out[i] = num_add({&offs[i / 4], &local[i]}, digits);
+    return out;
+}
+
+// Oblivious order-preserving compaction: non-NUL characters move left by the number of NULs before
+// them.  Shifts are prefix counts (base-4 numbers), routed LSB first through log2(n) conditional
+// moves by 2^k -- collision-free for monotone compaction.  Same result as the reference's n-pass
+// bubble (utils.rs:28-46) in O(n log n) PBS and O(log n) wide levels instead of O(n^2) / O(n).
+FStr Strings::f_compact(const FStr &s) {
+    const size_t n = s.size();
+    if (n <= 1) return s;
+    int K = 0;
+    while (((size_t)1 << K) < n) K++;                       // shifts are < n
+    const size_t D = (size_t)(K + 1) / 2;
+    const FChar zero = t(0);
+    std::vector<Ref> z(n);
+    for (size_t i = 0; i < n; i++) z[i] = and_tree(block_eq_flags(s[i], zero));
+    // per-position shift = (NULs in earlier chunks) + (NULs earlier in this chunk)
+    const size_t nch = (n + 14) / 15;
+    std::vector<Num> tot(nch);
+    for (size_t j = 0; j < nch; j++) {
+        const size_t cnt = std::min<size_t>(15, n - 15 * j);
+        Ref sm = sum_refs(e_, &z[15 * j], cnt);
+        tot[j] = Num(D);
+        for (size_t d = 0; d < D; d++) tot[j][d] = d == 0 ? pbs(sm, LUT_MSG) : (d == 1 ? pbs(sm, LUT_CARRY) : trivial_block(e_, 0));
+    }
+    std::vector<Num> offs = num_exclusive_scan(tot, D);
+    std::vector<std::vector<Ref>> bits(n, std::vector<Ref>(K));
+    for (size_t i = 0; i < n; i++) {
+        const size_t j = i / 15, k = i % 15;
+        Num loc(D);
+        Ref e = k ? sum_refs(e_, &z[15 * j], k) : trivial_block(e_, 0);
+        for (size_t d = 0; d < D; d++) loc[d] = d == 0 ? pbs(e, LUT_MSG) : (d == 1 ? pbs(e, LUT_CARRY) : trivial_block(e_, 0));
+        Num sh = num_add({&offs[j], &loc}, D);
+        for (int b = 0; b < K; b++) {
+            if (((size_t)1 << b) > i) { bits[i][b] = trivial_block(e_, 0); continue; }   // shift <= i
+            bits[i][b] = pbs(lin(e_, {{1, &sh[b / 2]}, {4, &z[i]}}), (b & 1) ? LUT_BIT1_UNLESS : LUT_BIT0_UNLESS);
+        }
+    }
+    FStr cur = s;
+    for (int k = 0; k < K; k++) {
+        const size_t d = (size_t)1 << k;
+        FStr nxt(n);
+        std::vector<std::vector<Ref>> nb(n, std::vector<Ref>(K));
+        for (size_t p = 0; p < n; p++) {
+            const Ref &bs = bits[p][k];
+            // statically known bits (shift <= position) need no PBS
+            const bool stays = e_->is_triv(bs.id()) && e_->triv_val(bs.id()) == 0;
+            const bool has_src = p + d < n && !(e_->is_triv(bits[p + d][k].id()) && e_->triv_val(bits[p + d][k].id()) == 0);
+            for (int blk = 0; blk < 4; blk++) {
+                Ref st = stays ? cur[p].b[blk] : pbs(lin(e_, {{4, &bs}, {1, &cur[p].b[blk]}}), LUT_SEL_F);
+                if (has_src) {
+                    Ref in = pbs(lin(e_, {{4, &bits[p + d][k]}, {1, &cur[p + d].b[blk]}}), LUT_SEL_T);
+                    nxt[p].b[blk] = lin(e_, {{1, &in}, {1, &st}});
+                } else nxt[p].b[blk] = st;
+            }
+            for (int jb = k + 1; jb < K; jb++) {
+                Ref st = stays ? bits[p][jb] : pbs(lin(e_, {{2, &bs}, {1, &bits[p][jb]}}), LUT_IS1);   // stays and bit set
+                if (has_src) {
+                    Ref in = pbs(lin(e_, {{2, &bits[p + d][k]}, {1, &bits[p + d][jb]}}), LUT_IS3);
+                    nb[p][jb] = lin(e_, {{1, &in}, {1, &st}});
+                } else nb[p][jb] = st;
+            }
+        }
+        cur.swap(nxt);
+        bits.swap(nb);
+    }
+    return cur;
 }
 
 // sum of 0/1 flags mod 256: groups of 15 -> (low, high) digit pair, then 4-operand radix adds

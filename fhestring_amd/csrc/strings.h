@@ -64,6 +64,12 @@ class Strings {
     std::vector<Ref> prefix_or(const std::vector<Ref> &f);
     FChar f_find(const FStr &s, const FStr &pat);
     FChar f_comparison(const FStr &a, const FStr &b, int cmp);
+    // oblivious compaction: replaces the O(n^2) bubble of utils.rs:28-46 in fused mode
+    typedef std::vector<Ref> Num;   // little-endian base-4 digits, clean (<= 3)
+    Num num_add(const std::vector<const Num *> &ops, size_t digits);
+    std::vector<Num> num_exclusive_scan(const std::vector<Num> &x, size_t digits);
+    FStr f_compact(const FStr &s);
+    FChar ite_flag(const Ref &flag, const FChar &t, const FChar &f);
     FChar f_contains(const FStr &s, const FStr &needle);
     FChar f_len(const FStr &s);
     FChar f_eq(const FStr &a, const FStr &b);

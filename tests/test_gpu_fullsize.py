@@ -48,6 +48,24 @@ def test_config3_find_256_encrypted_pattern(product):
     assert ck.decrypt_char(sk.find(es, ck.encrypt_no_padding("\x7f\x7f\x7f", sk))) == 255   # miss -> 255
 
 
+def test_config4_replace_1024(product):
+    """replace with encrypted from/to (5 -> 5) on a 1024-char string, 8 planted occurrences: as written
+    this is 36.9 M PBS (99.5 % in the O(n^2) bubble); the compaction makes it ~0.3 M."""
+    ck, sk = product
+    rnd = random.Random(SEED + 3)
+    s = list(_rand(rnd, 1024).replace("~", "-"))
+    frm, to = "~from", "[to!]"
+    for k in range(8):
+        off = 20 + 120 * k
+        s[off:off + 5] = frm
+    s = "".join(s)
+    sk.stats(reset=True)
+    out = sk.replace(ck.encrypt(s, 1, None, sk), ck.encrypt_no_padding(frm, sk), ck.encrypt_no_padding(to, sk))
+    assert ck.decrypt(out) == s.replace(frm, to)
+    st = sk.stats()
+    assert st["pbs_executed"] < 1_000_000 and st["levels"] < 400
+
+
 def test_config5_eq_ignore_case_and_le_4096(product):
     ck, sk = product
     rnd = random.Random(SEED + 2)
