@@ -100,3 +100,12 @@ def test_cipher_model_golden_less_than(oracle_keys, oracle_sk):
     v = [x for x in load_vectors() if x["name"] == "less_than"][0]
     eng, env = _cipher_env(oracle_keys, oracle_sk)
     check_vector(v, run_vector(v, *env))
+
+
+def test_config1_eq_hello_hello_on_the_cpu_oracle(oracle_keys, oracle_sk):
+    """BASELINE.json configs[0]: eq("hello","hello") on the CPU path, as the CLI does it
+    (src/utils.rs:691-703: both strings encrypted with STRING_PADDING = 1)."""
+    eng, (ops, enc_s, enc_p, enc_c, dec_s, dec_c) = _cipher_env(oracle_keys, oracle_sk)
+    a, b = enc_s("hello", 1), enc_s("hello", 1)
+    assert dec_c(ops.eq(a, b)) == 1
+    assert eng.pbs_count > 100 and eng.levels >= 10
