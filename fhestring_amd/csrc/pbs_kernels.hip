@@ -203,6 +203,52 @@ __device__ __forceinline__ int64_t f64_to_i64_exact(double v) {   // |v| < 2^51,
     return (int64_t)(__builtin_bit_cast(uint64_t, v + M) - __builtin_bit_cast(uint64_t, M));
 }
 
+
+// ---- phases that depend on the ownership parity Q (compile-time, so x[] and acc[] stay in registers) ----
+template <int Q>
+__device__ __forceinline__ void phase_digits(double (&x)[32], const uint64_t (&acc)[16], const uint64_t *s_base,
+                                             double *sib_w, int lane, uint32_t s, bool neg) {
+#pragma unroll
+    for (int o = 0; o < 16; o++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int r = 2 * o + Q;
+        const uint32_t n = lane + 64 * r;
+        const uint32_t m = (n - s) & (POLY_N - 1);                 // source coefficient of X^s * acc
+        uint64_t v = s_base[((m >> 6) & 1) * LDS_WAVE_SLOTS + m];
+        if ((n < s) != neg) v = (uint64_t)0 - v;
+        const uint64_t d = v - acc[o];
+        const int32_t dig = (int32_t)((uint32_t)(d >> 32) + 0x100u) >> 9;
+        const double dg = (double)dig;                             // identical for both primes (|dig| < p)
+        x[r] = dg;
+        sib_w[n] = dg;
+    }
+}
+template <int Q>
+__device__ __forceinline__ void phase_other_digits(double (&x)[32], const double *my, int lane) {
+#pragma unroll
+    for (int o = 0; o < 16; o++) x[2 * o + (1 - Q)] = my[lane + 64 * (2 * o + (1 - Q))];
+}
+template <int Q>
+__device__ __forceinline__ void phase_publish_residues(const double (&x)[32], double *my, int lane) {
+#pragma unroll
+    for (int o = 0; o < 16; o++) my[lane + 64 * (2 * o + (1 - Q))] = x[2 * o + (1 - Q)];
+}
+template <int Q>
+__device__ __forceinline__ void phase_crt(const double (&x)[32], uint64_t (&acc)[16], const double *sibling,
+                                          uint64_t *my_u, int lane, double crt_c, double p1, double p1inv) {
+#pragma unroll
+    for (int o = 0; o < 16; o++) {
+        const int r = 2 * o + Q;
+        const double other = sibling[lane + 64 * r];
+        const double r0 = Q ? other : x[r];
+        const double r1 = Q ? x[r] : other;
+        const double t = mulmod(r1 - r0, crt_c, p1, p1inv);
+        const uint64_t v = (uint64_t)f64_to_i64_exact(r0) + NTT_P0 * (uint64_t)f64_to_i64_exact(t);
+        acc[o] += v << BSK_QUANT_BITS;
+        my_u[lane + 64 * r] = acc[o];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // blind rotation + sample extract: grid = B workgroups, block = 256 threads (4 wavefronts)
 // ------------------------------------------------------------------------------------------
@@ -229,8 +275,15 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
     const double twA = lane < 32 ? C_FWD_UNI[q][lane] : C_INV_UNI[q][lane];
     const double twB = C_INV_UNI[q][lane & 31];
 
-    // acc[r] = coefficient (lane + 64 r) of GLWE polynomial j, u64 torus
-    uint64_t acc[32];
+    // The accumulator of polynomial j is shared by the two prime-waves (j,0), (j,1): wave (j,q) OWNS
+    // the coefficients n = lane + 64 r with r = 2 o + q (o < 16).  It computes their digits and their
+    // CRT; digits and residues of the other half come from the sibling through LDS.  The natural-order
+    // image S_j used for the rotated reads is distributed the same way: coefficient n lives in the
+    // buffer of wave (j, r & 1) at slot n.  Slots of the opposite parity in a buffer carry what the
+    // sibling publishes (digits, then residues), so the four uses never overlap.
+    uint64_t acc[16];
+    double *sib_w = reinterpret_cast<double *>(smem) + (wave ^ 1) * LDS_WAVE_SLOTS;
+    const uint64_t *s_base = reinterpret_cast<const uint64_t *>(smem) + (size_t)(wave & ~1) * LDS_WAVE_SLOTS;
     {
         const uint32_t b = mod_switch(ks[LWE_N]);
         const uint32_t a = (2 * POLY_N - b) & (2 * POLY_N - 1);     // X^{-b} = X^{2N-b}
@@ -238,16 +291,18 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
         const bool neg = a >= POLY_N;
         const uint64_t *lut = P.luts + (size_t)P.lut_idx[ct] * POLY_N;
 #pragma unroll
-        for (int r = 0; r < 32; r++) {
+        for (int o = 0; o < 16; o++) {
+            const uint32_t n = lane + 64 * (2 * o + q);
             uint64_t v = 0;
             if (j == 1) {
-                const uint32_t n = lane + 64 * r;
                 v = (n >= s) ? lut[n - s] : (uint64_t)0 - lut[n - s + POLY_N];
                 if (neg) v = (uint64_t)0 - v;
             }
-            acc[r] = v;
+            acc[o] = v;
+            my_u[n] = v;
         }
     }
+    __syncthreads();
 
     for (int i = 0; i < LWE_N; i++) {
         const uint32_t a = mod_switch(ks[i]);
@@ -257,19 +312,11 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
 
         // ---- rotate, subtract, decompose (closest multiple of 2^41 -> signed 23-bit digit) ----
         double x[32];
-#pragma unroll
-        for (int r = 0; r < 32; r++) my_u[lane + 64 * r] = acc[r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 32; r++) {
-            const uint32_t n = lane + 64 * r;
-            const bool wrap = n < s;
-            uint64_t v = my_u[wrap ? n - s + POLY_N : n - s];
-            if (wrap != neg) v = (uint64_t)0 - v;
-            const uint64_t d = v - acc[r];
-            const int32_t dig = (int32_t)((uint32_t)(d >> 32) + 0x100u) >> 9;
-            x[r] = (double)dig;
-        }
+        if (q == 0) phase_digits<0>(x, acc, s_base, sib_w, lane, s, neg);
+        else phase_digits<1>(x, acc, s_base, sib_w, lane, s, neg);
+        __syncthreads();
+        if (q == 0) phase_other_digits<0>(x, my, lane);
+        else phase_other_digits<1>(x, my, lane);
         __builtin_amdgcn_wave_barrier();
 
         ntt_forward(x, my, lane, twA, fwd_lane, p, pinv);
@@ -314,43 +361,26 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
 
         ntt_inverse(x, my, lane, twA, twB, inv_lane, p, pinv);
 
-        // ---- CRT of the two residues, accumulate ----
-#pragma unroll
-        for (int r = 0; r < 32; r++) my[r * 64 + lane] = x[r];
+        // ---- exchange residues, CRT for the owned half, restage the accumulator ----
+        if (q == 0) phase_publish_residues<0>(x, my, lane);
+        else phase_publish_residues<1>(x, my, lane);
         __syncthreads();
-        if (q == 0) {
-#pragma unroll
-            for (int r = 0; r < 32; r++) {
-                const double r0 = x[r], r1 = sibling[r * 64 + lane];
-                const double t = mulmod(r1 - r0, crt_c, p1, p1inv);
-                const uint64_t v = (uint64_t)f64_to_i64_exact(r0) + NTT_P0 * (uint64_t)f64_to_i64_exact(t);
-                acc[r] += v << BSK_QUANT_BITS;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 32; r++) {
-                const double r0 = sibling[r * 64 + lane], r1 = x[r];
-                const double t = mulmod(r1 - r0, crt_c, p1, p1inv);
-                const uint64_t v = (uint64_t)f64_to_i64_exact(r0) + NTT_P0 * (uint64_t)f64_to_i64_exact(t);
-                acc[r] += v << BSK_QUANT_BITS;
-            }
-        }
+        if (q == 0) phase_crt<0>(x, acc, sibling, my_u, lane, crt_c, p1, p1inv);
+        else phase_crt<1>(x, acc, sibling, my_u, lane, crt_c, p1, p1inv);
         __syncthreads();
     }
 
     // ---- sample extract (coefficient 0): a'[0] = A[0], a'[n] = -A[N-n], b' = B[0] ----
     uint64_t *out = P.out_ptrs ? P.out_ptrs[ct] : P.out + (size_t)ct * BIG_CT;
-    if (q == 0) {
-        if (j == 0) {
+    if (j == 0) {
 #pragma unroll
-            for (int r = 0; r < 32; r++) {
-                const int n = lane + 64 * r;
-                if (n == 0) out[0] = acc[r];
-                else out[POLY_N - n] = (uint64_t)0 - acc[r];
-            }
-        } else if (lane == 0) {
-            out[BIG_N] = acc[0];
+        for (int o = 0; o < 16; o++) {
+            const int n = lane + 64 * (2 * o + q);
+            if (n == 0) out[0] = acc[o];
+            else out[POLY_N - n] = (uint64_t)0 - acc[o];
         }
+    } else if (q == 0 && lane == 0) {
+        out[BIG_N] = acc[0];
     }
 }
 
