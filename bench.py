@@ -71,25 +71,41 @@ def usable_cores():
 
 
 def cpu_baseline(n_pbs):
-    """The oracle (CPU restatement, exact NTT) timed on the host cores: kind 'port'."""
+    """CPU side by side (kind 'port'): the oracle's PBS on the host cores, same parameter set.
+    Two variants are timed and the FASTER one is the baseline: the exact
+    Goldilocks-NTT path (the parity oracle) and an f64-FFT external product (the algorithm class of the
+    reference's tfhe/concrete-fft; approximate, validated at decrypt level in tests/test_oracle_pbs.py)."""
     import numpy as np
     from oracle import core, radix
     cores = usable_cores()
-    if n_pbs < 0:
-        n_pbs = 4 * cores
     K = core.Keys(SEED)
     S = core.ServerKey(K)
     rng = np.random.default_rng(0)
-    cts = np.stack([K.encrypt_block(int(m)) for m in rng.integers(0, 16, n_pbs)])
     luts = np.stack([radix.lut_poly("eq_c1"), radix.lut_poly("is4")])
-    idx = (np.arange(n_pbs) % 2).astype(np.uint32)
-    S.pbs_batch(cts[:cores], idx[:cores], luts, cores)          # warm-up
-    t0 = time.perf_counter()
-    S.pbs_batch(cts, idx, luts, cores)
-    dt = time.perf_counter() - t0
-    return {"value": n_pbs / dt, "unit": "PBS/s", "cores": cores, "kind": "port",
-            "sample": "%d PBS of the same parameter set (KS+MS+blind rotation+extract) through "
-                      "oracle/tfhe_oracle.c on %d host threads, %.1f s" % (n_pbs, cores, dt)}
+
+    def run(mode, n):
+        msgs = rng.integers(0, 16, n)
+        cts = np.stack([K.encrypt_block(int(m)) for m in msgs])
+        idx = (np.arange(n) % 2).astype(np.uint32)
+        S.pbs_batch(cts[:cores], idx[:cores], luts, cores, mode=mode)      # warm-up
+        t0 = time.perf_counter()
+        out = S.pbs_batch(cts, idx, luts, cores, mode=mode)
+        dt = time.perf_counter() - t0
+        names = ["eq_c1", "is4"]
+        ok = all(K.decrypt_block(out[i]) == radix.LUTS[names[idx[i]]](int(msgs[i])) for i in range(min(n, 16)))
+        return n / dt, dt, ok
+
+    n_fft = n_pbs if n_pbs > 0 else 32 * cores
+    n_exact = max(cores, n_fft // 16)
+    fft_rate, fft_dt, fft_ok = run(2, n_fft)
+    ex_rate, ex_dt, ex_ok = run(0, n_exact)
+    assert fft_ok and ex_ok, "CPU baseline produced wrong plaintexts"
+    best = max(fft_rate, ex_rate)
+    return {"value": best, "unit": "PBS/s", "cores": cores, "kind": "port",
+            "sample": "oracle/tfhe_oracle.c on %d host threads, KS+MS+blind rotation+extract per PBS: "
+                      "f64-FFT external product %d PBS in %.1f s = %.1f PBS/s; exact NTT (parity oracle) "
+                      "%d PBS in %.1f s = %.1f PBS/s; faster variant reported"
+                      % (cores, n_fft, fft_dt, fft_rate, n_exact, ex_dt, ex_rate)}
 
 
 def main():

@@ -160,11 +160,84 @@ static void g_ntt_inv(u64 *a) {
     for (unsigned j = 0; j < POLY_N; j++) a[j] = g_mul(a[j], g_ninv);
 }
 
+
+/* ---- f64 FFT variant of the external product (mode 2) ---------------------
+ * The algorithm CLASS the reference's tfhe/concrete-fft uses (Cargo.lock:168-179): a negacyclic
+ * product through a 1024-point complex FFT of the folded polynomial z[n] = (x[n] + i x[n+N/2]) * zeta^n.
+ * It is approximate (53-bit mantissa): used ONLY as the faster CPU baseline in bench.py and checked
+ * at decrypt level against the exact path; it is never the parity oracle. */
+#define FFT_N (POLY_N / 2)
+static double fft_tw_re[FFT_N], fft_tw_im[FFT_N];     /* zeta^n, zeta = exp(i pi / N)         */
+static double fft_w_re[FFT_N / 2], fft_w_im[FFT_N / 2]; /* exp(-2 pi i k / FFT_N)             */
+static unsigned fft_rev[FFT_N];
+static int fft_ready = 0;
+static void fft_init(void) {
+    pthread_mutex_lock(&g_tab_mu);
+    if (!fft_ready) {
+        const double PI = 3.14159265358979323846;
+        for (int n = 0; n < FFT_N; n++) {
+            fft_tw_re[n] = cos(PI * n / POLY_N);
+            fft_tw_im[n] = sin(PI * n / POLY_N);
+            unsigned r = 0;
+            for (int b = 0; b < 10; b++) r |= ((n >> b) & 1u) << (9 - b);
+            fft_rev[n] = r;
+        }
+        for (int k = 0; k < FFT_N / 2; k++) {
+            fft_w_re[k] = cos(-2.0 * PI * k / FFT_N);
+            fft_w_im[k] = sin(-2.0 * PI * k / FFT_N);
+        }
+        fft_ready = 1;
+    }
+    pthread_mutex_unlock(&g_tab_mu);
+}
+/* in-place radix-2 DIT on bit-reversed input; inverse = conjugated twiddles, unscaled */
+static void fft_core(double *re, double *im, int inverse) {
+    for (int len = 2; len <= FFT_N; len <<= 1) {
+        const int half = len >> 1, step = FFT_N / len;
+        for (int i = 0; i < FFT_N; i += len)
+            for (int k = 0; k < half; k++) {
+                const double wr = fft_w_re[k * step], wi = inverse ? -fft_w_im[k * step] : fft_w_im[k * step];
+                const int a = i + k, b = a + half;
+                const double tr = re[b] * wr - im[b] * wi, ti = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - tr; im[b] = im[a] - ti;
+                re[a] += tr; im[a] += ti;
+            }
+    }
+}
+/* forward transform of a real polynomial given as doubles: out[k] (bit-reversed permuted input) */
+static void fft_forward_poly(const double *x, double *re, double *im) {
+    for (int n = 0; n < FFT_N; n++) {
+        const double a = x[n], b = x[n + FFT_N];
+        const unsigned r = fft_rev[n];
+        re[r] = a * fft_tw_re[n] - b * fft_tw_im[n];
+        im[r] = a * fft_tw_im[n] + b * fft_tw_re[n];
+    }
+    fft_core(re, im, 0);
+}
+/* inverse: spectrum -> polynomial coefficients (as doubles, exact value up to rounding) */
+static void fft_inverse_poly(double *re, double *im, double *x) {
+    static __thread double tr[FFT_N], ti[FFT_N];
+    for (int k = 0; k < FFT_N; k++) { tr[fft_rev[k]] = re[k]; ti[fft_rev[k]] = im[k]; }
+    fft_core(tr, ti, 1);
+    const double sc = 1.0 / FFT_N;
+    for (int n = 0; n < FFT_N; n++) {
+        const double zr = tr[n] * sc, zi = ti[n] * sc;          /* undo the twist: multiply by conj(zeta^n) */
+        x[n] = zr * fft_tw_re[n] + zi * fft_tw_im[n];
+        x[n + FFT_N] = zi * fft_tw_re[n] - zr * fft_tw_im[n];
+    }
+}
+static inline u64 f64_to_torus(double v) {                         /* v mod 2^64, round to nearest */
+    const double two64 = 18446744073709551616.0;
+    v -= two64 * nearbyint(v / two64);                              /* now |v| <= 2^63 */
+    return (u64)(i64)llrint(v);
+}
+
 /* ---- server key --------------------------------------------------------- */
 typedef struct {
     u64 *bsk;      /* [742][2 rows][2 cols][2048] std domain, quantised to 2^6 */
     u64 *ksk;      /* [2048][5][743]                                          */
     u64 *bsk_ntt;  /* [742][2 rows][2 cols][2 limbs][2048] Goldilocks NTT     */
+    double *bsk_fft; /* [742][2 rows][2 cols][1024] complex (re,im): f64-FFT variant (mode 2) */
 } orc_server_key;
 
 u64 orc_bsk_words(void) { return BSK_WORDS; }
@@ -252,11 +325,22 @@ orc_server_key *orc_server_key_new(const u64 *bsk, const u64 *ksk) {
         g_ntt_fwd(l0);
         g_ntt_fwd(l1);
     }
+    fft_init();
+    k->bsk_fft = (double *)malloc(BSK_POLYS * 2 * FFT_N * sizeof(double));
+    {
+        double *tmp = (double *)malloc(POLY_N * sizeof(double));
+        for (size_t p = 0; p < BSK_POLYS; p++) {
+            const u64 *src = k->bsk + p * POLY_N;
+            for (int n = 0; n < POLY_N; n++) tmp[n] = (double)(i64)src[n];   /* signed torus, 53-bit rounding */
+            fft_forward_poly(tmp, k->bsk_fft + p * 2 * FFT_N, k->bsk_fft + p * 2 * FFT_N + FFT_N);
+        }
+        free(tmp);
+    }
     return k;
 }
 void orc_server_key_free(orc_server_key *k) {
     if (!k) return;
-    free(k->bsk); free(k->ksk); free(k->bsk_ntt); free(k);
+    free(k->bsk); free(k->ksk); free(k->bsk_ntt); free(k->bsk_fft); free(k);
 }
 
 /* ---- client side (src/client_key.rs:85-106 via RadixClientKey) ---------- */
@@ -373,7 +457,8 @@ static void negacyclic_mac_schoolbook(const i64 *d, const u64 *b, u64 *res) {
     }
 }
 
-/* mode 0: Goldilocks NTT (2 x 29-bit key limbs, exact); mode 1: schoolbook */
+/* mode 0: Goldilocks NTT (2 x 29-bit key limbs, exact); mode 1: schoolbook (exact);
+ * mode 2: f64 FFT (approximate, CPU-baseline only) */
 static void blind_rotate(const orc_server_key *k, const u32 *ms, const u64 *lut,
                          u64 *acc /* [2][N] */, int mode) {
     u64 *rot = (u64 *)malloc(POLY_N * sizeof(u64));
@@ -390,7 +475,23 @@ static void blind_rotate(const orc_server_key *k, const u32 *ms, const u64 *lut,
             poly_rotate(acc + c * POLY_N, a, rot);
             for (int n = 0; n < POLY_N; n++) dig[c * POLY_N + n] = pbs_digit(rot[n] - acc[c * POLY_N + n]);
         }
-        if (mode == 1) {
+        if (mode == 2) {
+            double dd[POLY_N], dre[2][FFT_N], dim[2][FFT_N], ore[FFT_N], oim[FFT_N], xo[POLY_N];
+            for (int c = 0; c < 2; c++) {
+                for (int n = 0; n < POLY_N; n++) dd[n] = (double)dig[c * POLY_N + n];
+                fft_forward_poly(dd, dre[c], dim[c]);
+            }
+            for (int col = 0; col < 2; col++) {
+                const double *b0 = k->bsk_fft + ((((size_t)i * 2 + 0) * 2 + col)) * 2 * FFT_N;
+                const double *b1 = k->bsk_fft + ((((size_t)i * 2 + 1) * 2 + col)) * 2 * FFT_N;
+                for (int q = 0; q < FFT_N; q++) {
+                    ore[q] = dre[0][q] * b0[q] - dim[0][q] * b0[FFT_N + q] + dre[1][q] * b1[q] - dim[1][q] * b1[FFT_N + q];
+                    oim[q] = dre[0][q] * b0[FFT_N + q] + dim[0][q] * b0[q] + dre[1][q] * b1[FFT_N + q] + dim[1][q] * b1[q];
+                }
+                fft_inverse_poly(ore, oim, xo);
+                for (int n = 0; n < POLY_N; n++) acc[col * POLY_N + n] += f64_to_torus(xo[n]);
+            }
+        } else if (mode == 1) {
             memset(res, 0, 2 * POLY_N * sizeof(u64));
             for (int row = 0; row < 2; row++)
                 for (int col = 0; col < 2; col++)

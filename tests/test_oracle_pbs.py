@@ -41,6 +41,20 @@ def test_pbs_decrypts_to_lut_value_for_all_inputs(oracle_keys, oracle_sk, name):
         assert oracle_keys.decrypt_block(outs[m]) == radix.LUTS[name](m)
 
 
+def test_fft_baseline_variant_decrypts_like_the_exact_path(oracle_keys, oracle_sk):
+    """mode 2 (f64 FFT, the reference's algorithm class) is only a CPU baseline: not bit-exact,
+    but it must decrypt to the same plaintexts with comparable noise."""
+    lut = radix.lut_poly("cmp_le")
+    cts = np.stack([oracle_keys.encrypt_block(m) for m in range(16)])
+    outs = oracle_sk.pbs_batch(cts, np.zeros(16, np.uint32), lut[None], mode=2)
+    exact = oracle_sk.pbs_batch(cts, np.zeros(16, np.uint32), lut[None], mode=0)
+    assert not np.array_equal(outs, exact)
+    for m in range(16):
+        assert oracle_keys.decrypt_block(outs[m]) == radix.LUTS["cmp_le"](m)
+        e = (oracle_keys.phase(outs[m]) - (radix.LUTS["cmp_le"](m) << core.DELTA_LOG)) & (2**64 - 1)
+        assert min(e, 2**64 - e) < 2**53
+
+
 def test_negacyclic_padding_bit_rule(oracle_keys, oracle_sk):
     # an input with the padding bit set (v+16) yields -f(v): what lt/le/gt/ge rely on
     lut = radix.lut_poly("sign")

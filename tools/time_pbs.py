@@ -3,15 +3,15 @@ import sys, time
 import numpy as np
 sys.path.insert(0, ".")
 import fhestring_amd
-from oracle import core, radix   # keys/LUTs only (this is a dev tool, not the product path)
+from fhestring_amd.api import MyClientKey
 
-K = core.Keys(0xF5E57121)
+ck = MyClientKey(0xF5E57121)
 ctx = fhestring_amd.Context(0)
-t = time.time(); ctx.load_server_key(K.bsk, K.ksk); print("key load %.2fs" % (time.time() - t))
-luts = np.stack([radix.lut_poly("msg"), radix.lut_poly("eq_biv")])
+t = time.time(); ctx.load_server_key(ck.bsk(), ck.ksk()); print("key load %.2fs" % (time.time() - t))
 rng = np.random.default_rng(0)
+luts = rng.integers(0, 2**64, (2, 2048), dtype=np.uint64)
 for B in [int(a) for a in sys.argv[1:]] or [64, 512, 1024, 2048]:
-    cts = rng.integers(0, 2**64, (B, core.BIG_CT), dtype=np.uint64)
+    cts = rng.integers(0, 2**64, (B, 2049), dtype=np.uint64)
     idx = (np.arange(B) % 2).astype(np.uint32)
     ctx.pbs_batch(cts, idx, luts)
     ctx.kernel_timing(reset=True)
