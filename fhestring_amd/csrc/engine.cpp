@@ -99,6 +99,7 @@ Bid Engine::triv(int v) {
 }
 
 Bid Engine::from_host(const uint64_t *ct) {
+    (void)hipSetDevice(ctx.device);   // one process may see several GPUs (torch sets its own current device)
     uint64_t *d = alloc_block();
     if (!d) return 0;
     if (hipMemcpyAsync(d, ct, BIG_CT * 8, hipMemcpyHostToDevice, ctx.stream) != hipSuccess) {
@@ -112,6 +113,7 @@ Bid Engine::from_host(const uint64_t *ct) {
 }
 
 Bid Engine::from_device(const uint64_t *d_ct) {
+    (void)hipSetDevice(ctx.device);
     uint64_t *d = alloc_block();
     if (!d) return 0;
     if (hipMemcpyAsync(d, d_ct, BIG_CT * 8, hipMemcpyDeviceToDevice, ctx.stream) != hipSuccess) {
@@ -346,6 +348,7 @@ int Engine::materialize_lin(Bid b) {
 }
 
 int Engine::read_block(Bid b, uint64_t *host_out) {
+    (void)hipSetDevice(ctx.device);
     int rc = flush();
     if (rc) return rc;
     if (nodes_[b].kind == BlockNode::TRIV) {
@@ -362,6 +365,7 @@ int Engine::read_block(Bid b, uint64_t *host_out) {
 }
 
 int Engine::copy_block_to_device(Bid b, uint64_t *d_out) {
+    (void)hipSetDevice(ctx.device);
     int rc = flush();
     if (rc) return rc;
     hipError_t e;

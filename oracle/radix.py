@@ -97,9 +97,10 @@ def from_ct(ct):
 class Engine:
     """Counts PBS and evaluates pending nodes level by level in thread batches."""
 
-    def __init__(self, server_key, nthreads=None):
+    def __init__(self, server_key, nthreads=None, mode=0):
         self.sk = server_key
         self.nthreads = nthreads
+        self.mode = mode          # 0 exact NTT (parity oracle), 2 f64 FFT (the reference's algorithm class)
         self.pbs_count = 0
         self.levels = 0
 
@@ -170,7 +171,7 @@ class Engine:
             names = sorted({b.lut for b in batch})
             luts = np.stack([lut_poly(n) for n in names])
             idx = np.array([names.index(b.lut) for b in batch], np.uint32)
-            outs = self.sk.pbs_batch(np.stack(ins), idx, luts, self.nthreads)
+            outs = self.sk.pbs_batch(np.stack(ins), idx, luts, self.nthreads, self.mode)
             for b, o in zip(batch, outs):
                 b.kind, b.ct, b.src, b.level = "ct", o, None, 0
             self.levels += 1

@@ -74,8 +74,8 @@ def test_pbs_output_noise_is_small(oracle_keys, oracle_sk):
     assert max(abs(e) for e in errs) < 2**53     # budget before the next KS is 2^58
 
 
-def _cipher_env(keys, sk):
-    eng = radix.Engine(sk)
+def _cipher_env(keys, sk, mode=0):
+    eng = radix.Engine(sk, mode=mode)
     ops = ostr.Ops(radix.CipherChar, eng)
     enc_c = lambda v: radix.CipherChar.from_cts(keys.encrypt_char(v), eng)
     enc_s = lambda t, pad: [enc_c(b) for b in ostr.pad_plain(t, pad)]
@@ -119,7 +119,8 @@ def test_cipher_model_golden_less_than(oracle_keys, oracle_sk):
 def test_config1_eq_hello_hello_on_the_cpu_oracle(oracle_keys, oracle_sk):
     """BASELINE.json configs[0]: eq("hello","hello") on the CPU path, as the CLI does it
     (src/utils.rs:691-703: both strings encrypted with STRING_PADDING = 1)."""
-    eng, (ops, enc_s, enc_p, enc_c, dec_s, dec_c) = _cipher_env(oracle_keys, oracle_sk)
+    # f64-FFT external product, like the reference's CPU engine (tfhe + concrete-fft)
+    eng, (ops, enc_s, enc_p, enc_c, dec_s, dec_c) = _cipher_env(oracle_keys, oracle_sk, mode=2)
     a, b = enc_s("hello", 1), enc_s("hello", 1)
     assert dec_c(ops.eq(a, b)) == 1
     assert eng.pbs_count > 100 and eng.levels >= 10
