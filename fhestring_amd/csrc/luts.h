@@ -21,6 +21,7 @@ enum LutId : uint16_t {
     LUT_CASEFLAG,      // v = (h_a + lo_nz) + 4*(h_b + lo_le10) -> letter-of-that-case flag
     LUT_BIT0_UNLESS,   // v = digit + 4*mask -> mask ? 0 : digit & 1
     LUT_BIT1_UNLESS,   // v = digit + 4*mask -> mask ? 0 : (digit >> 1) & 1
+    LUT_LO_WS0,        // low nibble of NUL or of an ASCII whitespace 0x09..0x0D: v in {0, 9..13}
     LUT_COUNT
 };
 
@@ -54,6 +55,7 @@ inline int lut_function(int id, int v) {
         case LUT_CASEFLAG: return ((v & 3) == 2) || ((v >> 2) == 2);
         case LUT_BIT0_UNLESS: return (v >> 2) ? 0 : (v & 1);
         case LUT_BIT1_UNLESS: return (v >> 2) ? 0 : ((v >> 1) & 1);
+        case LUT_LO_WS0: return v == 0 || (v >= 9 && v <= 13);
         default: break;
     }
     if (id >= LUT_EQ_C0 && id <= LUT_EQ_C3) return v == id - LUT_EQ_C0;

@@ -7,6 +7,7 @@
 namespace fhs {
 
 static size_t adjust_end_of_pattern(size_t e) { return e == 0 ? 1 : e; }   // utils.rs:106-112
+static Ref sum_refs(Engine *e, const Ref *r, size_t n);
 
 FStr Strings::clear(const char *s, size_t n) const {
     FStr r;
@@ -64,6 +65,7 @@ FChar Strings::contains(const FStr &s, const FStr &needle) { // mod.rs:151-182
 FChar Strings::ends_with(const FStr &s, const FStr &needle) {   // mod.rs:241-288
     if (s.empty() && needle.empty()) return t(1);
     if (needle.size() > s.size()) return t(0);
+    if (fused()) return f_ends_with(s, needle, nullptr);
     FChar result = t(0);
     const FChar one = t(1), zero = t(0);
     for (size_t i = 0; i + needle.size() <= s.size(); i++) {
@@ -206,6 +208,7 @@ FChar Strings::rfind(const FStr &s_in, const FStr &pat) {    // mod.rs:727-790
         err = {FHS_ERR_LIMIT, "Maximum supported size for find reached"};
         return zero;
     }
+    if (fused()) return f_rfind(s, pat);
     if (pat.empty()) {
         FChar last = zero;
         for (size_t i = 0; i < s.size(); i++) last = ch_ite(ch_ne(s[i], zero), t((uint8_t)(i + 1)), last);
@@ -287,6 +290,21 @@ FStr Strings::strip_suffix(const FStr &s_in, const FStr &needle, FChar *found) {
         return s;
     }
     const size_t end = s.size() - needle.size();
+    if (fused()) {
+        // pos == i exactly for the window picked by ends_with (last window without padding, if it matches)
+        std::vector<Ref> pick;
+        FChar r = f_ends_with(s, needle, &pick);
+        *found = r;
+        for (size_t k = 0; k < s.size(); k++) {
+            std::vector<Ref> cover;   // windows that contain position k; at most one pick is set overall
+            for (size_t i = (k + 1 >= needle.size() ? k + 1 - needle.size() : 0); i <= std::min(k, end); i++)
+                cover.push_back(pick[i]);
+            if (cover.empty()) continue;
+            Ref zk = cover.size() <= 15 ? sum_refs(e_, cover.data(), cover.size()) : or_tree(cover);
+            s[k] = ite_flag(zk, zero, s[k]);
+        }
+        return s;
+    }
     FChar pos = t(255);
     for (size_t i = 0; i <= end; i++) {
         FChar fnd = one, nonzero = one;
@@ -351,6 +369,7 @@ FStr Strings::concatenate(const FStr &a, const FStr &b) {    // mod.rs:1864-1875
 }
 
 FStr Strings::trim_end(const FStr &s) {                      // trim.rs:36-57
+    if (fused()) return f_trim(s, true);
     const FChar zero = t(0);
     FChar stop = zero;
     FStr r(s.size(), zero);
@@ -362,6 +381,7 @@ FStr Strings::trim_end(const FStr &s) {                      // trim.rs:36-57
     return r;
 }
 FStr Strings::trim_start(const FStr &s) {                    // trim.rs:86-115
+    if (fused()) return f_compact(f_trim(s, false));
     const FChar zero = t(0);
     FChar stop = zero;
     FStr r(s.size(), zero);
@@ -500,34 +520,7 @@ FChar Strings::f_find(const FStr &s, const FStr &pat) {
     Ref found = or_tree(f);
     Ref one = trivial_block(e_, 1);
     Ref nf = lin(e_, {{1, &one}, {-1, &found}});
-    FChar r;
-    for (int blk = 0; blk < 4; blk++) {
-        // level 0: groups of <= 15 windows, each group sum is in [0,3]
-        std::vector<Ref> cur;
-        for (size_t g = 0; g < W; g += 15) {
-            Term tt[16];
-            size_t m = 0;
-            for (size_t i = g; i < std::min(W, g + 15); i++) {
-                const int dig = (int)((i >> (2 * blk)) & 3);
-                if (dig) tt[m++] = {dig, first[i].id()};
-            }
-            cur.push_back(Ref(e_, e_->lin(tt, m, 0)));
-        }
-        while (cur.size() > 15) {            // refresh noise, regroup
-            std::vector<Ref> nxt;
-            for (size_t g = 0; g < cur.size(); g += 15) {
-                std::vector<Ref> fresh;
-                for (size_t i = g; i < std::min(cur.size(), g + 15); i++) fresh.push_back(pbs(cur[i], LUT_MSG));
-                nxt.push_back(sum_refs(e_, fresh.data(), fresh.size()));
-            }
-            cur.swap(nxt);
-        }
-        std::vector<Ref> fresh;
-        for (Ref &c : cur) fresh.push_back(cur.size() > 1 ? pbs(c, LUT_MSG) : c);
-        Ref digit = fresh.size() == 1 ? fresh[0] : sum_refs(e_, fresh.data(), fresh.size());
-        r.b[blk] = lin(e_, {{1, &digit}, {3, &nf}});   // 255 = 3,3,3,3 when absent
-    }
-    return r;
+    return position_of(first, 0, &nf, 255);                  // 255 = 3,3,3,3 when absent (:1023)
 }
 
 // comparison (mod.rs:1470-1541) re-associated.  The reference's 4-op state machine per character
@@ -567,6 +560,125 @@ FChar Strings::f_comparison(const FStr &a_in, const FStr &b_in, int cmp) {
     // result = any_diff ? ret : by_len; ret is 0 whenever nothing differs
     Ref sel = pbs(lin(e_, {{2, &by_len}, {1, &any_diff}}), LUT_IS2);   // by_len & !any_diff
     return ch_flag(e_, lin(e_, {{1, &sel}, {1, &ret}}));
+}
+
+std::vector<Ref> Strings::suffix_or(const std::vector<Ref> &f) {
+    std::vector<Ref> rev(f.rbegin(), f.rend());
+    std::vector<Ref> p = prefix_or(rev);
+    return std::vector<Ref>(p.rbegin(), p.rend());
+}
+
+Ref Strings::char_nonzero(const FChar &c) {
+    Ref one = trivial_block(e_, 1);
+    Ref z = and_tree(block_eq_flags(c, t(0)));
+    return lin(e_, {{1, &one}, {-1, &z}});
+}
+
+// NUL = 0x00, whitespace = 0x20, 0x09..0x0D (fheasciichar.rs:106-130): high nibble 0 with low nibble in
+// {0, 9..13}, or high nibble 2 with low nibble 0 -- same 5-PBS shape as the case detector
+Ref Strings::char_significant(const FChar &c) {
+    Ref lo = lin(e_, {{1, &c.b[0]}, {4, &c.b[1]}});
+    Ref hi = lin(e_, {{1, &c.b[2]}, {4, &c.b[3]}});
+    Ref h0 = pbs(hi, LUT_IS0), h2 = pbs(hi, LUT_IS2), l0 = pbs(lo, LUT_IS0), lw = pbs(lo, LUT_LO_WS0);
+    Ref bad = pbs(lin(e_, {{1, &h0}, {1, &lw}, {4, &h2}, {4, &l0}}), LUT_CASEFLAG);
+    Ref one = trivial_block(e_, 1);
+    return lin(e_, {{1, &one}, {-1, &bad}});
+}
+
+// u8 position encoded by one-hot flags: sum_i pick_i * (i + offset) digit-wise (at most one pick is set);
+// when `absent_flag` is set the result is `absent_value` (255 for find/rfind, mod.rs:1023)
+FChar Strings::position_of(const std::vector<Ref> &pick, size_t off, const Ref *absent_flag, int absent_value) {
+    const size_t W = pick.size();
+    FChar r;
+    for (int blk = 0; blk < 4; blk++) {
+        std::vector<Ref> cur;
+        for (size_t g = 0; g < W; g += 15) {
+            Term tt[16];
+            size_t m = 0;
+            for (size_t i = g; i < std::min(W, g + 15); i++) {
+                const int dig = (int)(((i + off) >> (2 * blk)) & 3);
+                if (dig) tt[m++] = {dig, pick[i].id()};
+            }
+            cur.push_back(Ref(e_, e_->lin(tt, m, 0)));
+        }
+        while (cur.size() > 15) {
+            std::vector<Ref> nxt;
+            for (size_t g = 0; g < cur.size(); g += 15) {
+                std::vector<Ref> fresh;
+                for (size_t i = g; i < std::min(cur.size(), g + 15); i++) fresh.push_back(pbs(cur[i], LUT_MSG));
+                nxt.push_back(sum_refs(e_, fresh.data(), fresh.size()));
+            }
+            cur.swap(nxt);
+        }
+        std::vector<Ref> fresh;
+        for (Ref &c : cur) fresh.push_back(cur.size() > 1 ? pbs(c, LUT_MSG) : c);
+        Ref digit = fresh.empty() ? trivial_block(e_, 0)
+                                  : (fresh.size() == 1 ? fresh[0] : sum_refs(e_, fresh.data(), fresh.size()));
+        if (absent_flag) r.b[blk] = lin(e_, {{1, &digit}, {(absent_value >> (2 * blk)) & 3, absent_flag}});
+        else r.b[blk] = digit;
+    }
+    return r;
+}
+
+// rfind (mod.rs:727-790) re-associated: the LAST matching window wins (the loop ascends and overwrites);
+// `s` already carries the NUL pushed at :737
+FChar Strings::f_rfind(const FStr &s, const FStr &pat) {
+    if (pat.empty()) {                                      // :747-760: index after the last non-NUL char
+        std::vector<Ref> nz(s.size());
+        for (size_t i = 0; i < s.size(); i++) nz[i] = char_nonzero(s[i]);
+        std::vector<Ref> after = suffix_or(nz);
+        std::vector<Ref> last(s.size());
+        for (size_t i = 0; i < s.size(); i++) last[i] = pbs(lin(e_, {{2, &nz[i]}, {1, &after[i]}}), LUT_IS2);
+        return position_of(last, 1, nullptr, 0);
+    }
+    if (pat.size() > s.size()) return t(255);
+    const size_t E = std::max<size_t>(1, s.size() - pat.size());   // adjust_end_of_pattern, exclusive bound (:768-771)
+    std::vector<Ref> f(E);
+    for (size_t i = 0; i < E; i++) f[i] = window_match(s, i, pat);
+    std::vector<Ref> after = suffix_or(f);
+    std::vector<Ref> last(E);
+    for (size_t i = 0; i < E; i++) last[i] = pbs(lin(e_, {{2, &f[i]}, {1, &after[i]}}), LUT_IS2);
+    Ref found = or_tree(f);
+    Ref one = trivial_block(e_, 1);
+    Ref nf = lin(e_, {{1, &one}, {-1, &found}});
+    return position_of(last, 0, &nf, 255);
+}
+
+// ends_with (mod.rs:241-288) re-associated: the result is the match flag of the LAST window that
+// contains no NUL ("use the last result that has not encountered padding", :281-286), 0 if none.
+FChar Strings::f_ends_with(const FStr &s, const FStr &needle, std::vector<Ref> *pick_out) {
+    const size_t W = s.size() - needle.size() + 1;
+    std::vector<Ref> nzc(s.size());
+    for (size_t k = 0; k < s.size(); k++) nzc[k] = char_nonzero(s[k]);
+    std::vector<Ref> valid(W), match(W);
+    for (size_t i = 0; i < W; i++) {
+        std::vector<Ref> v(nzc.begin() + i, nzc.begin() + i + needle.size());
+        valid[i] = and_tree(v);
+        match[i] = needle.empty() ? trivial_block(e_, 1) : window_match(s, i, needle);
+    }
+    std::vector<Ref> after = suffix_or(valid);
+    std::vector<Ref> pick(W);
+    for (size_t i = 0; i < W; i++)                           // match & valid & !after
+        pick[i] = pbs(lin(e_, {{1, &match[i]}, {1, &valid[i]}, {4, &after[i]}}), LUT_IS2);
+    Ref res = or_tree(pick);
+    if (pick_out) *pick_out = pick;
+    return ch_flag(e_, res);
+}
+
+// trim_end / the marking half of trim_start (trim.rs:36-57, 86-115): a char survives iff some
+// non-NUL, non-whitespace char sits at or after it (from_end) / at or before it
+FStr Strings::f_trim(const FStr &s, bool from_end) {
+    const size_t n = s.size();
+    std::vector<Ref> sig(n);
+    for (size_t i = 0; i < n; i++) sig[i] = char_significant(s[i]);
+    std::vector<Ref> other = from_end ? suffix_or(sig) : prefix_or(sig);
+    const FChar zero = t(0);
+    FStr r(n);
+    for (size_t i = 0; i < n; i++) {
+        Ref stop = pbs(lin(e_, {{1, &sig[i]}, {1, &other[i]}}), LUT_NZ);   // inclusive OR
+        r[i] = ite_flag(stop, s[i], zero);
+    }
+    return r;
 }
 
 // cond ? t : f with cond a clean single-block 0/1 flag (no scalar_ne needed)

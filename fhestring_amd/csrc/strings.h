@@ -70,6 +70,13 @@ class Strings {
     std::vector<Num> num_exclusive_scan(const std::vector<Num> &x, size_t digits);
     FStr f_compact(const FStr &s);
     FChar ite_flag(const Ref &flag, const FChar &t, const FChar &f);
+    std::vector<Ref> suffix_or(const std::vector<Ref> &f);            // exclusive: OR_{k>i}
+    Ref char_nonzero(const FChar &c);                                 // 1 block: c != 0
+    Ref char_significant(const FChar &c);                             // 1 block: c is neither NUL nor whitespace
+    FChar position_of(const std::vector<Ref> &pick, size_t index_offset, const Ref *absent_flag, int absent_value);
+    FChar f_rfind(const FStr &s, const FStr &pat);
+    FChar f_ends_with(const FStr &s, const FStr &needle, std::vector<Ref> *pick_out);
+    FStr f_trim(const FStr &s, bool from_end);
     FChar f_contains(const FStr &s, const FStr &needle);
     FChar f_len(const FStr &s);
     FChar f_eq(const FStr &a, const FStr &b);

@@ -82,7 +82,8 @@ def test_golden_vectors_on_gpu(product, v, mode):
         pytest.skip("as-written O(n^2)/O(n^3) op: set FHS_SLOW=1")
     if mode == 1 and v["op"] not in ("contains", "starts_with", "is_empty", "len", "eq", "eq_ignore_case",
                                      "to_upper", "to_lower", "find", "lt", "le", "gt", "ge", "replace",
-                                     "replacen", "repeat", "trim_start", "trim", "strip_prefix", "concatenate"):
+                                     "replacen", "repeat", "trim_start", "trim", "trim_end", "strip_prefix",
+                                     "strip_suffix", "concatenate", "ends_with", "rfind"):
         pytest.skip("no fused formulation yet: identical to as-written")
     env = _env(ck, sk)
     if "expected_panic" in v:
@@ -127,6 +128,32 @@ def test_compaction_equals_bubble_on_random_strings(product):
             sk.set_mode(0)
             got0 = [ck.decrypt_char(c) for c in sk.bubble_zeroes_right(chars).chars]
             assert got0 == want
+
+
+def test_fused_suffix_family_random(product):
+    """ends_with / rfind / strip_suffix / trim in fused mode vs python str on random inputs."""
+    import random
+    ck, sk = product
+    sk.set_mode(1)
+    rnd = random.Random(21)
+    ws = " \t\n\x0b\x0c\r"
+    for _ in range(4):
+        n, m = rnd.randint(3, 14), rnd.randint(1, 3)
+        s = "".join(rnd.choice("ab ") for _ in range(n))
+        pat = s[n - m:] if rnd.random() < 0.5 else "".join(rnd.choice("ab ") for _ in range(m))
+        es = ck.encrypt(s, rnd.randint(1, 3), None, sk)
+        ep = ck.encrypt_no_padding(pat, sk)
+        assert ck.decrypt_char(sk.ends_with(es, ep)) == int(s.endswith(pat)), (s, pat)
+        assert ck.decrypt_char(sk.rfind(es, ep)) == (s.rfind(pat) if pat in s else 255), (s, pat)
+        out, found = sk.strip_suffix(es, ep)
+        assert ck.decrypt_char(found) == int(s.endswith(pat))
+        assert ck.decrypt(out) == (s[:n - m] if s.endswith(pat) else s)
+        t = "".join(rnd.choice(ws) for _ in range(rnd.randint(0, 3))) + s.strip() + "".join(rnd.choice(ws) for _ in range(rnd.randint(0, 3)))
+        et = ck.encrypt(t, 1, None, sk)
+        assert ck.decrypt(sk.trim_end(et)) == t.rstrip(ws)
+        assert ck.decrypt(sk.trim_start(et)) == t.lstrip(ws)
+        assert ck.decrypt(sk.trim(et)) == t.strip(ws)
+    assert ck.decrypt_char(sk.rfind(ck.encrypt("ab cd", 1, None, sk), [])) == 5     # empty pattern (mod.rs:747-760)
 
 
 def test_fused_comparisons_random(product):
