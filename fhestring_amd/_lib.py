@@ -139,6 +139,12 @@ def _declare(L):
     L.fhs_client_encrypt_str.restype = i
     L.fhs_client_decrypt_str.argtypes = [vp, vp, sz, C.c_char_p, C.POINTER(sz)]
     L.fhs_client_decrypt_str.restype = i
+    L.fhs_client_save.argtypes = [vp, C.c_char_p, i]
+    L.fhs_client_save.restype = i
+    L.fhs_client_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.fhs_client_load.restype = i
+    L.fhs_load_server_key_file.argtypes = [vp, C.c_char_p]
+    L.fhs_load_server_key_file.restype = i
     L.fhs_client_secret_keys.argtypes = [vp, vp, vp]
     L.fhs_client_secret_keys.restype = i
 

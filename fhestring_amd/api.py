@@ -100,13 +100,28 @@ MODE_FUSED = 1
 class MyClientKey:
     """Host-CPU client key (keygen / encrypt / decrypt), like the reference's."""
 
-    def __init__(self, seed=0xF5E57121):
+    def __init__(self, seed=0xF5E57121, _handle=None):
         self._L = lib()
+        if _handle is not None:
+            self._h = _handle
+            return
         h = C.c_void_p()
         rc = self._L.fhs_client_create(int(seed), C.byref(h))
         if rc != 0:
             raise FhsError("fhs_client_create failed (%d)" % rc)
         self._h = h
+
+    def save(self, path, server_key_only=False):
+        """Key file (include/fhestring_hip.h "key files"): raw little-endian u64 arrays + 64-byte header."""
+        if self._L.fhs_client_save(self._h, str(path).encode(), int(server_key_only)) != 0:
+            raise FhsError("cannot write key file %s" % path)
+
+    @classmethod
+    def load(cls, path):
+        h = C.c_void_p()
+        if lib().fhs_client_load(str(path).encode(), C.byref(h)) != 0:
+            raise FhsError("cannot read client key file %s" % path)
+        return cls(_handle=h)
 
     @classmethod
     def from_params(cls, params=None, num_blocks=4, seed=0xF5E57121):   # client_key.rs:30-35
@@ -274,6 +289,12 @@ class MyServerKey:
     def from_client_key(cls, client_key, device_id=0):
         ctx = Context(device_id)
         ctx.load_server_key(client_key.bsk(), client_key.ksk())
+        return cls(ctx)
+
+    @classmethod
+    def from_key_file(cls, path, device_id=0):
+        ctx = Context(device_id)
+        ctx._check(ctx._L.fhs_load_server_key_file(ctx._h, str(path).encode()))
         return cls(ctx)
 
     @classmethod

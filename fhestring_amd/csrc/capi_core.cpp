@@ -35,6 +35,16 @@ int fhs_load_server_key(fhs_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) 
     return ctx->eng.on_key_loaded();
 }
 
+int fhs_read_server_key_file(const char *path, std::vector<uint64_t> &bsk, std::vector<uint64_t> &ksk);
+
+int fhs_load_server_key_file(fhs_ctx *ctx, const char *path) {
+    if (!ctx || !path) return FHS_ERR_ARG;
+    std::vector<uint64_t> bsk, ksk;
+    if (fhs_read_server_key_file(path, bsk, ksk) != FHS_OK)
+        return ctx->eng.ctx.fail(FHS_ERR_STATE, "cannot read key file (missing, truncated or wrong parameters)");
+    return fhs_load_server_key(ctx, bsk.data(), ksk.data());
+}
+
 int fhs_pbs_batch(fhs_ctx *ctx, const uint64_t *in, const uint32_t *lut_idx, const uint64_t *luts,
                   size_t n_luts, uint64_t *out, size_t B) {
     if (!ctx) return FHS_ERR_ARG;

@@ -3,6 +3,7 @@
 // this on the CPU through tfhe::integer::{gen_keys_radix, RadixClientKey}; so does this file.  Own
 // seeded generator (SplitMix64 + Box-Muller): keys cannot be shared with tfhe-rs anyway.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -173,6 +174,78 @@ int fhs_client_decrypt_str(const fhs_client *ck, const uint64_t *chars, size_t n
     *out_len = k;
     return FHS_OK;
 }
+namespace {
+struct KeyFileHeader {
+    char magic[8];
+    uint64_t kind, lwe_n, poly_n, ks_levels, ks_base_log, pbs_base_log, bsk_quant_bits;
+};
+static_assert(sizeof(KeyFileHeader) == 64, "header is 64 bytes");
+KeyFileHeader make_header(uint64_t kind) {
+    KeyFileHeader h{};
+    std::memcpy(h.magic, "FHSKEY01", 8);
+    h.kind = kind; h.lwe_n = LWE_N; h.poly_n = POLY_N; h.ks_levels = KS_LEVEL; h.ks_base_log = KS_BASE_LOG;
+    h.pbs_base_log = PBS_BASE_LOG; h.bsk_quant_bits = BSK_QUANT_BITS;
+    return h;
+}
+bool header_ok(const KeyFileHeader &h) {
+    const KeyFileHeader w = make_header(h.kind);
+    return std::memcmp(&h, &w, sizeof(h)) == 0 && (h.kind == 1 || h.kind == 2);
+}
+bool write_all(FILE *f, const void *p, size_t n) { return std::fwrite(p, 1, n, f) == n; }
+bool read_all(FILE *f, void *p, size_t n) { return std::fread(p, 1, n, f) == n; }
+}  // namespace
+
+int fhs_client_save(const fhs_client *ck, const char *path, int server_key_only) {
+    if (!ck || !path) return FHS_ERR_ARG;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return FHS_ERR_STATE;
+    const KeyFileHeader h = make_header(server_key_only ? 2 : 1);
+    bool ok = write_all(f, &h, sizeof(h));
+    if (!server_key_only) {
+        ok = ok && write_all(f, &ck->seed, 8) && write_all(f, ck->lwe_sk.data(), ck->lwe_sk.size() * 8) &&
+             write_all(f, ck->glwe_sk.data(), ck->glwe_sk.size() * 8);
+    }
+    ok = ok && write_all(f, ck->bsk.data(), ck->bsk.size() * 8) && write_all(f, ck->ksk.data(), ck->ksk.size() * 8);
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? FHS_OK : FHS_ERR_STATE;
+}
+
+int fhs_client_load(const char *path, fhs_client **out) {
+    if (!path || !out) return FHS_ERR_ARG;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return FHS_ERR_STATE;
+    KeyFileHeader h;
+    fhs_client *ck = new (std::nothrow) fhs_client();
+    bool ok = ck && read_all(f, &h, sizeof(h)) && header_ok(h) && h.kind == 1;
+    if (ok) {
+        ck->lwe_sk.resize(LWE_N); ck->glwe_sk.resize(POLY_N);
+        ck->bsk.resize((size_t)LWE_N * 4 * POLY_N); ck->ksk.resize((size_t)BIG_N * KS_LEVEL * SMALL_CT);
+        ok = read_all(f, &ck->seed, 8) && read_all(f, ck->lwe_sk.data(), LWE_N * 8) &&
+             read_all(f, ck->glwe_sk.data(), POLY_N * 8) && read_all(f, ck->bsk.data(), ck->bsk.size() * 8) &&
+             read_all(f, ck->ksk.data(), ck->ksk.size() * 8);
+        ck->enc_rng = Rng{mix(ck->seed, 7777)};
+    }
+    std::fclose(f);
+    if (!ok) { delete ck; return FHS_ERR_STATE; }
+    *out = ck;
+    return FHS_OK;
+}
+
+// reads only the server-key part of a key file (used by fhs_load_server_key_file in capi_core.cpp)
+int fhs_read_server_key_file(const char *path, std::vector<uint64_t> &bsk, std::vector<uint64_t> &ksk) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return FHS_ERR_STATE;
+    KeyFileHeader h;
+    bool ok = read_all(f, &h, sizeof(h)) && header_ok(h);
+    if (ok && h.kind == 1) ok = std::fseek(f, 8 + (LWE_N + POLY_N) * 8, SEEK_CUR) == 0;
+    if (ok) {
+        bsk.resize((size_t)LWE_N * 4 * POLY_N); ksk.resize((size_t)BIG_N * KS_LEVEL * SMALL_CT);
+        ok = read_all(f, bsk.data(), bsk.size() * 8) && read_all(f, ksk.data(), ksk.size() * 8);
+    }
+    std::fclose(f);
+    return ok ? FHS_OK : FHS_ERR_STATE;
+}
+
 int fhs_client_secret_keys(const fhs_client *ck, uint64_t *lwe_sk, uint64_t *glwe_sk) {
     if (!ck || !lwe_sk || !glwe_sk) return FHS_ERR_ARG;
     std::memcpy(lwe_sk, ck->lwe_sk.data(), LWE_N * 8);

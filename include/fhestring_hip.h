@@ -168,6 +168,14 @@ int fhs_client_encrypt_str(fhs_client *ck, const char *s, size_t len, size_t pad
 int fhs_client_decrypt_str(const fhs_client *ck, const uint64_t *chars, size_t n, char *out, size_t *out_len);
 int fhs_client_secret_keys(const fhs_client *ck, uint64_t *lwe_sk /*[742]*/, uint64_t *glwe_sk /*[2048]*/);
 
+/* ---- key files (the reference derives serde traits at client_key.rs:9 and
+ * server_key/mod.rs:13 but never calls them).  Little-endian: 64-byte header {magic "FHSKEY01", kind,
+ * lwe_n, poly_n, ks_levels, ks_base_log, pbs_base_log, bsk_quant_bits}, then raw u64 arrays.
+ * kind 1 = client key (secret keys + server key), kind 2 = server key only (bsk, ksk). */
+int fhs_client_save(const fhs_client *ck, const char *path, int server_key_only);
+int fhs_client_load(const char *path, fhs_client **out);             /* kind 1 files only */
+int fhs_load_server_key_file(fhs_ctx *ctx, const char *path);        /* kind 1 or 2 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,3 +190,20 @@ def test_edge_cases_match_reference_semantics(product):
     assert ck.decrypt_char(sk.ne(e("abc", 1), e("ab", 2))) == 1
     with pytest.raises(OverflowError):
         sk.find(e("a" * 257, 1), p("abc"))                            # mod.rs:1025-1027
+
+
+def test_server_key_from_key_file(tmp_path):
+    """Key file: server-key-only file -> device, client keeps the secret key."""
+    from fhestring_amd.api import MyClientKey, MyServerKey
+    ck = MyClientKey(4242)
+    path = tmp_path / "server.key"
+    ck.save(path, server_key_only=True)
+    sk = MyServerKey.from_key_file(path)
+    try:
+        sk.set_mode(1)
+        s = ck.encrypt("key file ok", 1, None, sk)
+        assert ck.decrypt_char(sk.contains_clear(s, "file")) == 1
+        assert ck.decrypt(sk.to_upper(s)) == "KEY FILE OK"
+    finally:
+        sk.close()
+        ck.close()
