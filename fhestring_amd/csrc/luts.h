@@ -22,6 +22,9 @@ enum LutId : uint16_t {
     LUT_BIT0_UNLESS,   // v = digit + 4*mask -> mask ? 0 : digit & 1
     LUT_BIT1_UNLESS,   // v = digit + 4*mask -> mask ? 0 : (digit >> 1) & 1
     LUT_LO_WS0,        // low nibble of NUL or of an ASCII whitespace 0x09..0x0D: v in {0, 9..13}
+    // greedy non-overlapping match selection, v = blocked_countdown + 8 * match_flag (countdown < 8)
+    LUT_GREEDY_SEL,    // 1 iff countdown == 0 and match
+    LUT_GREEDY_DEC,    // countdown > 0 ? countdown - 1 : 0
     LUT_COUNT
 };
 
@@ -56,6 +59,8 @@ inline int lut_function(int id, int v) {
         case LUT_BIT0_UNLESS: return (v >> 2) ? 0 : (v & 1);
         case LUT_BIT1_UNLESS: return (v >> 2) ? 0 : ((v >> 1) & 1);
         case LUT_LO_WS0: return v == 0 || (v >= 9 && v <= 13);
+        case LUT_GREEDY_SEL: return v == 8;
+        case LUT_GREEDY_DEC: return (v & 7) ? (v & 7) - 1 : 0;
         default: break;
     }
     if (id >= LUT_EQ_C0 && id <= LUT_EQ_C3) return v == id - LUT_EQ_C0;

@@ -166,6 +166,7 @@ FStr Strings::longer_from(const FStr &s, const FStr &from, FStr to, const FChar 
 }
 
 FStr Strings::shorter_from(const FStr &s, const FStr &from, const FStr &to, const FChar &n, bool use_counter) {   // mod.rs:885-980
+    if (fused() && !use_counter && !from.empty() && from.size() <= 8) return f_replace_expand(s, from, to);
     const FChar zero = t(0), one = t(1);
     FStr data = s;
     data.push_back(zero);
@@ -663,6 +664,53 @@ FChar Strings::f_ends_with(const FStr &s, const FStr &needle, std::vector<Ref> *
     Ref res = or_tree(pick);
     if (pick_out) *pick_out = pick;
     return ch_flag(e_, res);
+}
+
+// replace with |from| < |to| (handle_shorter_from, mod.rs:885-980) re-associated.  The reference scans
+// left to right, splices `to` in place and masks the inserted text, i.e. it replaces the greedy
+// leftmost NON-overlapping matches.  Here: match flags on the original string; a countdown state
+// machine (1 block, 2 PBS per position) picks the greedy matches; every position then emits a slot of
+// |to| characters (`to` at a selected start, nothing inside a match, itself otherwise) and the slots
+// are compacted.  Same plaintext as the reference; the buffer is (n+1)*|to| chars instead of
+// |to|*(n+1) + (n+1).
+FStr Strings::f_replace_expand(const FStr &s_in, const FStr &from, const FStr &to) {
+    const FChar zero = t(0);
+    FStr s = s_in;
+    s.push_back(zero);                                       // :898
+    const size_t n = s.size(), m = from.size(), L = to.size();
+    std::vector<Ref> sel(n), covered(n);
+    Ref state = trivial_block(e_, 0);                        // positions still blocked by the last match
+    for (size_t i = 0; i < n; i++) {
+        Ref f = i + m <= n ? window_match(s, i, from) : trivial_block(e_, 0);
+        Ref v = lin(e_, {{1, &state}, {8, &f}});
+        sel[i] = pbs(v, LUT_GREEDY_SEL);
+        Ref dec = pbs(v, LUT_GREEDY_DEC);
+        state = m > 1 ? lin(e_, {{1, &dec}, {(int64_t)(m - 1), &sel[i]}}) : dec;   // sel => countdown was 0
+    }
+    for (size_t i = 0; i < n; i++) {
+        Term tt[8];
+        size_t k = 0;
+        for (size_t d = 1; d < m && d <= i; d++) tt[k++] = {1, sel[i - d].id()};
+        covered[i] = Ref(e_, e_->lin(tt, k, 0));             // inside a selected match (not its start)
+    }
+    Ref one = trivial_block(e_, 1);
+    FStr slots;
+    slots.reserve(n * L);
+    for (size_t i = 0; i < n; i++) {
+        Ref keep = lin(e_, {{1, &one}, {-1, &sel[i]}, {-1, &covered[i]}});
+        for (size_t j = 0; j < L; j++) {
+            FChar c;
+            for (int b = 0; b < 4; b++) {
+                Ref a = pbs(lin(e_, {{4, &sel[i]}, {1, &to[j].b[b]}}), LUT_SEL_T);
+                if (j == 0) {
+                    Ref o = pbs(lin(e_, {{4, &keep}, {1, &s[i].b[b]}}), LUT_SEL_T);
+                    c.b[b] = lin(e_, {{1, &a}, {1, &o}});
+                } else c.b[b] = a;
+            }
+            slots.push_back(c);
+        }
+    }
+    return f_compact(slots);
 }
 
 // trim_end / the marking half of trim_start (trim.rs:36-57, 86-115): a char survives iff some

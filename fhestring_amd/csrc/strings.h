@@ -77,6 +77,7 @@ class Strings {
     FChar f_rfind(const FStr &s, const FStr &pat);
     FChar f_ends_with(const FStr &s, const FStr &needle, std::vector<Ref> *pick_out);
     FStr f_trim(const FStr &s, bool from_end);
+    FStr f_replace_expand(const FStr &s, const FStr &from, const FStr &to);
     FChar f_contains(const FStr &s, const FStr &needle);
     FChar f_len(const FStr &s);
     FChar f_eq(const FStr &a, const FStr &b);

@@ -77,7 +77,7 @@ def _env(ck, sk):
 def test_golden_vectors_on_gpu(product, v, mode):
     ck, sk = product
     sk.set_mode(mode)
-    slow = SLOW if mode == 0 else {"replace2"}     # shorter_from (mod.rs:885-980) has no fused form yet
+    slow = SLOW if mode == 0 else set()
     if v["name"] in slow and not os.environ.get("FHS_SLOW"):
         pytest.skip("as-written O(n^2)/O(n^3) op: set FHS_SLOW=1")
     if mode == 1 and v["op"] not in ("contains", "starts_with", "is_empty", "len", "eq", "eq_ignore_case",
@@ -154,6 +154,21 @@ def test_fused_suffix_family_random(product):
         assert ck.decrypt(sk.trim_start(et)) == t.lstrip(ws)
         assert ck.decrypt(sk.trim(et)) == t.strip(ws)
     assert ck.decrypt_char(sk.rfind(ck.encrypt("ab cd", 1, None, sk), [])) == 5     # empty pattern (mod.rs:747-760)
+
+
+def test_fused_replace_expand_random(product):
+    """|from| < |to| (handle_shorter_from): greedy leftmost non-overlapping matches, like str.replace."""
+    import random
+    ck, sk = product
+    sk.set_mode(1)
+    rnd = random.Random(8)
+    cases = [("aaa", "aa", "bbb"), ("abcabc", "b", "xyz"), ("hello", "l", "LL"), ("aaaa", "a", "ab"), ("xyz", "q", "rs")]
+    for _ in range(2):
+        s = "".join(rnd.choice("ab") for _ in range(rnd.randint(3, 9)))
+        cases.append((s, rnd.choice(["a", "ab", "ba"]), rnd.choice(["xyz", "abab"])))
+    for s, frm, to in cases:
+        out = sk.replace(ck.encrypt(s, 1, None, sk), ck.encrypt_no_padding(frm, sk), ck.encrypt_no_padding(to, sk))
+        assert ck.decrypt(out) == s.replace(frm, to), (s, frm, to)
 
 
 def test_fused_comparisons_random(product):
