@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--mode", choices=["fused", "as_written"], default="fused")
     ap.add_argument("--op", choices=["contains", "find"], default="contains")
     ap.add_argument("--cpu-pbs", type=int, default=-1, help="PBS in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--dist-mode", choices=["windows", "levels"], default="windows",
+                    help="N>1: 'windows' shards the match windows (1 all-gather of 1 char per rank); 'levels' "
+                         "replicates the string and splits every PBS level (1 all-gather per level)")
     ap.add_argument("--skip-single-op", action="store_true",
                     help="do not run the extra single-op latency section (profiling: every launch is then timed)")
     return ap.parse_args()
@@ -136,7 +139,11 @@ def main():
     ck = MyClientKey(SEED)                      # same seed on every rank -> identical keys
     sk = MyServerKey.from_client_key(ck, local_rank)
     sk.set_mode(1 if args.mode == "fused" else 0)
-    job = ShardedContains(sk, rank, world, dist, torch)
+    if args.dist_mode == "levels" and world > 1:
+        sk.enable_level_parallel(rank, world, dist, torch)
+        job = ShardedContains(sk, 0, 1, None, torch)                     # every rank holds the whole string
+    else:
+        job = ShardedContains(sk, rank, world, dist, torch)
     shards = [job.upload_shard(ck, s, args.chars, m) for s in strings]   # resident before timing
     sk.flush()
 
@@ -223,7 +230,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s_clear, %d-char FheString per GPU (+1 NUL pad), clear pattern m=%d, "
                                    "%d string(s)/step, %s DAG" % (args.op, args.chars, m, args.strings, args.mode),
-                       "parallelism": "windows sharded over %d GPU(s), 1 all-gather" % world},
+                       "parallelism": ("windows sharded over %d GPU(s), 1 all-gather" % world)
+                       if args.dist_mode == "windows" else
+                       ("every PBS level split over %d GPU(s), 1 all-gather per level" % world)},
             "ms_per_op": dt / args.steps / args.strings * 1e3,
             "single_op_latency_ms": single_ms if single_ms is not None else dt / args.steps * 1e3,
             "pbs_per_op": pbs_total / args.steps / args.strings,

@@ -119,6 +119,16 @@ def _declare(L):
         f = getattr(L, name)
         f.argtypes = [vp, hp, sz, hp]
         f.restype = i
+    L.fhs_dist_config.argtypes = [vp, i, i]
+    L.fhs_dist_config.restype = i
+    L.fhs_flush_plan.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.fhs_flush_plan.restype = i
+    L.fhs_flush_level_exec.argtypes = [vp, u64, vp, C.POINTER(u64), C.POINTER(u64)]
+    L.fhs_flush_level_exec.restype = i
+    L.fhs_flush_level_commit.argtypes = [vp, u64, vp]
+    L.fhs_flush_level_commit.restype = i
+    L.fhs_stream_sync.argtypes = [vp]
+    L.fhs_stream_sync.restype = i
     L.fhs_get_stats.argtypes = [vp, vp]
     L.fhs_get_stats.restype = i
     L.fhs_reset_stats.argtypes = [vp]

@@ -247,6 +247,7 @@ class FheAsciiChar:
 
     def download(self):
         out = np.zeros((4, BIG_CT), np.uint64)
+        self.sk.flush()                      # (collective in level-parallel mode)
         self.sk.ctx._check(self.sk.ctx._L.fhs_download(self.sk.ctx._h, self.h, _ptr(out)))
         return out
 
@@ -325,10 +326,20 @@ class MyServerKey:
         return FheAsciiChar(self, self.ctx._L.fhs_import_device(self.ctx._h, C.c_void_p(d_ptr)))
 
     def export_device(self, ch, d_ptr):
+        self.flush()
         self.ctx._check(self.ctx._L.fhs_export_device(self.ctx._h, ch.h, C.c_void_p(d_ptr)))
 
     def flush(self):
+        if getattr(self, "_dist", None) is not None:
+            return self._dist.flush()
         self.ctx._check(self.ctx._L.fhs_flush(self.ctx._h))
+
+    def enable_level_parallel(self, rank, world, dist, torch):
+        """Level-parallel multi-GPU mode (fhestring_amd.parallel.LevelParallel): every rank records the
+        same DAG on the same ciphertexts and runs 1/world of every PBS level."""
+        from .parallel import LevelParallel
+        self.ctx._check(self.ctx._L.fhs_dist_config(self.ctx._h, int(rank), int(world)))
+        self._dist = LevelParallel(self, rank, world, dist, torch) if world > 1 else None
 
     def _flags(self, name, flags):
         flags = self._chars(flags)

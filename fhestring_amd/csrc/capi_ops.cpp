@@ -1,4 +1,6 @@
 // extern "C" boundary, part 2: FheAsciiChar ops, MyServerKey string methods, statistics.
+#include <algorithm>
+
 #include "capi_internal.h"
 
 using namespace fhs;
@@ -302,6 +304,39 @@ int fhs_flags_and(fhs_ctx *c, const fhs_char_t *flags, size_t n, fhs_char_t *out
     Strings S(&c->eng);
     FChar r = S.flags_and(load_str(c->eng, flags, n));
     *out = store(c->eng, r);
+    return FHS_OK;
+}
+
+int fhs_dist_config(fhs_ctx *c, int rank, int world) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return bad(c);
+    c->eng.dist_rank = rank;
+    c->eng.dist_world = world;
+    return FHS_OK;
+}
+int fhs_flush_plan(fhs_ctx *c, uint64_t *n_levels, uint64_t *max_level_width) {
+    if (!c || !n_levels || !max_level_width) return bad(c);
+    int rc = c->eng.plan_flush();
+    if (rc) return rc;
+    *n_levels = c->eng.planned_levels();
+    *max_level_width = c->eng.planned_levels() ? c->eng.planned_max_width() : 0;
+    return FHS_OK;
+}
+int fhs_flush_level_exec(fhs_ctx *c, uint64_t level, uint64_t *d_slice, uint64_t *width, uint64_t *cap) {
+    if (!c || !d_slice || !width || !cap || level >= c->eng.planned_levels()) return bad(c);
+    const size_t w = c->eng.level_width(level), world = (size_t)c->eng.dist_world;
+    const size_t cp = (w + world - 1) / world;
+    const size_t lo = std::min(w, (size_t)c->eng.dist_rank * cp), hi = std::min(w, lo + cp);
+    *width = w;
+    *cap = cp;
+    return c->eng.exec_level(level, lo, hi, d_slice);
+}
+int fhs_flush_level_commit(fhs_ctx *c, uint64_t level, const uint64_t *d_all) {
+    if (!c || !d_all || level >= c->eng.planned_levels()) return bad(c);
+    return c->eng.commit_level(level, d_all);
+}
+int fhs_stream_sync(fhs_ctx *c) {
+    if (!c) return FHS_ERR_ARG;
+    if (hipStreamSynchronize(c->eng.ctx.stream) != hipSuccess) return c->eng.ctx.fail(FHS_ERR_HIP, "stream sync failed");
     return FHS_OK;
 }
 

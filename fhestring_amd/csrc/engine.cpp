@@ -189,6 +189,19 @@ Bid Engine::pbs(Bid x, int lut) {
 // flush: plan every level on the host, upload the plan once, enqueue all launches
 // ------------------------------------------------------------------------------------------
 int Engine::flush() {
+    if (dist_world > 1 && !pending_.empty())
+        return ctx.fail(-3, "distributed context: pending PBS must be run with fhs_flush_plan/level_exec/level_commit");
+    int rc = plan_flush();
+    if (rc) return rc;
+    for (size_t k = 0; k < plan_.levels.size(); k++)
+        if ((rc = exec_level(k, 0, plan_.levels[k].count, nullptr))) return rc;
+    plan_.levels.clear();
+    return 0;
+}
+
+// Builds the plan for every pending level and uploads it; nodes get their output blocks here.
+int Engine::plan_flush() {
+    plan_.levels.clear();
     if (pending_.empty()) return 0;
     if (!ctx.key_loaded) return ctx.fail(-3, "server key not loaded");
     if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
@@ -199,8 +212,7 @@ int Engine::flush() {
     pending_.clear();
     if (by_level.empty()) return 0;
 
-    struct LevelPlan { size_t first, count; };
-    std::vector<LevelPlan> levels;
+    std::vector<LevelPlan> &levels = plan_.levels;
     std::vector<LinDesc> descs;
     std::vector<LinTerm> terms;
     std::vector<uint32_t> lut_idx;
@@ -280,37 +292,67 @@ int Engine::flush() {
     }
     // pageable host memory: hipMemcpyAsync has consumed `host` when it returns
 
+    plan_.off_desc = off_desc;
+    plan_.off_terms = off_terms;
+    plan_.off_lut = off_lut;
+    plan_.off_out = off_out;
+    plan_.max_width = max_width;
+    return 0;
+}
+
+// Runs items [lo, hi) of level k.  dense_out == nullptr: results go straight to the nodes' blocks;
+// otherwise they are written as rows 0..hi-lo of dense_out (distributed mode, before the all-gather).
+int Engine::exec_level(size_t k, size_t lo, size_t hi, uint64_t *dense_out) {
+    if (k >= plan_.levels.size()) return ctx.fail(-1, "level index out of range");
+    const LevelPlan &lp = plan_.levels[k];
+    if (lo > hi || hi > lp.count) return ctx.fail(-1, "slice out of range");
+    const size_t cnt = hi - lo;
+    if (cnt == 0) return 0;
+    if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
     const uint8_t *dp = plan_buf_.as<uint8_t>();
-    for (const LevelPlan &lp : levels) {
-        const LinDesc *d_desc = reinterpret_cast<const LinDesc *>(dp + off_desc) + lp.first;
-        const LinTerm *d_terms = reinterpret_cast<const LinTerm *>(dp + off_terms);
-        const uint32_t *d_lut = reinterpret_cast<const uint32_t *>(dp + off_lut) + lp.first;
-        uint64_t *const *d_out = reinterpret_cast<uint64_t *const *>(dp + off_out) + lp.first;
-        e = launch_lincomb(d_desc, d_terms, batch_in_.as<uint64_t>(), (int)lp.count, ctx.stream);
-        if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
-        ctx.timer.begin(1, lp.count, ctx.stream);
-        e = launch_keyswitch(batch_in_.as<uint64_t>(), ctx.d_ksk, ctx.d_colsum4, ctx.ks_buf.as<uint64_t>(),
-                             (int)lp.count, ctx.stream);
-        ctx.timer.end(ctx.stream);
-        if (e != hipSuccess) return ctx.hip_fail(e, "keyswitch launch");
-        BlindRotateParams p{};
-        p.ks = ctx.ks_buf.as<uint64_t>();
-        p.lut_idx = d_lut;
-        p.luts = d_luts_;
-        p.bsk_ntt = ctx.d_bsk_ntt;
-        p.tw = ctx.tw;
-        p.crt_c = ctx.crt_c;
-        p.out = nullptr;
-        p.out_ptrs = d_out;
-        p.B = (int)lp.count;
-        ctx.timer.begin(0, lp.count, ctx.stream);
-        e = launch_blind_rotate(p, ctx.stream);
-        ctx.timer.end(ctx.stream);
-        if (e != hipSuccess) return ctx.hip_fail(e, "blind_rotate launch");
-        stats.pbs_executed += lp.count;
+    const LinDesc *d_desc = reinterpret_cast<const LinDesc *>(dp + plan_.off_desc) + lp.first + lo;
+    const LinTerm *d_terms = reinterpret_cast<const LinTerm *>(dp + plan_.off_terms);
+    const uint32_t *d_lut = reinterpret_cast<const uint32_t *>(dp + plan_.off_lut) + lp.first + lo;
+    uint64_t *const *d_out = reinterpret_cast<uint64_t *const *>(dp + plan_.off_out) + lp.first + lo;
+    hipError_t e = launch_lincomb(d_desc, d_terms, batch_in_.as<uint64_t>(), (int)cnt, ctx.stream);
+    if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
+    ctx.timer.begin(1, cnt, ctx.stream);
+    e = launch_keyswitch(batch_in_.as<uint64_t>(), ctx.d_ksk, ctx.d_colsum4, ctx.ks_buf.as<uint64_t>(), (int)cnt,
+                         ctx.stream);
+    ctx.timer.end(ctx.stream);
+    if (e != hipSuccess) return ctx.hip_fail(e, "keyswitch launch");
+    BlindRotateParams p{};
+    p.ks = ctx.ks_buf.as<uint64_t>();
+    p.lut_idx = d_lut;
+    p.luts = d_luts_;
+    p.bsk_ntt = ctx.d_bsk_ntt;
+    p.tw = ctx.tw;
+    p.crt_c = ctx.crt_c;
+    p.out = dense_out;
+    p.out_ptrs = dense_out ? nullptr : d_out;
+    p.B = (int)cnt;
+    ctx.timer.begin(0, cnt, ctx.stream);
+    e = launch_blind_rotate(p, ctx.stream);
+    ctx.timer.end(ctx.stream);
+    if (e != hipSuccess) return ctx.hip_fail(e, "blind_rotate launch");
+    stats.pbs_executed += cnt;
+    if (lo == 0 || dense_out) {
         stats.levels += 1;
         stats.max_level_width = std::max<uint64_t>(stats.max_level_width, lp.count);
     }
+    return 0;
+}
+
+// Distributed mode: rows 0..count of d_all (the gathered level, item order) -> the nodes' blocks.
+int Engine::commit_level(size_t k, const uint64_t *d_all) {
+    if (k >= plan_.levels.size()) return ctx.fail(-1, "level index out of range");
+    const LevelPlan &lp = plan_.levels[k];
+    if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
+    uint64_t *const *d_out =
+        reinterpret_cast<uint64_t *const *>(plan_buf_.as<uint8_t>() + plan_.off_out) + lp.first;
+    hipError_t e = launch_scatter_blocks(d_all, d_out, (int)lp.count, ctx.stream);
+    if (e != hipSuccess) return ctx.hip_fail(e, "scatter launch");
+    if (k + 1 == plan_.levels.size()) plan_.levels.clear();
     return 0;
 }
 

@@ -61,6 +61,16 @@ class Engine {
     int triv_val(Bid b) const { return nodes_[b].triv; }
 
     int flush();
+    // distributed execution (one process per GPU, identical DAGs on every rank): plan once, then per
+    // level every rank runs its slice into a dense buffer, the caller all-gathers, commit scatters
+    int dist_rank = 0, dist_world = 1;
+    struct LevelPlan { size_t first, count; };
+    int plan_flush();
+    size_t planned_levels() const { return plan_.levels.size(); }
+    size_t level_width(size_t k) const { return plan_.levels[k].count; }
+    size_t planned_max_width() const { return plan_.max_width; }
+    int exec_level(size_t k, size_t lo, size_t hi, uint64_t *dense_out);
+    int commit_level(size_t k, const uint64_t *d_all);
     int read_block(Bid b, uint64_t *host_out);        // flushes if needed
     int copy_block_to_device(Bid b, uint64_t *d_out);  // flushes if needed
     uint64_t blocks_live() const { return live_dev_blocks_; }
@@ -89,6 +99,11 @@ class Engine {
     // LUT table on device (catalogue)
     uint64_t *d_luts_ = nullptr;
     DevBuf plan_buf_, batch_in_;
+
+    struct FlushPlan {
+        std::vector<LevelPlan> levels;
+        size_t off_desc = 0, off_terms = 0, off_lut = 0, off_out = 0, max_width = 0;
+    } plan_;
 
     Bid new_node();
     int materialize_lin(Bid b);

@@ -69,3 +69,47 @@ class ShardedContains:
             torch.cuda.synchronize()
         parts = [sk.import_device(allp.data_ptr() + 8 * CHAR_WORDS * r) for r in range(self.world)]
         return sk.flags_or(parts)
+
+
+class LevelParallel:
+    """Generic multi-GPU execution of ANY op: the ranks hold the same ciphertexts, record the same DAG
+    and split every PBS level; one all-gather of the level's outputs (width x 16 392 B) per level.
+    Works for replace / compare / find / ... without op-specific partial results (the window sharding
+    above moves less data and is what bench.py uses for contains)."""
+
+    def __init__(self, sk, rank, world, dist, torch):
+        self.sk, self.rank, self.world, self.dist, self.torch = sk, rank, world, dist, torch
+        self._send = self._recv = None
+
+    def _buffers(self, cap):
+        torch = self.torch
+        words = cap * 2049
+        if self._send is None or self._send.numel() < words:
+            self._send = torch.empty(words, dtype=torch.int64, device="cuda")
+            self._recv = torch.empty(self.world * words, dtype=torch.int64, device="cuda")
+        return self._send[:words], self._recv[:self.world * words]
+
+    def flush(self):
+        import ctypes as C
+        L, h, torch = self.sk.ctx._L, self.sk.ctx._h, self.torch
+        n_levels, max_w = C.c_uint64(), C.c_uint64()
+        self.sk.ctx._check(L.fhs_flush_plan(h, C.byref(n_levels), C.byref(max_w)))
+        if n_levels.value == 0:
+            return
+        cap_max = (max_w.value + self.world - 1) // self.world
+        self._buffers(cap_max)
+        for k in range(n_levels.value):
+            width, cap = C.c_uint64(), C.c_uint64()
+            self.sk.ctx._check(L.fhs_flush_level_exec(h, k, C.c_void_p(self._send.data_ptr()), C.byref(width),
+                                                      C.byref(cap)))
+            self.sk.ctx._check(L.fhs_stream_sync(h))
+            send, recv = self._buffers(cap.value)
+            if self.dist.get_backend() != "nccl":             # tests: ranks sharing one GPU, CPU group
+                parts = [torch.empty(send.numel(), dtype=torch.int64) for _ in range(self.world)]
+                self.dist.all_gather(parts, send.cpu())
+                recv.copy_(torch.cat(parts))
+            else:
+                self.dist.all_gather_into_tensor(recv, send)   # RCCL over xGMI
+            torch.cuda.synchronize()
+            self.sk.ctx._check(L.fhs_flush_level_commit(h, k, C.c_void_p(recv.data_ptr())))
+        self.sk.ctx._check(L.fhs_stream_sync(h))

@@ -144,6 +144,18 @@ int fhs_bubble_zeroes_right(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_
 int fhs_flags_or(fhs_ctx *c, const fhs_char_t *flags, size_t n, fhs_char_t *out);
 int fhs_flags_and(fhs_ctx *c, const fhs_char_t *flags, size_t n, fhs_char_t *out);
 
+/* ---- level-parallel multi-GPU execution (one process per GPU; SURVEY 5 "per-level" pattern) --------
+ * Every rank holds the same ciphertexts and records the same DAG.  fhs_flush_plan levelises it;
+ * for each level k every rank runs its slice [rank*cap, (rank+1)*cap) of the level's PBS
+ * (cap = ceil(width / world)) into rows of `d_slice` (device, cap x 2049 u64), the caller all-gathers
+ * the slices (RCCL) into `d_all` (world x cap x 2049) and fhs_flush_level_commit installs the results.
+ * fhs_flush() refuses to run while world > 1 has pending work. */
+int fhs_dist_config(fhs_ctx *ctx, int rank, int world);
+int fhs_flush_plan(fhs_ctx *ctx, uint64_t *n_levels, uint64_t *max_level_width);
+int fhs_flush_level_exec(fhs_ctx *ctx, uint64_t level, uint64_t *d_slice, uint64_t *width, uint64_t *cap);
+int fhs_flush_level_commit(fhs_ctx *ctx, uint64_t level, const uint64_t *d_all);
+int fhs_stream_sync(fhs_ctx *ctx);
+
 /* ---- statistics ---------------------------------------------------------------- */
 typedef struct {
     uint64_t pbs_executed;     /* PBS actually run on the GPU (constant-folded ones excluded) */

@@ -42,3 +42,46 @@ def test_sharded_contains_two_ranks_one_gpu(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
     rcs = [p.wait(timeout=500) for p in procs]
     assert rcs == [0, 0]
+
+
+LEVEL_WORKER = r'''
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["FHS_ROOT"])
+from fhestring_amd.api import MyClientKey, MyServerKey
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ck = MyClientKey(0xF5E57121)                 # same seed and call order -> identical ciphertexts on every rank
+sk = MyServerKey.from_client_key(ck, 0)
+sk.set_mode(1)
+sk.enable_level_parallel(rank, world, dist, torch)
+s = ck.encrypt("hello abc abc test", 1, None, sk)
+o = ck.encrypt("hello abd", 2, None, sk)
+ok = True
+ok &= ck.decrypt(sk.replace(s, ck.encrypt_no_padding("abc", sk), ck.encrypt_no_padding("world", sk))) == "hello world world test"
+ok &= ck.decrypt_char(sk.find(s, ck.encrypt_no_padding("abc", sk))) == 6
+ok &= ck.decrypt_char(sk.le(s, o)) == int("hello abc abc test" <= "hello abd")
+ok &= ck.decrypt(sk.to_upper(s)) == "HELLO ABC ABC TEST"
+st = sk.stats()
+mine = torch.tensor([float(st["pbs_executed"])])
+tot = [torch.zeros(1) for _ in range(world)]
+dist.all_gather(tot, mine)
+share = st["pbs_executed"] / sum(float(t) for t in tot)
+ok &= 0.35 < share < 0.65                    # each rank ran about half of every level
+dist.barrier()
+dist.destroy_process_group()
+sk.close()
+sys.exit(0 if ok else 3)
+'''
+
+
+def test_level_parallel_two_ranks_one_gpu(tmp_path):
+    """Generic level-parallel mode: identical DAGs, every PBS level split over the ranks, one all-gather
+    per level -- replace (compaction), find, le and to_upper decrypt correctly on both ranks."""
+    script = tmp_path / "level_worker.py"
+    script.write_text(LEVEL_WORKER)
+    env = dict(os.environ, FHS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    rcs = [p.wait(timeout=900) for p in procs]
+    assert rcs == [0, 0]
