@@ -119,6 +119,10 @@ def _declare(L):
         f = getattr(L, name)
         f.argtypes = [vp, hp, sz, hp]
         f.restype = i
+    L.fhs_str_split_dim.argtypes = [i, sz]
+    L.fhs_str_split_dim.restype = sz
+    L.fhs_str_split.argtypes = [vp, i, hp, sz, hp, sz, h, hp, sz, C.POINTER(sz), hp]
+    L.fhs_str_split.restype = i
     L.fhs_dist_config.argtypes = [vp, i, i]
     L.fhs_dist_config.restype = i
     L.fhs_flush_plan.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]

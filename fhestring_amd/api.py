@@ -270,6 +270,29 @@ class FheString:
         return np.stack([c.download() for c in self.chars])
 
 
+class FheSplit:
+    """Vec<FheString> + pattern_found (src/ciphertext/fhesplit.rs:5-8)."""
+
+    def __init__(self, buffers, pattern_found):
+        self.buffers = buffers
+        self.pattern_found = pattern_found
+
+    @staticmethod
+    def decrypt(fhe_split, my_client_key):                               # fhesplit.rs:29-40
+        return ([my_client_key.decrypt(b) for b in fhe_split.buffers],
+                my_client_key.decrypt_char(fhe_split.pattern_found))
+
+
+def trim_vector(vec):
+    """src/utils.rs:59-92."""
+    vec = list(vec)
+    while vec and vec[0] == "":
+        vec.pop(0)
+    while vec and vec[-1] == "":
+        vec.pop()
+    return vec
+
+
 def _harr(chars):
     arr = (C.c_uint64 * max(1, len(chars)))()
     for i, ch in enumerate(chars):
@@ -503,6 +526,40 @@ class MyServerKey:
         self.ctx._check(getattr(self.ctx._L, name)(self.ctx._h, _harr(s), len(s), _harr(pat), len(pat), out,
                                                    C.byref(found)))
         return FheString([FheAsciiChar(self, out[i]) for i in range(len(s))]), FheAsciiChar(self, found.value)
+
+    # ---- split family (src/server_key/split.rs) ---------------------------------
+    def _split(self, kind, s, pat=(), n=None):
+        s, pat = self._chars(s), self._chars(pat)
+        d = self.ctx._L.fhs_str_split_dim(kind, len(s))
+        out = (C.c_uint64 * max(1, d * d))()
+        dim, found = C.c_size_t(), C.c_uint64()
+        self.ctx._check(self.ctx._L.fhs_str_split(self.ctx._h, kind, _harr(s), len(s), _harr(pat), len(pat),
+                                                  n.h if n is not None else 0, out, d * d, C.byref(dim),
+                                                  C.byref(found)))
+        d = dim.value
+        bufs = [FheString([FheAsciiChar(self, out[i * d + j]) for j in range(d)]) for i in range(d)]
+        return FheSplit(bufs, FheAsciiChar(self, found.value))
+
+    def _clear(self, text):
+        return [self.trivial(b) for b in text.encode("ascii")]
+
+    def split(self, s, p, public_parameters=None): return self._split(0, s, p)                         # :989
+    def split_clear(self, s, p, public_parameters=None): return self._split(0, s, self._clear(p))
+    def split_inclusive(self, s, p, public_parameters=None): return self._split(1, s, p)               # :1020
+    def split_inclusive_clear(self, s, p, public_parameters=None): return self._split(1, s, self._clear(p))
+    def split_terminator(self, s, p, public_parameters=None): return self._split(2, s, p)              # :1051
+    def split_terminator_clear(self, s, p, public_parameters=None): return self._split(2, s, self._clear(p))
+    def splitn(self, s, p, n, public_parameters=None): return self._split(3, s, p, n)                  # :1448
+    def splitn_clear(self, s, p, n, public_parameters=None): return self._split(3, s, self._clear(p), self.trivial(n))
+    def rsplit(self, s, p, public_parameters=None): return self._split(4, s, p)                        # :394
+    def rsplit_clear(self, s, p, public_parameters=None): return self._split(4, s, self._clear(p))
+    def rsplit_terminator(self, s, p, public_parameters=None): return self._split(5, s, p)             # :504
+    def rsplit_terminator_clear(self, s, p, public_parameters=None): return self._split(5, s, self._clear(p))
+    def rsplitn(self, s, p, n, public_parameters=None): return self._split(6, s, p, n)                 # :421
+    def rsplitn_clear(self, s, p, n, public_parameters=None): return self._split(6, s, self._clear(p), self.trivial(n))
+    def rsplit_once(self, s, p, public_parameters=None): return self._split(7, s, p)                   # :462
+    def rsplit_once_clear(self, s, p, public_parameters=None): return self._split(7, s, self._clear(p))
+    def split_ascii_whitespace(self, s, public_parameters=None): return self._split(8, s)              # :1377
 
     def strip_prefix(self, s, pat, public_parameters=None): return self._strip("fhs_str_strip_prefix", s, pat)   # mod.rs:1261
     def strip_suffix(self, s, pat, public_parameters=None): return self._strip("fhs_str_strip_suffix", s, pat)   # mod.rs:1335

@@ -1,5 +1,5 @@
 """CLI diff harness: counterpart of the reference binary's `main` + `run_fhe_str_method`
-(src/main.rs:34-116, src/utils.rs:114-718) for every non-split method.
+(src/main.rs:34-116, src/utils.rs:114-718) for all 52 `StringMethod` variants.
 
     python -m fhestring_amd.cli --string "hello" --pattern "ello" --n 1 --from "ello" --to "_llo"
 
@@ -7,20 +7,21 @@ Encrypts the inputs with the client key, runs each MyServerKey method on the MI3
 compares with the plaintext semantics (python `str` here, Rust `std::str` there) and prints the
 reference's lines: `Test Passed: OK, Result: ..., ` / `Test Failed: Expected: ..., Got: ..., `
 (utils.rs:114-120) followed by `<Method> <duration>` (main.rs:114).  As in the reference the timed
-region includes encryption and decryption (utils.rs:135-145).  The split family (16 variants,
-src/server_key/split.rs) is out of scope this round and is listed as skipped.
+region includes encryption and decryption (utils.rs:135-145).
 """
 import argparse
 import sys
 import time
 
-from .api import MAX_FIND_LENGTH, MAX_REPETITIONS, STRING_PADDING, MyClientKey
+from .api import MAX_FIND_LENGTH, MAX_REPETITIONS, STRING_PADDING, FheSplit, MyClientKey, trim_vector
 
 WS = " \t\n\x0b\x0c\r"
 
 
 def rust_debug(v):
-    """`{:?}` of a u8 / String / &str."""
+    """`{:?}` of a u8 / String / &str / Vec<String>."""
+    if isinstance(v, (list, tuple)):
+        return "[" + ", ".join(rust_debug(x) for x in v) + "]"
     if isinstance(v, str):
         out = '"'
         for ch in v:
@@ -59,17 +60,36 @@ def rust_duration(sec):
     return ("%.3f" % (sec * 1e6)).rstrip("0").rstrip(".") + "µs"
 
 
-METHODS = [  # order of src/main.rs:47-100, split family removed
+METHODS = [  # order of src/main.rs:47-100
     "Contains", "ContainsClear", "EndsWith", "EndsWithClear", "EqIgnoreCase", "Find", "FindClear", "IsEmpty",
     "Len", "Repeat", "RepeatClear", "Replace", "ReplaceClear", "ReplaceN", "ReplaceNClear", "Rfind",
-    "RfindClear", "StartsWith", "StartsWithClear", "StripPrefix", "StripPrefixClear", "StripSuffix",
-    "StripSuffixClear", "ToLower", "ToUpper", "Trim", "TrimEnd", "TrimStart", "Concatenate", "Lt", "Le",
-    "Gt", "Ge", "Eq", "Ne",
+    "RfindClear", "Rsplit", "RsplitClear", "RsplitOnce", "RsplitOnceClear", "RsplitN", "RsplitNClear",
+    "RsplitTerminator", "RsplitTerminatorClear", "Split", "SplitClear", "SplitAsciiWhitespace", "SplitInclusive",
+    "SplitInclusiveClear", "SplitTerminator", "SplitTerminatorClear", "SplitN", "SplitNClear", "StartsWith",
+    "StartsWithClear", "StripPrefix", "StripPrefixClear", "StripSuffix", "StripSuffixClear", "ToLower",
+    "ToUpper", "Trim", "TrimEnd", "TrimStart", "Concatenate", "Lt", "Le", "Gt", "Ge", "Eq", "Ne",
 ]
-SKIPPED = ["Rsplit", "RsplitClear", "RsplitOnce", "RsplitOnceClear", "RsplitN", "RsplitNClear",
-           "RsplitTerminator", "RsplitTerminatorClear", "Split", "SplitClear", "SplitAsciiWhitespace",
-           "SplitInclusive", "SplitInclusiveClear", "SplitTerminator", "SplitTerminatorClear", "SplitN",
-           "SplitNClear"]
+SKIPPED = []
+
+
+def _py_split(method, s, p, n):
+    """Rust std semantics of the split family (the `expected` side of src/utils.rs:321-521)."""
+    base = method[:-5] if method.endswith("Clear") else method
+    if base == "Split": return s.split(p)
+    if base == "SplitInclusive":
+        parts = s.split(p)
+        return [x + p for x in parts[:-1]] + ([parts[-1]] if parts[-1] != "" else [])
+    if base == "SplitTerminator":
+        parts = s.split(p)
+        return parts[:-1] if parts and parts[-1] == "" else parts
+    if base == "SplitAsciiWhitespace": return s.split()
+    if base == "SplitN": return s.split(p, n - 1) if n > 0 else []
+    if base == "Rsplit": return s.split(p)[::-1]
+    if base == "RsplitN": return s.rsplit(p, n - 1)[::-1] if n > 0 else []
+    if base == "RsplitTerminator":
+        parts = s.split(p)
+        return (parts[:-1] if parts and parts[-1] == "" else parts)[::-1]
+    raise KeyError(method)
 
 
 def run_fhe_str_method(sk, ck, a, method, out=sys.stdout):       # utils.rs:122-718
@@ -137,6 +157,28 @@ def run_fhe_str_method(sk, ck, a, method, out=sys.stdout):       # utils.rs:122-
         ok = compare_and_print(s_plain.lstrip(WS), dst(sk.trim_start(s)), out)
     elif method == "Concatenate":
         ok = compare_and_print(s_plain + p_plain, dst(sk.concatenate(s, other())), out)
+    elif "plit" in method:                                         # split family, utils.rs:321-521
+        clear = method.endswith("Clear")
+        base = method[:-5] if clear else method
+        pp = p_plain if clear else pat
+        if base == "SplitAsciiWhitespace":
+            r = sk.split_ascii_whitespace(s)
+        elif base in ("SplitN", "RsplitN"):
+            f = {"SplitN": (sk.splitn, sk.splitn_clear), "RsplitN": (sk.rsplitn, sk.rsplitn_clear)}[base][clear]
+            r = f(s, pp, n_plain if clear else n)
+        else:
+            name = {"Split": "split", "SplitInclusive": "split_inclusive", "SplitTerminator": "split_terminator",
+                    "Rsplit": "rsplit", "RsplitTerminator": "rsplit_terminator", "RsplitOnce": "rsplit_once"}[base]
+            r = getattr(sk, name + ("_clear" if clear else ""))(s, pp)
+        bufs, found = FheSplit.decrypt(r, ck)
+        if base == "RsplitOnce":                                   # utils.rs:345-385
+            if p_plain in s_plain:
+                a, b = s_plain.rsplit(p_plain, 1)
+                ok = compare_and_print(trim_vector([b, a]), trim_vector(bufs), out)
+            else:
+                ok = compare_and_print(0, found, out)
+        else:
+            ok = compare_and_print(trim_vector(_py_split(method, s_plain, p_plain, n_plain)), trim_vector(bufs), out)
     elif method in ("Lt", "Le", "Gt", "Ge", "Eq", "Ne"):
         f = {"Lt": sk.lt, "Le": sk.le, "Gt": sk.gt, "Ge": sk.ge, "Eq": sk.eq, "Ne": sk.ne}[method]
         e = {"Lt": s_plain < p_plain, "Le": s_plain <= p_plain, "Gt": s_plain > p_plain,
@@ -172,8 +214,6 @@ def main(argv=None):
         except OverflowError as e:                                # the reference panics here
             sys.stdout.write("panicked: %s, " % e)
         print("%s %s" % (m, rust_duration(time.perf_counter() - t0)))
-    if not a.methods:
-        print("skipped (split family, out of scope this round): " + ", ".join(SKIPPED))
     sk.close()
     return 1 if failed else 0
 

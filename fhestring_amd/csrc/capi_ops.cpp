@@ -292,6 +292,26 @@ int fhs_str_strip_suffix(fhs_ctx *c, const fhs_char_t *s, size_t n, const fhs_ch
     return FHS_OK;
 }
 
+size_t fhs_str_split_dim(int kind, size_t n) { return kind == Strings::SPLIT_ASCII_WHITESPACE ? n : n + 1; }
+int fhs_str_split(fhs_ctx *c, int kind, const fhs_char_t *s, size_t n, const fhs_char_t *pat, size_t m,
+                  fhs_char_t count, fhs_char_t *out, size_t out_cap, size_t *dim, fhs_char_t *found) {
+    if (!ok_all(c, s, n) || !ok_all(c, pat, m) || !out || !dim || !found || kind < 0 || kind > 8) return bad(c);
+    const bool needs_n = kind == Strings::SPLITN || kind == Strings::RSPLITN;
+    if (needs_n && !ok(c, count)) return bad(c);
+    const size_t d = fhs_str_split_dim(kind, n);
+    if (out_cap < d * d) return c->eng.ctx.fail(FHS_ERR_ARG, "output capacity too small");
+    Strings S(&c->eng);
+    FChar nn, f;
+    if (needs_n) nn = load(c->eng, count);
+    std::vector<FStr> r = S.split_family(kind, load_str(c->eng, s, n), load_str(c->eng, pat, m),
+                                         needs_n ? &nn : nullptr, &f);
+    for (size_t i = 0; i < d; i++)
+        for (size_t j = 0; j < d; j++) out[i * d + j] = store(c->eng, r[i][j]);
+    *dim = d;
+    *found = store(c->eng, f);
+    return FHS_OK;
+}
+
 int fhs_flags_or(fhs_ctx *c, const fhs_char_t *flags, size_t n, fhs_char_t *out) {
     if (!ok_all(c, flags, n) || !out) return bad(c);
     Strings S(&c->eng);

@@ -396,6 +396,162 @@ FStr Strings::trim_start(const FStr &s) {                    // trim.rs:86-115
 FStr Strings::trim(const FStr &s) { return trim_start(trim_end(s)); }   // trim.rs:146-149
 
 // ---------------------------------------------------------------------------------------------
+// split family (src/server_key/split.rs), same loops as the reference; in fused mode the char-level
+// helpers work on single-block flags and the buffers are compacted instead of bubble-sorted
+// ---------------------------------------------------------------------------------------------
+FChar Strings::s_eq(const FChar &a, const FChar &b) {
+    return fused() ? ch_flag(e_, and_tree(block_eq_flags(a, b))) : ch_eq(a, b);
+}
+FChar Strings::s_ite(const FChar &flag, const FChar &tv, const FChar &fv) {
+    return fused() ? ite_flag(flag.b[0], tv, fv) : ch_ite(flag, tv, fv);
+}
+FChar Strings::s_not(const FChar &flag) {
+    if (!fused()) return ch_flip(flag);
+    Ref one = trivial_block(e_, 1);
+    return ch_flag(e_, lin(e_, {{1, &one}, {-1, &flag.b[0]}}));
+}
+
+FChar Strings::split_match(bool reverse, size_t i, const FStr &s, const FStr &pat, FStr &mask) {
+    const FChar zero = t(0), one = t(1);
+    FChar found = one;
+    if (reverse) {                                           // rsplit_pattern_matching, split.rs:10-67
+        if (pat.empty()) {
+            FChar cur_pad = s_eq(s[i], zero);
+            if (i >= 1) {
+                FChar prev_nonpad = s_not(s_eq(s[i - 1], zero));
+                found = s_ite(ch_bitand(prev_nonpad, cur_pad), one, zero);
+                found = ch_bitor(found, s_ite(cur_pad, zero, one));
+            } else found = s_ite(cur_pad, zero, one);
+        } else if (pat.size() > s.size() || i + pat.size() >= s.size()) {
+            found = zero;
+        } else {
+            for (size_t j = 0; j < pat.size(); j++) {
+                found = ch_bitand(found, s_eq(s[i + j], pat[j]));
+                found = ch_bitand(found, mask[i + j]);
+            }
+        }
+    } else {                                                 // split_pattern_matching, split.rs:69-108
+        if (pat.size() > s.size() || i + 1 < pat.size()) {
+            found = zero;
+        } else {
+            for (size_t j = 0; j < pat.size(); j++) {
+                const size_t k = i + 1 - pat.size() + j;
+                found = ch_bitand(found, s_eq(s[k], pat[j]));
+                found = ch_bitand(found, mask[k]);
+            }
+        }
+    }
+    for (size_t j = 0; j < pat.size(); j++)                  // no overlapping re-match
+        if (i + j < s.size()) mask[i + j] = ch_bitand(mask[i + j], s_ite(found, zero, one));
+    return found;
+}
+
+std::vector<FStr> Strings::xsplit(const FStr &s_in, const FStr &pat, bool inclusive, bool terminator,
+                                  const FChar *n, bool reverse, FChar *found_out) {   // _rsplit :307-393, _split :883-988
+    const FChar zero = t(0), one = t(1);
+    FStr s = s_in;
+    s.push_back(zero);
+    const size_t size = s.size();
+    FChar cur_buf = zero, stop_inc = zero, global_found = zero, allow = zero;
+    std::vector<FStr> result(size, FStr(size, zero));
+    FStr mask(size, one);
+    if (n) allow = ch_ne(*n, zero);
+    if (!reverse && pat.empty() && n) {                      // split.rs:925-937
+        FChar enc_len = len(s);
+        FChar skip = ch_bitand(ch_gt(*n, one), ch_le(*n, enc_len));
+        cur_buf = s_ite(skip, t(1), cur_buf);
+    }
+    for (size_t step = 0; step < size; step++) {
+        const size_t i = reverse ? size - 1 - step : step;
+        for (size_t j = 0; j < size; j++) {                  // copy_logic, split.rs:110-134
+            FChar flag = s_eq(t((uint8_t)j), cur_buf);
+            if (n) flag = ch_bitand(flag, allow);
+            result[j][i] = s_ite(flag, s[i], result[j][i]);
+        }
+        FChar f = split_match(reverse, i, s, pat, mask);
+        global_found = ch_bitor(global_found, f);
+        if (!n) {                                            // handle_n_case, split.rs:136-173
+            cur_buf = s_ite(f, ch_add(cur_buf, one), cur_buf);
+        } else {
+            stop_inc = ch_bitor(stop_inc, s_eq(cur_buf, ch_sub(*n, one)));
+            cur_buf = s_ite(ch_bitand(f, s_not(stop_inc)), ch_add(cur_buf, one), cur_buf);
+        }
+    }
+    // clear_pattern_from_result, split.rs:175-305
+    FStr to(pat.size(), zero);
+    if (n) {
+        FChar stop = zero;
+        for (size_t i = 0; i < size; i++) {
+            stop = ch_bitor(stop, s_eq(*n, ch_add(t((uint8_t)i), one)));
+            FStr cur = bubble_zeroes_right(result[i]);
+            FStr rep = replace(cur, pat, to);
+            for (size_t j = 0; j < size; j++) result[i][j] = s_ite(stop, cur[j], rep[j]);
+        }
+    } else {
+        for (size_t i = 0; i < size; i++)
+            result[i] = inclusive ? bubble_zeroes_right(result[i]) : replace(result[i], pat, to);
+        if (terminator) {                                    // split.rs:266-302
+            FChar nonzero_found = zero;
+            for (size_t i = size; i-- > 0;) {
+                FChar is_zero = one;
+                for (size_t j = 0; j < size; j++) is_zero = ch_bitand(is_zero, s_eq(result[i][j], zero));
+                FStr head(result[i].begin(), result[i].begin() + size);
+                FChar starts = starts_with(head, pat);
+                FChar del = ch_bitand(ch_bitand(starts, is_zero), s_not(nonzero_found));
+                for (size_t j = 0; j < size; j++) result[i][j] = s_ite(del, zero, result[i][j]);
+                nonzero_found = ch_bitor(nonzero_found, s_not(is_zero));
+            }
+        }
+    }
+    *found_out = global_found;
+    return result;
+}
+
+std::vector<FStr> Strings::split_ws(const FStr &s, FChar *found_out) {   // split.rs:1377-1447
+    const FChar zero = t(0), one = t(1);
+    const size_t size = s.size();
+    FChar cur_buf = zero, prev_ws = t(1), global_found = zero;
+    std::vector<FStr> result(size, FStr(size, zero));
+    auto is_ws = [&](const FChar &c) {
+        if (!fused()) return ch_is_whitespace(c);
+        // significant = neither NUL nor whitespace; whitespace = !significant & nonzero
+        Ref sig = char_significant(c), nz = char_nonzero(c);
+        return ch_flag(e_, lin(e_, {{1, &nz}, {-1, &sig}}));
+    };
+    for (size_t i = 0; i < size; i++) {
+        FChar f = is_ws(s[i]);
+        global_found = ch_bitor(global_found, f);
+        FChar inc = ch_bitand(f, s_not(prev_ws));
+        cur_buf = s_ite(inc, ch_add(cur_buf, one), cur_buf);
+        FChar not_ws = s_not(f);
+        for (size_t j = 0; j < size; j++) {
+            FChar flag = ch_bitand(s_eq(t((uint8_t)j), cur_buf), not_ws);
+            result[j][i] = s_ite(flag, s[i], result[j][i]);
+        }
+        prev_ws = f;
+    }
+    // (:1428-1436 re-tests every buffer char for whitespace: only non-whitespace was ever copied)
+    for (size_t j = 0; j < size; j++) result[j] = bubble_zeroes_right(result[j]);
+    *found_out = global_found;
+    return result;
+}
+
+std::vector<FStr> Strings::split_family(int kind, const FStr &s, const FStr &pat, const FChar *n, FChar *found) {
+    const FChar two = t(2);
+    switch (kind) {
+        case SPLIT: return xsplit(s, pat, false, false, nullptr, false, found);             // split.rs:989
+        case SPLIT_INCLUSIVE: return xsplit(s, pat, true, false, nullptr, false, found);    // :1020
+        case SPLIT_TERMINATOR: return xsplit(s, pat, false, true, nullptr, false, found);   // :1051
+        case SPLITN: return xsplit(s, pat, false, false, n, false, found);                  // :1448
+        case RSPLIT: return xsplit(s, pat, false, false, nullptr, true, found);             // :394
+        case RSPLIT_TERMINATOR: return xsplit(s, pat, false, true, nullptr, true, found);   // :504
+        case RSPLITN: return xsplit(s, pat, false, false, n, true, found);                  // :421
+        case RSPLIT_ONCE: return xsplit(s, pat, false, false, &two, true, found);           // :462
+        default: return split_ws(s, found);                                                 // :1377
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // fused mode: single-block 0/1 flags, sums of up to 15 flags per PBS (the carry space holds 15),
 // log_15-depth AND/OR trees.  Decrypts identically to the as-written mode.
 // ---------------------------------------------------------------------------------------------

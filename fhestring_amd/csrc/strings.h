@@ -46,8 +46,20 @@ class Strings {
     FStr bubble_zeroes_right(const FStr &s);
     FChar flags_or(const FStr &flags);
     FChar flags_and(const FStr &flags);
+    // split family (src/server_key/split.rs): result[buffer][position] + pattern_found, like FheSplit
+    enum SplitKind { SPLIT = 0, SPLIT_INCLUSIVE, SPLIT_TERMINATOR, SPLITN, RSPLIT, RSPLIT_TERMINATOR, RSPLITN,
+                     RSPLIT_ONCE, SPLIT_ASCII_WHITESPACE };
+    std::vector<FStr> split_family(int kind, const FStr &s, const FStr &pat, const FChar *n, FChar *found);
 
   private:
+    // char-level ops of the split family: as written, or single-block-flag versions in fused mode
+    FChar s_eq(const FChar &a, const FChar &b);
+    FChar s_ite(const FChar &flag, const FChar &tv, const FChar &fv);
+    FChar s_not(const FChar &flag);
+    FChar split_match(bool reverse, size_t i, const FStr &s, const FStr &pat, FStr &mask);
+    std::vector<FStr> xsplit(const FStr &s, const FStr &pat, bool inclusive, bool terminator, const FChar *n,
+                             bool reverse, FChar *found);
+    std::vector<FStr> split_ws(const FStr &s, FChar *found);
     Engine *e_;
     bool fused() const { return e_->mode == 1; }
     FChar t(uint8_t v) const { return ch_trivial(e_, v); }

@@ -139,6 +139,14 @@ int fhs_str_trim_end(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out 
 int fhs_str_trim_start(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out /*[n]*/);                             /* trim.rs:86 */
 int fhs_str_trim(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out /*[n]*/);                                   /* trim.rs:146 */
 int fhs_bubble_zeroes_right(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out /*[n]*/);                        /* utils.rs:28 */
+/* split family (src/server_key/split.rs, FheSplit of src/ciphertext/fhesplit.rs:5-8).
+ * kind: 0 split :989, 1 split_inclusive :1020, 2 split_terminator :1051, 3 splitn :1448, 4 rsplit :394,
+ * 5 rsplit_terminator :504, 6 rsplitn :421, 7 rsplit_once :462, 8 split_ascii_whitespace :1377.
+ * `count` is the encrypted (or trivial) n of splitn/rsplitn, 0 otherwise.  The reference returns
+ * d buffers of d chars with d = n + 1 (d = n for kind 8): out[d*d] row-major, *dim = d. */
+size_t fhs_str_split_dim(int kind, size_t n);
+int fhs_str_split(fhs_ctx *c, int kind, const fhs_char_t *s, size_t n, const fhs_char_t *pat, size_t m,
+                  fhs_char_t count, fhs_char_t *out, size_t out_cap, size_t *dim, fhs_char_t *found);
 /* OR / AND of n 0/1 flag chars in log_15(n) levels (chains of bitor/bitand :65-81 re-associated);
  * used to combine per-GPU partial results after the gather. */
 int fhs_flags_or(fhs_ctx *c, const fhs_char_t *flags, size_t n, fhs_char_t *out);

@@ -1,10 +1,9 @@
 """Oracle string layer -- TEST INFRASTRUCTURE ONLY.
 
 Restatement, loop for loop, of the reference's `MyServerKey` string algorithms
-(src/server_key/mod.rs, src/server_key/trim.rs, src/utils.rs:28-112) on top of
-an abstract FheAsciiChar (oracle/radix.py: ClearChar or CipherChar).  Every
-function cites the reference lines it follows.  The split family
-(src/server_key/split.rs) is out of scope.
+(src/server_key/mod.rs, src/server_key/trim.rs, src/server_key/split.rs,
+src/utils.rs:28-112) on top of an abstract FheAsciiChar (oracle/radix.py:
+ClearChar or CipherChar).  Every function cites the reference lines it follows.
 
 Strings are python lists of chars (FheString.bytes, fhestring.rs:6-9); the case
 delta `cst` = trivial 32 (fhestring.rs:24).
@@ -338,6 +337,158 @@ class Ops:
 
     def trim(self, s):                                       # trim.rs:146-149
         return self.trim_start(self.trim_end(s))
+
+
+# ---- split family (src/server_key/split.rs); returns (buffers, pattern_found) like FheSplit ----
+class SplitOps(Ops):
+    def _rsplit_pattern_matching(self, i, s, pattern, mask, zero, one):        # split.rs:10-67
+        found = one
+        if not pattern:
+            cur_pad = s[i].eq(zero)
+            if i >= 1:
+                prev_nonpad = s[i - 1].ne(zero)
+                found = prev_nonpad.bitand(cur_pad).if_then_else(one, zero)
+                found = found.bitor(cur_pad.if_then_else(zero, one))
+            else:
+                found = cur_pad.if_then_else(zero, one)
+        elif len(pattern) > len(s) or i + len(pattern) >= len(s):
+            found = zero
+        else:
+            for j, pc in enumerate(pattern):
+                found = found.bitand(s[i + j].eq(pc))
+                found = found.bitand(mask[i + j])
+        for j in range(len(pattern)):                                         # :58-65
+            if i + j < len(s):
+                mask[i + j] = mask[i + j].bitand(found.if_then_else(zero, one))
+        return found
+
+    def _split_pattern_matching(self, i, s, pattern, mask, zero, one):         # split.rs:69-108
+        found = one
+        if len(pattern) > len(s) or i < len(pattern) - 1:
+            found = zero
+        else:
+            for j, pc in enumerate(pattern):
+                k = i - len(pattern) + 1 + j
+                found = found.bitand(s[k].eq(pc))
+                found = found.bitand(mask[k])
+        for j in range(len(pattern)):                                         # :99-105
+            if i + j < len(s):
+                mask[i + j] = mask[i + j].bitand(found.if_then_else(zero, one))
+        return found
+
+    def _copy_logic(self, i, n, s, result, allow_copying, cur_buf):            # split.rs:110-134
+        for j in range(len(result)):
+            flag = self.t(j).eq(cur_buf)
+            if n is not None:
+                flag = flag.bitand(allow_copying)
+            result[j][i] = flag.if_then_else(s[i], result[j][i])
+
+    def _handle_n_case(self, found, n, cur_buf, stop_inc, one):                # split.rs:136-173
+        if n is None:
+            return found.if_then_else(cur_buf.add(one), cur_buf), stop_inc
+        stop_inc = stop_inc.bitor(cur_buf.eq(n.sub(one)))
+        cur_buf = found.bitand(stop_inc.flip()).if_then_else(cur_buf.add(one), cur_buf)
+        return cur_buf, stop_inc
+
+    def _clear_pattern_from_result(self, n, result, pattern, zero, one, inclusive, terminator):   # split.rs:175-305
+        nb = len(result)
+        to = [self.t(0)] * len(pattern)
+        if n is not None:
+            stop = zero
+            for i in range(nb):
+                stop = stop.bitor(n.eq(self.t(i).add(one)))
+                cur = self.bubble_zeroes_right(result[i])
+                rep = self.replace(cur, pattern, to)
+                for j in range(nb):
+                    result[i][j] = stop.if_then_else(cur[j], rep[j])
+            return
+        if not inclusive:
+            for i in range(nb):
+                result[i] = self.replace(result[i], pattern, to)
+        else:
+            for i in range(nb):
+                result[i] = self.bubble_zeroes_right(result[i])
+        if terminator:                                                         # :266-302
+            nonzero_found = zero
+            for i in reversed(range(nb)):
+                is_zero = one
+                for j in range(nb):
+                    is_zero = is_zero.bitand(result[i][j].eq(zero))
+                starts = self.starts_with(result[i], pattern)
+                delete = starts.bitand(is_zero).bitand(nonzero_found.flip())
+                for j in range(nb):
+                    result[i][j] = delete.if_then_else(zero, result[i][j])
+                nonzero_found = nonzero_found.bitor(is_zero.flip())
+
+    def _xsplit(self, s, pattern, inclusive, terminator, n, reverse):          # _rsplit :307-393, _split :883-988
+        zero, one = self.t(0), self.t(1)
+        s = list(s) + [zero]
+        size = len(s)
+        cur_buf, stop_inc = zero, zero
+        result = [[zero] * size for _ in range(size)]
+        global_found = zero
+        allow_copying = zero
+        mask = [one] * size
+        if n is not None:
+            allow_copying = n.ne(zero)
+        if not reverse and not pattern and n is not None:                      # :925-937
+            enc_len = self.len(s)
+            skip = n.gt(one).bitand(n.le(enc_len))
+            cur_buf = skip.if_then_else(self.t(1), cur_buf)
+        order = reversed(range(size)) if reverse else range(size)
+        for i in order:
+            self._copy_logic(i, n, s, result, allow_copying, cur_buf)
+            if reverse:
+                found = self._rsplit_pattern_matching(i, s, pattern, mask, zero, one)
+            else:
+                found = self._split_pattern_matching(i, s, pattern, mask, zero, one)
+            global_found = global_found.bitor(found)
+            cur_buf, stop_inc = self._handle_n_case(found, n, cur_buf, stop_inc, one)
+        self._clear_pattern_from_result(n, result, pattern, zero, one, inclusive, terminator)
+        return result, global_found
+
+    def rsplit(self, s, p): return self._xsplit(s, p, False, False, None, True)               # :394
+    def rsplitn(self, s, p, n): return self._xsplit(s, p, False, False, n, True)             # :421
+    def rsplit_once(self, s, p): return self._xsplit(s, p, False, False, self.t(2), True)    # :462
+    def rsplit_terminator(self, s, p): return self._xsplit(s, p, False, True, None, True)    # :504
+    def split(self, s, p): return self._xsplit(s, p, False, False, None, False)              # :989
+    def split_inclusive(self, s, p): return self._xsplit(s, p, True, False, None, False)     # :1020
+    def split_terminator(self, s, p): return self._xsplit(s, p, False, True, None, False)    # :1051
+    def splitn(self, s, p, n): return self._xsplit(s, p, False, False, n, False)             # :1448
+
+    def split_ascii_whitespace(self, s):                                       # split.rs:1377-1447
+        zero, one = self.t(0), self.t(1)
+        size = len(s)
+        cur_buf = zero
+        result = [[zero] * size for _ in range(size)]
+        prev_ws = self.t(1)
+        global_found = zero
+        for i in range(size):
+            found = self.is_whitespace(s[i])
+            global_found = global_found.bitor(found)
+            inc = found.bitand(prev_ws.flip())
+            cur_buf = inc.if_then_else(cur_buf.add(one), cur_buf)
+            for j in range(size):
+                flag = self.t(j).eq(cur_buf).bitand(self.is_whitespace(s[i]).flip())
+                result[j][i] = flag.if_then_else(s[i], result[j][i])
+            prev_ws = found
+        for j in range(size):
+            for k in range(size):
+                c = result[j][k]
+                result[j][k] = self.is_whitespace(c).if_then_else(zero, c)
+        for j in range(size):
+            result[j] = self.bubble_zeroes_right(result[j])
+        return result, global_found
+
+
+def trim_vector(vec):
+    """utils.rs:59-92: drop leading and trailing empty strings (what the split tests compare)."""
+    vec = list(vec)
+    while vec and vec[0] == "":
+        vec.pop(0)
+    while vec and vec[-1] == "":
+        vec.pop()
+    return vec
 
 
 # ---- client side (src/client_key.rs:45-106) ---------------------------------

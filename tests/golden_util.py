@@ -44,8 +44,48 @@ def python_expected(v):
     if op == "le": return int(s <= v["other"])
     if op == "gt": return int(s > v["other"])
     if op == "ge": return int(s >= v["other"])
+    if op in SPLIT_OPS:
+        return _trim(_py_split(v))
     if op == "strip_prefix": return s[len(p):] if s.startswith(p) else s
     if op == "strip_suffix": return s[:len(s) - len(p)] if s.endswith(p) else s
+    raise KeyError(op)
+
+
+SPLIT_OPS = ("split", "split_inclusive", "split_terminator", "split_ascii_whitespace", "splitn", "rsplit",
+             "rsplit_once", "rsplitn", "rsplit_terminator")
+
+
+def _trim(vec):
+    vec = list(vec)
+    while vec and vec[0] == "":
+        vec.pop(0)
+    while vec and vec[-1] == "":
+        vec.pop()
+    return vec
+
+
+def _py_split(v):
+    """Rust std semantics of the split family on python strings."""
+    op, s, p = v["op"], v["string"], v.get("pattern")
+    if op == "split": return s.split(p)
+    if op == "split_inclusive":
+        parts = s.split(p)
+        out = [x + p for x in parts[:-1]] + ([parts[-1]] if parts[-1] != "" else [])
+        return out
+    if op == "split_terminator":
+        parts = s.split(p)
+        return parts[:-1] if parts and parts[-1] == "" else parts
+    if op == "split_ascii_whitespace": return s.split()
+    if op == "splitn": return s.split(p, v["n"] - 1) if v["n"] > 0 else []
+    if op == "rsplit": return s.split(p)[::-1]
+    if op == "rsplit_once":
+        a, b = s.rsplit(p, 1)
+        return [b, a]
+    if op == "rsplitn": return s.rsplit(p, v["n"] - 1)[::-1] if v["n"] > 0 else []
+    if op == "rsplit_terminator":
+        parts = s.split(p)
+        parts = parts[:-1] if parts and parts[-1] == "" else parts
+        return parts[::-1]
     raise KeyError(op)
 
 
@@ -72,6 +112,15 @@ def run_vector(v, ops, enc_string, enc_pattern, enc_char, dec_string, dec_char):
     if op == "concatenate":
         o = enc_string(v["other"], v["other_pad"])
         return dec_string(ops.concatenate(s, o))
+    if op in SPLIT_OPS:
+        args = [s]
+        if op != "split_ascii_whitespace":
+            args.append(enc_pattern(v["pattern"]))
+        if op in ("splitn", "rsplitn"):
+            args.append(ops.trivial_char(v["n"]) if v.get("n_trivial") else enc_char(v["n"]))
+        r = getattr(ops, op)(*args)
+        bufs = r[0] if isinstance(r, tuple) else r.buffers          # oracle tuple / product FheSplit
+        return _trim([dec_string(b) for b in bufs])
     if op in ("strip_prefix", "strip_suffix"):
         pat = enc_string(v["pattern"], v["pattern_pad"]) if "pattern_pad" in v else enc_pattern(v["pattern"])
         out, found = getattr(ops, op)(s, pat)

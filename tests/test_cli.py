@@ -11,7 +11,8 @@ def test_output_format_matches_reference_helpers():
     assert not cli.compare_and_print("a\"b", "x\ny", out)
     assert out.getvalue() == 'Test Passed: OK, Result: 1, Test Failed: Expected: "a\\"b", Got: "x\\ny", '
     assert cli.rust_duration(1.5) == "1.5s" and cli.rust_duration(0.0123) == "12.3ms"
-    assert len(cli.METHODS) + len(cli.SKIPPED) == 52          # enum StringMethod, src/string_method.rs:2-55
+    assert len(cli.METHODS) == 52 and not cli.SKIPPED         # enum StringMethod, src/string_method.rs:2-55
+    assert cli.rust_debug(["a", "b c"]) == '["a", "b c"]'
 
 
 @pytest.mark.gpu

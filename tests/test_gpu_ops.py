@@ -15,7 +15,8 @@ from golden_util import load_vectors, run_vector, check_vector
 pytestmark = pytest.mark.gpu
 VECTORS = load_vectors()
 # O(n^2 * |to|) / 48-char bubble sort as written: minutes of GPU time; opt in with FHS_SLOW=1
-SLOW = {"replace2", "repeat", "replacen"}
+SLOW = {"replace2", "repeat", "replacen", "split", "split_inclusive", "split_terminator", "split_ascii_whitespace",
+        "splitn", "rsplit", "rsplit_once", "rsplitn", "rsplit_terminator"}   # as written: O(n^3) char ops
 
 
 @pytest.fixture(scope="module")
@@ -66,6 +67,7 @@ def product():
 
 
 def _env(ck, sk):
+    sk.trivial_char = sk.trivial
     enc_s = lambda t, pad: ck.encrypt(t, pad, None, sk)
     enc_p = lambda t: ck.encrypt_no_padding(t, sk)
     enc_c = lambda v: ck.encrypt_char(v, sk)
@@ -83,7 +85,9 @@ def test_golden_vectors_on_gpu(product, v, mode):
     if mode == 1 and v["op"] not in ("contains", "starts_with", "is_empty", "len", "eq", "eq_ignore_case",
                                      "to_upper", "to_lower", "find", "lt", "le", "gt", "ge", "replace",
                                      "replacen", "repeat", "trim_start", "trim", "trim_end", "strip_prefix",
-                                     "strip_suffix", "concatenate", "ends_with", "rfind"):
+                                     "strip_suffix", "concatenate", "ends_with", "rfind", "split", "split_inclusive",
+                                     "split_terminator", "split_ascii_whitespace", "splitn", "rsplit",
+                                     "rsplit_once", "rsplitn", "rsplit_terminator"):
         pytest.skip("no fused formulation yet: identical to as-written")
     env = _env(ck, sk)
     if "expected_panic" in v:

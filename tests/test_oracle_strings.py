@@ -10,7 +10,8 @@ VECTORS = load_vectors()
 
 
 def clear_env():
-    ops = ostr.Ops(ClearChar)
+    ops = ostr.SplitOps(ClearChar)
+    ops.trivial_char = lambda v: ClearChar(v)
     enc_s = lambda t, pad: [ClearChar(b) for b in ostr.pad_plain(t, pad)]
     enc_p = lambda t: [ClearChar(b) for b in ostr.pad_plain(t, 0)]
     enc_c = lambda v: ClearChar(v)
