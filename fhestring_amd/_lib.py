@@ -78,6 +78,13 @@ def _declare(L):
     L.fhs_download.restype = i
     L.fhs_export_device.argtypes = [vp, h, vp]
     L.fhs_export_device.restype = i
+    L.fhs_set_arithmetic.argtypes = [vp, i]
+    L.fhs_set_arithmetic.restype = i
+    L.fhs_get_arithmetic.argtypes = [vp]
+    L.fhs_get_arithmetic.restype = i
+    dp = C.POINTER(C.c_double)
+    L.fhs_fft_tables.argtypes = [dp, dp, dp, dp]
+    L.fhs_fft_tables.restype = None
     L.fhs_set_mode.argtypes = [vp, i]
     L.fhs_set_mode.restype = i
     for name in ("contains", "starts_with", "ends_with", "find", "rfind", "eq", "ne", "eq_ignore_case"):
@@ -166,3 +173,13 @@ def _declare(L):
 class Stats(C.Structure):
     _fields_ = [("pbs_executed", C.c_uint64), ("pbs_folded", C.c_uint64), ("levels", C.c_uint64),
                 ("max_level_width", C.c_uint64), ("blocks_live", C.c_uint64)]
+
+
+def fft_tables():
+    """Host-derived twiddle tables of the F64_FFT arithmetic (diagnostic)."""
+    import numpy as np
+    w_re, w_im = np.zeros(1024), np.zeros(1024)
+    u_re, u_im = np.zeros(16), np.zeros(16)
+    dp = C.POINTER(C.c_double)
+    lib().fhs_fft_tables(*(a.ctypes.data_as(dp) for a in (w_re, w_im, u_re, u_im)))
+    return w_re, w_im, u_re, u_im

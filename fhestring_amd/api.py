@@ -45,6 +45,17 @@ class Context:
         if rc != 0:
             raise FhsError("fhs error %d: %s" % (rc, self._L.fhs_last_error(self._h).decode()))
 
+    ARITH_EXACT_NTT = 0
+    ARITH_F64_FFT = 1
+
+    def set_arithmetic(self, arith):
+        """fhs_set_arithmetic: ARITH_EXACT_NTT (default) or ARITH_F64_FFT (select before load_server_key)."""
+        self._check(self._L.fhs_set_arithmetic(self._h, int(arith)))
+
+    @property
+    def arithmetic(self):
+        return int(self._L.fhs_get_arithmetic(self._h))
+
     def load_server_key(self, bsk, ksk):
         bsk = np.ascontiguousarray(bsk, np.uint64)
         ksk = np.ascontiguousarray(ksk, np.uint64)

@@ -1,4 +1,5 @@
 // extern "C" boundary, part 1: context, server key, raw batched PBS (include/fhestring_hip.h).
+#include <algorithm>
 #include <new>
 
 #include "capi_internal.h"
@@ -33,6 +34,21 @@ int fhs_load_server_key(fhs_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) 
     int rc = ctx->eng.ctx.load_server_key(bsk, ksk);
     if (rc) return rc;
     return ctx->eng.on_key_loaded();
+}
+
+int fhs_set_arithmetic(fhs_ctx *ctx, int arith) {
+    if (!ctx) return FHS_ERR_ARG;
+    if (int rc = ctx->eng.flush()) return rc;   // pending work runs in the arithmetic it was built under
+    return ctx->eng.ctx.set_arithmetic(arith);
+}
+int fhs_get_arithmetic(const fhs_ctx *ctx) { return ctx ? ctx->eng.ctx.arith : FHS_ERR_ARG; }
+void fhs_fft_tables(double *w_re, double *w_im, double *u_re, double *u_im) {
+    fhs::HostFftTables t;
+    fhs::build_fft_tables(t);
+    std::copy(t.w_re.begin(), t.w_re.end(), w_re);
+    std::copy(t.w_im.begin(), t.w_im.end(), w_im);
+    std::copy(t.u_re.begin(), t.u_re.end(), u_re);
+    std::copy(t.u_im.begin(), t.u_im.end(), u_im);
 }
 
 int fhs_read_server_key_file(const char *path, std::vector<uint64_t> &bsk, std::vector<uint64_t> &ksk);

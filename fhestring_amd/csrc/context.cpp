@@ -109,6 +109,10 @@ void Context::shutdown() {
     d_colsum4 = nullptr;
     if (d_bsk_ntt) (void)hipFree(d_bsk_ntt);
     if (d_tables) (void)hipFree(d_tables);
+    if (d_bsk_fft) (void)hipFree(d_bsk_fft);
+    if (d_fft_tables) (void)hipFree(d_fft_tables);
+    d_bsk_fft = nullptr;
+    d_fft_tables = nullptr;
     d_ksk = nullptr;
     d_bsk_ntt = nullptr;
     d_tables = nullptr;
@@ -157,7 +161,63 @@ int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
         if (fu != ht.fwd_uni || iu != ht.inv_uni || c != ht.crt_c)
             return fail(-3, "ntt_consts.inc does not match the derived twiddle tables (regenerate it)");
     }
+    if (arith == 1) {
+        const size_t n = (size_t)LWE_N * 4 * POLY_N;   // 1024 complex per polynomial
+        if (!d_bsk_fft) HIP_TRY(hipMalloc(&d_bsk_fft, n * sizeof(double)), "hipMalloc bsk fft");
+        std::vector<double> host(n);
+        unsigned hc = std::thread::hardware_concurrency();
+        convert_bsk_to_fft(bsk, host.data(), (int)std::min(32u, std::max(1u, hc)));
+        HIP_TRY(hipMemcpy(d_bsk_fft, host.data(), n * sizeof(double), hipMemcpyHostToDevice), "copy bsk fft");
+        HostFftTables ft;
+        build_fft_tables(ft);
+        std::vector<double> flat;
+        flat.insert(flat.end(), ft.w_re.begin(), ft.w_re.begin() + 64);
+        flat.insert(flat.end(), ft.w_im.begin(), ft.w_im.begin() + 64);
+        flat.insert(flat.end(), ft.u_re.begin(), ft.u_re.end());
+        flat.insert(flat.end(), ft.u_im.begin(), ft.u_im.end());
+        flat.insert(flat.end(), ft.lanetab.begin(), ft.lanetab.end());
+        if (!d_fft_tables) HIP_TRY(hipMalloc(&d_fft_tables, flat.size() * sizeof(double)), "hipMalloc fft tables");
+        HIP_TRY(hipMemcpy(d_fft_tables, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice),
+                "copy fft tables");
+    } else if (d_bsk_fft) {   // a key loaded in exact mode invalidates an older Fourier-domain key
+        (void)hipFree(d_bsk_fft);
+        d_bsk_fft = nullptr;
+    }
     key_loaded = true;
+    return 0;
+}
+
+int Context::set_arithmetic(int mode) {
+    if (mode != 0 && mode != 1) return fail(-1, "unknown arithmetic mode");
+    if (mode == 1 && key_loaded && !d_bsk_fft)
+        return fail(-3, "select the f64-FFT arithmetic before loading the server key");
+    arith = mode;
+    return 0;
+}
+
+int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const uint64_t *d_luts, uint64_t *d_out,
+                          uint64_t *const *d_out_ptrs, size_t B, hipStream_t s) {
+    hipError_t e;
+    timer.begin(0, B, s);
+    if (arith == 1) {
+        if (!d_bsk_fft) return fail(-3, "Fourier-domain key not loaded");
+        BlindRotateFftParams p{};
+        p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;
+        p.bsk_fft = d_bsk_fft;
+        p.w_re = d_fft_tables; p.w_im = d_fft_tables + 64;
+        p.u_re = d_fft_tables + 128; p.u_im = d_fft_tables + 144;
+        p.lanetab = d_fft_tables + 160;
+        p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
+        e = launch_blind_rotate_fft(p, s);
+    } else {
+        BlindRotateParams p{};
+        p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;
+        p.bsk_ntt = d_bsk_ntt; p.tw = tw; p.crt_c = crt_c;
+        p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
+        e = launch_blind_rotate(p, s);
+    }
+    timer.end(s);
+    if (e != hipSuccess) return hip_fail(e, "blind_rotate launch");
     return 0;
 }
 
@@ -170,18 +230,7 @@ int Context::pbs_batch_device(const uint64_t *d_in, const uint32_t *d_lut_idx, c
     timer.begin(1, B, s);
     HIP_TRY(launch_keyswitch(d_in, d_ksk, d_colsum4, ks_buf.as<uint64_t>(), (int)B, s), "keyswitch launch");
     timer.end(s);
-    BlindRotateParams p{};
-    p.ks = ks_buf.as<uint64_t>();
-    p.lut_idx = d_lut_idx;
-    p.luts = d_luts;
-    p.bsk_ntt = d_bsk_ntt;
-    p.tw = tw;
-    p.crt_c = crt_c;
-    p.out = d_out;
-    p.B = (int)B;
-    timer.begin(0, B, s);
-    HIP_TRY(launch_blind_rotate(p, s), "blind_rotate launch");
-    timer.end(s);
+    if (int rc = blind_rotate(ks_buf.as<uint64_t>(), d_lut_idx, d_luts, d_out, nullptr, B, s)) return rc;
     return 0;
 }
 

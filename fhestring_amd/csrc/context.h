@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#include "fft_tables.h"
 #include "ntt_tables.h"
 #include "pbs_kernels.h"
 
@@ -51,6 +52,16 @@ class Context {
     double *d_tables = nullptr;   // fwd_uni | fwd_lane | inv_uni | inv_lane
     NttTables tw{};
     double crt_c = 0;
+
+    // optional f64-FFT arithmetic (fft_kernels.hip): 0 = exact two-prime NTT (default), 1 = f64 FFT.
+    // Select before load_server_key: the Fourier-domain key is only built when the mode asks for it.
+    int arith = 0;
+    double *d_bsk_fft = nullptr;
+    double *d_fft_tables = nullptr;   // w_re[64] | w_im[64] | u_re[16] | u_im[16] | lanetab[12*64]
+    int set_arithmetic(int mode);
+    // blind rotation in the selected arithmetic (timed as kernel kind 0)
+    int blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const uint64_t *d_luts, uint64_t *d_out,
+                     uint64_t *const *d_out_ptrs, size_t B, hipStream_t s);
 
     // scratch
     DevBuf ks_buf, ms_buf, in_buf, out_buf, lutidx_buf, luts_buf;

@@ -321,20 +321,9 @@ int Engine::exec_level(size_t k, size_t lo, size_t hi, uint64_t *dense_out) {
                          ctx.stream);
     ctx.timer.end(ctx.stream);
     if (e != hipSuccess) return ctx.hip_fail(e, "keyswitch launch");
-    BlindRotateParams p{};
-    p.ks = ctx.ks_buf.as<uint64_t>();
-    p.lut_idx = d_lut;
-    p.luts = d_luts_;
-    p.bsk_ntt = ctx.d_bsk_ntt;
-    p.tw = ctx.tw;
-    p.crt_c = ctx.crt_c;
-    p.out = dense_out;
-    p.out_ptrs = dense_out ? nullptr : d_out;
-    p.B = (int)cnt;
-    ctx.timer.begin(0, cnt, ctx.stream);
-    e = launch_blind_rotate(p, ctx.stream);
-    ctx.timer.end(ctx.stream);
-    if (e != hipSuccess) return ctx.hip_fail(e, "blind_rotate launch");
+    if (int rc = ctx.blind_rotate(ctx.ks_buf.as<uint64_t>(), d_lut, d_luts_, dense_out, dense_out ? nullptr : d_out, cnt,
+                                  ctx.stream))
+        return rc;
     stats.pbs_executed += cnt;
     if (lo == 0 || dense_out) {
         stats.levels += 1;

@@ -45,6 +45,20 @@ struct BlindRotateParams {
     int B;
 };
 
+// Optional f64-FFT arithmetic mode (fft_kernels.hip); same inputs/outputs as BlindRotateParams.
+struct BlindRotateFftParams {
+    const uint64_t *ks;
+    const uint32_t *lut_idx;
+    const uint64_t *luts;
+    const double *bsk_fft;    // [742][row 2][col 2][16][64 lanes][2 re,im], pre-scaled by 1/1024
+    const double *w_re, *w_im;   // [64]  W[0..63] (index 0 unused)
+    const double *u_re, *u_im;   // [16]
+    const double *lanetab;       // [12][64]
+    uint64_t *out;
+    uint64_t *const *out_ptrs;
+    int B;
+};
+
 // One lincomb output: out[dst] = sum_t coef[t] * src[t] + konst * 2^59 (body only)
 struct LinDesc {
     uint32_t first_term;
@@ -59,6 +73,7 @@ struct LinTerm {
 size_t blind_rotate_lds_bytes();
 hipError_t read_device_ntt_consts(double *fwd_uni /*[64]*/, double *inv_uni /*[128]*/, double *crt);
 hipError_t launch_blind_rotate(const BlindRotateParams &p, hipStream_t s);
+hipError_t launch_blind_rotate_fft(const BlindRotateFftParams &p, hipStream_t s);
 hipError_t launch_ksk_colsum(const uint64_t *d_ksk, uint64_t *d_colsum4 /*[743]*/, hipStream_t s);
 hipError_t launch_keyswitch(const uint64_t *d_in /*[B][2049]*/, const uint64_t *d_ksk, const uint64_t *d_colsum4,
                             uint64_t *d_ks_out /*[B][743]*/, int B, hipStream_t s);

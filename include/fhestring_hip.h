@@ -56,6 +56,18 @@ const char *fhs_last_error(const fhs_ctx *ctx);
 /* Copies the key to the device; the BSK is rounded to the 58-bit torus grid and
  * transformed to the device NTT representation (DESIGN.md "BSK precision"). */
 int fhs_load_server_key(fhs_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk);
+/* Arithmetic of the negacyclic products inside blind rotation.  EXACT_NTT (default): exact integer
+ * arithmetic over two 47-bit NTT primes.  F64_FFT: folded f64 complex FFT, the algorithm class of the
+ * reference's CPU engine (tfhe 0.5.2 + concrete-fft 0.4.0, Cargo.lock:168-179) - ~3x faster, approximate
+ * at the 2^-53 relative level (far below the scheme's noise) and deterministic.  Select F64_FFT BEFORE
+ * loading the key (the Fourier-domain key is only built then); switching back to EXACT_NTT is always
+ * allowed. */
+#define FHS_ARITH_EXACT_NTT 0
+#define FHS_ARITH_F64_FFT 1
+int fhs_set_arithmetic(fhs_ctx *ctx, int arith);
+int fhs_get_arithmetic(const fhs_ctx *ctx);
+/* Diagnostic: the host-derived twiddle tables of the F64_FFT mode (W[1024] re/im, U[16] re/im). */
+void fhs_fft_tables(double *w_re, double *w_im, double *u_re, double *u_im);
 
 /* ---- raw batched PBS (the hot path; kernel-level parity tests use these) ----
  * replaces: tfhe::shortint::ServerKey::apply_lookup_table on B blocks.

@@ -74,6 +74,9 @@ def lib():
         L.orc_negacyclic_schoolbook.restype = None
         L.orc_negacyclic_ntt.argtypes = [_i64p, _u64p, _u64p]
         L.orc_negacyclic_ntt.restype = None
+        _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+        L.orc_fft_tables.argtypes = [_f64p, _f64p, _f64p, _f64p]
+        L.orc_fft_tables.restype = None
         _lib = L
     return _lib
 
@@ -164,6 +167,13 @@ class ServerKey:
                             np.ascontiguousarray(luts, np.uint64).reshape(-1, POLY_N), out, B,
                             int(nthreads), mode)
         return out
+
+
+def fft_tables():
+    """Twiddle tables of mode 3 (the mirror of the product's f64-FFT kernel): W[1024] re/im, U[16] re/im."""
+    w_re, w_im, u_re, u_im = np.zeros(1024), np.zeros(1024), np.zeros(16), np.zeros(16)
+    lib().orc_fft_tables(w_re, w_im, u_re, u_im)
+    return w_re, w_im, u_re, u_im
 
 
 def make_lut(f):

@@ -232,12 +232,190 @@ static inline u64 f64_to_torus(double v) {                         /* v mod 2^64
     return (u64)(i64)llrint(v);
 }
 
+/* ---- mode 3: lane-for-lane mirror of the product's f64-FFT blind-rotation kernel ------------------
+ * (fhestring_amd/csrc/fft_kernels.hip).  Folded negacyclic transform: z[n] = x[n] + i x[n+1024],
+ * merged-twist Cooley-Tukey over 1024 complex points, twiddle table
+ *   W[m+i] = exp(i*pi/2048 * (1024/(2m)) * (4*bitrev_log2m(i) + 1)).
+ * The loops below walk (lane, register) exactly like one wavefront does, with the same IEEE-754
+ * operation order (explicit fma, no contraction), so GPU and CPU results are bit-identical.
+ * This is the reference's algorithm CLASS (tfhe + concrete-fft, Cargo.lock:168-179); approximate
+ * w.r.t. the exact modes 0/1 (differences far below the noise), exact w.r.t. the GPU FFT path. */
+#define FM 1024               /* complex points */
+#define FSLOT(n) ((n) + ((n) >> 6))
+static double fW_re[FM], fW_im[FM];          /* W[1..1023] */
+static double fU_re[16], fU_im[16];          /* U[G+g] = exp(i*pi*bitrev(g)/G), G = 2,4,8 */
+static int fmirror_ready = 0;
+static unsigned brev_bits(unsigned x, int bits) {
+    unsigned r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+static void fmirror_init(void) {
+    pthread_mutex_lock(&g_tab_mu);
+    if (!fmirror_ready) {
+        const double PI = 3.14159265358979323846;
+        int d = 0;
+        for (unsigned m = 1; m < FM; m <<= 1, d++)
+            for (unsigned i = 0; i < m; i++) {
+                const double e = (double)((FM / (2 * m)) * (4 * brev_bits(i, d) + 1));   /* exact integer */
+                fW_re[m + i] = cos(PI * e / 2048.0);
+                fW_im[m + i] = sin(PI * e / 2048.0);
+            }
+        for (int G = 2, lg = 1; G <= 8; G <<= 1, lg++)
+            for (int g = 0; g < G; g++) {
+                fU_re[G + g] = cos(PI * (double)brev_bits(g, lg) / (double)G);
+                fU_im[G + g] = sin(PI * (double)brev_bits(g, lg) / (double)G);
+            }
+        fmirror_ready = 1;
+    }
+    pthread_mutex_unlock(&g_tab_mu);
+}
+void orc_fft_tables(double *w_re, double *w_im, double *u_re, double *u_im) {
+    fmirror_init();
+    memcpy(w_re, fW_re, sizeof(fW_re)); memcpy(w_im, fW_im, sizeof(fW_im));
+    memcpy(u_re, fU_re, sizeof(fU_re)); memcpy(u_im, fU_im, sizeof(fU_im));
+}
+#define CMUL(tr, ti, ar, ai, wr, wi) do { const double a_r__ = (ar), a_i__ = (ai), w_r__ = (wr), w_i__ = (wi); \
+    (tr) = fma(-a_i__, w_i__, a_r__ * w_r__); (ti) = fma(a_i__, w_r__, a_r__ * w_i__); } while (0)
+
+/* forward: x[2048] real coefficients (as doubles) -> F[lane][c] complex at array index 16*lane + c */
+static void fmirror_forward(const double *x, double (*Fr)[16], double (*Fi)[16]) {
+    static __thread double zr[64][16], zi[64][16], lr[FM + 16], li[FM + 16];
+    for (int l = 0; l < 64; l++)
+        for (int r = 0; r < 16; r++) { zr[l][r] = x[l + 64 * r]; zi[l][r] = x[l + 64 * r + 1024]; }
+    for (int l = 0; l < 64; l++) {
+        for (int T = 8; T >= 1; T >>= 1) {
+            const int m = 8 / T;
+            for (int i = 0; i < m; i++) {
+                const double wr = fW_re[m + i], wi = fW_im[m + i];
+                for (int r = 2 * i * T; r < 2 * i * T + T; r++) {
+                    double vr, vi;
+                    CMUL(vr, vi, zr[l][r + T], zi[l][r + T], wr, wi);
+                    const double ur = zr[l][r], ui = zi[l][r];
+                    zr[l][r] = ur + vr; zi[l][r] = ui + vi;
+                    zr[l][r + T] = ur - vr; zi[l][r + T] = ui - vi;
+                }
+            }
+        }
+        for (int r = 0; r < 16; r++) { lr[FSLOT(l + 64 * r)] = zr[l][r]; li[FSLOT(l + 64 * r)] = zi[l][r]; }
+    }
+    for (int L = 0; L < 64; L++) {
+        const int q = L & 3, gL = L >> 2;
+        const double war = fW_re[16 + gL], wai = fW_im[16 + gL];
+        const double wbr = fW_re[32 + 2 * gL + (q >> 1)], wbi = fW_im[32 + 2 * gL + (q >> 1)];
+        const double s1 = q < 2 ? 1.0 : -1.0, s2 = (q & 1) ? -1.0 : 1.0;
+        double *yr = Fr[L], *yi = Fi[L];
+        for (int c = 0; c < 16; c++) {
+            const int b = FSLOT(64 * gL + c);               /* members at +16 qq (same 64-block => same pad) */
+            double t2r, t2i, t3r, t3i, tbr, tbi;
+            CMUL(t2r, t2i, lr[b + 32], li[b + 32], war, wai);
+            CMUL(t3r, t3i, lr[b + 48], li[b + 48], war, wai);
+            const double Ar = fma(s1, t2r, lr[b]), Ai = fma(s1, t2i, li[b]);
+            const double Br = fma(s1, t3r, lr[b + 16]), Bi = fma(s1, t3i, li[b + 16]);
+            CMUL(tbr, tbi, Br, Bi, wbr, wbi);
+            yr[c] = fma(s2, tbr, Ar); yi[c] = fma(s2, tbi, Ai);
+        }
+        int lg = 0;
+        for (int t = 8; t >= 1; t >>= 1, lg++) {
+            const int G = 8 / t;
+            const double br_ = fW_re[64 * G + G * L], bi_ = fW_im[64 * G + G * L];
+            for (int g = 0; g < G; g++) {
+                double wr = br_, wi = bi_;
+                if (g) CMUL(wr, wi, br_, bi_, fU_re[G + g], fU_im[G + g]);
+                for (int c = 2 * g * t; c < 2 * g * t + t; c++) {
+                    double vr, vi;
+                    CMUL(vr, vi, yr[c + t], yi[c + t], wr, wi);
+                    const double ur = yr[c], ui = yi[c];
+                    yr[c] = ur + vr; yi[c] = ui + vi;
+                    yr[c + t] = ur - vr; yi[c + t] = ui - vi;
+                }
+            }
+        }
+    }
+}
+/* inverse (unscaled: 1/1024 is folded into the key): T[lane][c] -> x[2048] real coefficients */
+static void fmirror_inverse(double (*Tr)[16], double (*Ti)[16], double *x) {
+    static __thread double lr[FM + 16], li[FM + 16];
+    for (int L = 0; L < 64; L++) {
+        double *yr = Tr[L], *yi = Ti[L];
+        int lg = 3;
+        for (int t = 1; t <= 8; t <<= 1, lg--) {
+            const int G = 8 / t;
+            const double br_ = fW_re[64 * G + G * L], bi_ = fW_im[64 * G + G * L];
+            for (int g = 0; g < G; g++) {
+                double wr = br_, wi = bi_;
+                if (g) CMUL(wr, wi, br_, bi_, fU_re[G + g], fU_im[G + g]);
+                for (int c = 2 * g * t; c < 2 * g * t + t; c++) {
+                    const double ur = yr[c], ui = yi[c], vr = yr[c + t], vi = yi[c + t];
+                    yr[c] = ur + vr; yi[c] = ui + vi;
+                    CMUL(yr[c + t], yi[c + t], ur - vr, ui - vi, wr, -wi);      /* conj twiddle */
+                }
+            }
+        }
+        for (int c = 0; c < 16; c++) { lr[FSLOT(16 * L + c)] = yr[c]; li[FSLOT(16 * L + c)] = yi[c]; }
+    }
+    for (int l = 0; l < 64; l++) {
+        const int q = (l >> 4) & 3, l4 = l & 15;
+        const double s2 = (q & 1) ? -1.0 : 1.0, s1 = q >= 2 ? -1.0 : 1.0;
+        double zr[16], zi[16];
+        for (int r = 0; r < 16; r++) {
+            const int b = FSLOT(64 * r) + l4;
+            const double d01r = fma(s2, lr[b + 16], lr[b]), d01i = fma(s2, li[b + 16], li[b]);
+            const double d23r = fma(s2, lr[b + 48], lr[b + 32]), d23i = fma(s2, li[b + 48], li[b + 32]);
+            double pr = d01r, pi_ = d01i, qr = d23r, qi = d23i;
+            if (q & 1) {
+                CMUL(pr, pi_, d01r, d01i, fW_re[32 + 2 * r], -fW_im[32 + 2 * r]);
+                CMUL(qr, qi, d23r, d23i, fW_re[32 + 2 * r + 1], -fW_im[32 + 2 * r + 1]);
+            }
+            const double hr = fma(s1, qr, pr), hi = fma(s1, qi, pi_);
+            zr[r] = hr; zi[r] = hi;
+            if (q >= 2) CMUL(zr[r], zi[r], hr, hi, fW_re[16 + r], -fW_im[16 + r]);
+        }
+        for (int T = 1; T <= 8; T <<= 1) {
+            const int h = 8 / T;
+            for (int i = 0; i < h; i++) {
+                const double wr = fW_re[h + i], wi = -fW_im[h + i];
+                for (int r = 2 * i * T; r < 2 * i * T + T; r++) {
+                    const double ur = zr[r], ui = zi[r], vr = zr[r + T], vi = zi[r + T];
+                    zr[r] = ur + vr; zi[r] = ui + vi;
+                    CMUL(zr[r + T], zi[r + T], ur - vr, ui - vi, wr, wi);
+                }
+            }
+        }
+        for (int r = 0; r < 16; r++) { x[l + 64 * r] = zr[r]; x[l + 64 * r + 1024] = zi[r]; }
+    }
+}
+/* torus value of an (approximately) integral double of any magnitude < 2^116, mod 2^64 */
+static inline u64 fmirror_to_torus(double v) {
+    const double k = floor(v * 5.421010862427522e-20 + 0.5);                  /* 2^-64 */
+    const double rr = fma(-k, 18446744073709551616.0, v);                     /* in [-2^63, 2^63), exact */
+    const double hi = floor(rr * 2.3283064365386963e-10);                     /* 2^-32 */
+    const double lo = fma(-hi, 4294967296.0, rr);                             /* in [0, 2^32), exact */
+    return ((u64)(i64)(int32_t)hi << 32) + (u64)(uint32_t)lo;
+}
+/* BSK polynomial -> Fourier domain in the kernel's layout [c][lane] (re, im), pre-scaled by 1/1024 */
+static void fmirror_bsk_poly(const u64 *src, double *dst /* [16][64][2] */) {
+    static __thread double x[POLY_N], Fr[64][16], Fi[64][16];
+    for (int n = 0; n < POLY_N; n++) x[n] = (double)(i64)src[n];
+    fmirror_forward(x, Fr, Fi);
+    for (int L = 0; L < 64; L++)
+        for (int c = 0; c < 16; c++) {
+            dst[(c * 64 + L) * 2 + 0] = Fr[L][c] * 0.0009765625;
+            dst[(c * 64 + L) * 2 + 1] = Fi[L][c] * 0.0009765625;
+        }
+}
+void orc_fft_bsk_convert(const u64 *bsk_quantised, double *out /* [742*4][16][64][2] */) {
+    fmirror_init();
+    for (size_t p = 0; p < BSK_POLYS; p++) fmirror_bsk_poly(bsk_quantised + p * POLY_N, out + p * 2 * FM);
+}
+
 /* ---- server key --------------------------------------------------------- */
 typedef struct {
     u64 *bsk;      /* [742][2 rows][2 cols][2048] std domain, quantised to 2^6 */
     u64 *ksk;      /* [2048][5][743]                                          */
     u64 *bsk_ntt;  /* [742][2 rows][2 cols][2 limbs][2048] Goldilocks NTT     */
     double *bsk_fft; /* [742][2 rows][2 cols][1024] complex (re,im): f64-FFT variant (mode 2) */
+    double *bsk_fm;  /* [742][2 rows][2 cols][16][64][2]: mirror of the GPU FFT kernel (mode 3), lazy */
 } orc_server_key;
 
 u64 orc_bsk_words(void) { return BSK_WORDS; }
@@ -340,7 +518,7 @@ orc_server_key *orc_server_key_new(const u64 *bsk, const u64 *ksk) {
 }
 void orc_server_key_free(orc_server_key *k) {
     if (!k) return;
-    free(k->bsk); free(k->ksk); free(k->bsk_ntt); free(k->bsk_fft); free(k);
+    free(k->bsk); free(k->ksk); free(k->bsk_ntt); free(k->bsk_fft); free(k->bsk_fm); free(k);
 }
 
 /* ---- client side (src/client_key.rs:85-106 via RadixClientKey) ---------- */
@@ -458,7 +636,7 @@ static void negacyclic_mac_schoolbook(const i64 *d, const u64 *b, u64 *res) {
 }
 
 /* mode 0: Goldilocks NTT (2 x 29-bit key limbs, exact); mode 1: schoolbook (exact);
- * mode 2: f64 FFT (approximate, CPU-baseline only) */
+ * mode 2: f64 FFT (approximate, CPU-baseline only); mode 3: mirror of the GPU f64-FFT kernel */
 static void blind_rotate(const orc_server_key *k, const u32 *ms, const u64 *lut,
                          u64 *acc /* [2][N] */, int mode) {
     u64 *rot = (u64 *)malloc(POLY_N * sizeof(u64));
@@ -475,7 +653,29 @@ static void blind_rotate(const orc_server_key *k, const u32 *ms, const u64 *lut,
             poly_rotate(acc + c * POLY_N, a, rot);
             for (int n = 0; n < POLY_N; n++) dig[c * POLY_N + n] = pbs_digit(rot[n] - acc[c * POLY_N + n]);
         }
-        if (mode == 2) {
+        if (mode == 3) {
+            static __thread double xx[POLY_N], Fr[2][64][16], Fi[2][64][16], Tr[64][16], Ti[64][16], xo[POLY_N];
+            for (int c = 0; c < 2; c++) {
+                for (int n = 0; n < POLY_N; n++) xx[n] = (double)dig[c * POLY_N + n];
+                fmirror_forward(xx, Fr[c], Fi[c]);
+            }
+            for (int col = 0; col < 2; col++) {
+                /* wave `col` multiplies its own transform first (row = col), then the partner's */
+                const double *bo = k->bsk_fm + ((((size_t)i * 2 + col) * 2 + col)) * 2 * FM;
+                const double *bp = k->bsk_fm + ((((size_t)i * 2 + (1 - col)) * 2 + col)) * 2 * FM;
+                for (int L = 0; L < 64; L++)
+                    for (int c = 0; c < 16; c++) {
+                        const double fr = Fr[col][L][c], fi = Fi[col][L][c], gr = Fr[1 - col][L][c], gi = Fi[1 - col][L][c];
+                        const double b0r = bo[(c * 64 + L) * 2], b0i = bo[(c * 64 + L) * 2 + 1];
+                        const double b1r = bp[(c * 64 + L) * 2], b1i = bp[(c * 64 + L) * 2 + 1];
+                        double rr = fr * b0r; rr = fma(-fi, b0i, rr); rr = fma(gr, b1r, rr); rr = fma(-gi, b1i, rr);
+                        double ii = fr * b0i; ii = fma(fi, b0r, ii); ii = fma(gr, b1i, ii); ii = fma(gi, b1r, ii);
+                        Tr[L][c] = rr; Ti[L][c] = ii;
+                    }
+                fmirror_inverse(Tr, Ti, xo);
+                for (int n = 0; n < POLY_N; n++) acc[col * POLY_N + n] += fmirror_to_torus(xo[n]);
+            }
+        } else if (mode == 2) {
             double dd[POLY_N], dre[2][FFT_N], dim[2][FFT_N], ore[FFT_N], oim[FFT_N], xo[POLY_N];
             for (int c = 0; c < 2; c++) {
                 for (int n = 0; n < POLY_N; n++) dd[n] = (double)dig[c * POLY_N + n];
@@ -529,8 +729,24 @@ static void blind_rotate(const orc_server_key *k, const u32 *ms, const u64 *lut,
     free(rot); free(dig); free(dn); free(tt); free(res);
 }
 
+static void ensure_mode(const orc_server_key *kc, int mode) {
+    orc_server_key *k = (orc_server_key *)kc;
+    if (mode != 3) return;
+    pthread_mutex_lock(&g_tab_mu);
+    const int need = k->bsk_fm == 0;
+    pthread_mutex_unlock(&g_tab_mu);
+    if (need) {
+        double *m = (double *)malloc(BSK_POLYS * 2 * FM * sizeof(double));
+        orc_fft_bsk_convert(k->bsk, m);
+        pthread_mutex_lock(&g_tab_mu);
+        if (!k->bsk_fm) k->bsk_fm = m; else free(m);
+        pthread_mutex_unlock(&g_tab_mu);
+    }
+}
+
 /* one PBS: in big LWE [2049], lut [2048] -> out big LWE [2049] */
 void orc_pbs(const orc_server_key *k, const u64 *in, const u64 *lut, u64 *out, int mode) {
+    ensure_mode(k, mode);
     u32 ms[SMALL_CT];
     orc_keyswitch_modswitch(k, in, ms);
     u64 *acc = (u64 *)malloc(2 * POLY_N * sizeof(u64));
@@ -543,6 +759,7 @@ void orc_pbs(const orc_server_key *k, const u64 *in, const u64 *lut, u64 *out, i
 }
 /* blind rotation only, from given mod-switched values (kernel-level tests) */
 void orc_blind_rotate(const orc_server_key *k, const u32 *ms, const u64 *lut, u64 *acc, int mode) {
+    ensure_mode(k, mode);
     blind_rotate(k, ms, lut, acc, mode);
 }
 
@@ -564,6 +781,7 @@ static void *pbs_worker(void *p) {
 }
 void orc_pbs_batch(const orc_server_key *k, const u64 *in, const u32 *lut_idx, const u64 *luts,
                    u64 *out, u64 B, int nthreads, int mode) {
+    ensure_mode(k, mode);
     volatile u64 next = 0;
     pbs_job job = { k, in, lut_idx, luts, out, B, mode, &next };
     if (nthreads < 1) nthreads = 1;

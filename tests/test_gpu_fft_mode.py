@@ -1,0 +1,93 @@
+"""Optional f64-FFT arithmetic (fhs_set_arithmetic(FHS_ARITH_F64_FFT)): the GPU kernel against the oracle's
+lane-for-lane mirror (mode 3), bit for bit, and against the exact path at the message level."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fft_ctx(oracle_keys):
+    import fhestring_amd
+    ctx = fhestring_amd.Context(0)
+    ctx.set_arithmetic(ctx.ARITH_F64_FFT)
+    ctx.load_server_key(oracle_keys.bsk, oracle_keys.ksk)
+    yield ctx
+    ctx.close()
+
+
+def _inputs(keys, B, seed):
+    rng = np.random.default_rng(seed)
+    msgs = rng.integers(0, 16, B)
+    return msgs, np.stack([keys.encrypt_block(int(m)) for m in msgs])
+
+
+def test_tables_match_oracle(fft_ctx):
+    """Both sides derive the twiddles with the same libm calls; a mismatch would explain any bit difference."""
+    from oracle import core
+    w_re, w_im, u_re, u_im = core.fft_tables()
+    from fhestring_amd._lib import fft_tables
+    t = fft_tables()
+    assert np.array_equal(t[0], w_re) and np.array_equal(t[1], w_im)
+    assert np.array_equal(t[2], u_re) and np.array_equal(t[3], u_im)
+
+
+@pytest.mark.parametrize("B", [1, 5, 32])
+def test_fft_pbs_bit_exact_vs_mirror(fft_ctx, oracle_keys, oracle_sk, B):
+    from oracle import radix
+    msgs, cts = _inputs(oracle_keys, B, 900 + B)
+    names = ["msg", "carry", "eq_biv", "sign", "cmp_le"]
+    luts = np.stack([radix.lut_poly(n) for n in names])
+    idx = (np.arange(B) % len(names)).astype(np.uint32)
+    assert fft_ctx.arithmetic == fft_ctx.ARITH_F64_FFT
+    got = fft_ctx.pbs_batch(cts, idx, luts)
+    want = oracle_sk.pbs_batch(cts, idx, luts, mode=3)
+    assert np.array_equal(got, want)
+    for b in range(B):
+        assert oracle_keys.decrypt_block(got[b]) == radix.lut_eval(names[idx[b]], int(msgs[b]))
+
+
+def test_fft_noise_close_to_exact(fft_ctx, oracle_keys, oracle_sk):
+    """FFT and exact outputs encrypt the same message; their phases differ by far less than Delta/2 = 2^58."""
+    from oracle import radix
+    msgs, cts = _inputs(oracle_keys, 64, 77)
+    luts = radix.lut_poly("msg")[None]
+    idx = np.zeros(64, np.uint32)
+    got = fft_ctx.pbs_batch(cts, idx, luts)
+    fft_ctx.set_arithmetic(fft_ctx.ARITH_EXACT_NTT)
+    exact = fft_ctx.pbs_batch(cts, idx, luts)
+    fft_ctx.set_arithmetic(fft_ctx.ARITH_F64_FFT)
+    assert np.array_equal(exact, oracle_sk.pbs_batch(cts, idx, luts))
+    worst = 0
+    for b in range(64):
+        d = (int(oracle_keys.phase(got[b])) - int(oracle_keys.phase(exact[b]))) & (2**64 - 1)
+        worst = max(worst, min(d, 2**64 - d))
+        assert oracle_keys.decrypt_block(got[b]) == radix.lut_eval("msg", int(msgs[b]))
+    assert worst < 1 << 52, worst
+
+
+def test_fft_mode_string_ops():
+    """End to end through the lazy engine in FFT arithmetic (product client key)."""
+    import fhestring_amd
+    from fhestring_amd.api import MyClientKey, MyServerKey
+    ck = MyClientKey(0xF5E57121)
+    ctx = fhestring_amd.Context(0)
+    ctx.set_arithmetic(ctx.ARITH_F64_FFT)
+    ctx.load_server_key(ck.bsk(), ck.ksk())
+    sk = MyServerKey(ctx)
+    s = ck.encrypt("hello world", 3, None, sk)
+    p = ck.encrypt_no_padding("o w", sk)
+    assert ck.decrypt_char(sk.contains(s, p)) == 1
+    assert ck.decrypt(sk.to_upper(s)) == "HELLO WORLD"
+    assert ck.decrypt_char(sk.find(s, p)) == 4
+    sk.close()
+    ck.close()
+
+
+def test_fft_needs_key_built_for_it(oracle_keys):
+    import fhestring_amd
+    ctx = fhestring_amd.Context(0)
+    ctx.load_server_key(oracle_keys.bsk, oracle_keys.ksk)
+    with pytest.raises(fhestring_amd.FhsError):
+        ctx.set_arithmetic(ctx.ARITH_F64_FFT)
+    ctx.close()

@@ -55,6 +55,26 @@ def test_fft_baseline_variant_decrypts_like_the_exact_path(oracle_keys, oracle_s
         assert min(e, 2**64 - e) < 2**53
 
 
+def test_fft_mirror_mode_decrypts_and_tracks_the_exact_path(oracle_keys, oracle_sk):
+    """mode 3 mirrors the product's optional f64-FFT kernel lane for lane (the GPU test asserts
+    bit-equality with it); here: same plaintexts as the exact path, phase within 2^52 of it."""
+    names = ["msg", "carry", "eq_biv", "sign"]
+    luts = np.stack([radix.lut_poly(n) for n in names])
+    rng = np.random.default_rng(31)
+    msgs = rng.integers(0, 16, 12)
+    idx = (np.arange(12) % 4).astype(np.uint32)
+    cts = np.stack([oracle_keys.encrypt_block(int(m)) for m in msgs])
+    outs = oracle_sk.pbs_batch(cts, idx, luts, mode=3)
+    exact = oracle_sk.pbs_batch(cts, idx, luts, mode=0)
+    for b in range(12):
+        assert oracle_keys.decrypt_block(outs[b]) == radix.lut_eval(names[idx[b]], int(msgs[b]))
+        d = (oracle_keys.phase(outs[b]) - oracle_keys.phase(exact[b])) & (2**64 - 1)
+        assert min(d, 2**64 - d) < 2**52
+    w_re, w_im, u_re, u_im = core.fft_tables()
+    assert abs(w_re[1] - np.cos(np.pi / 4)) < 1e-15 and abs(w_im[1] - np.sin(np.pi / 4)) < 1e-15
+    assert np.allclose(w_re[1:] ** 2 + w_im[1:] ** 2, 1.0, atol=1e-15)
+
+
 def test_negacyclic_padding_bit_rule(oracle_keys, oracle_sk):
     # an input with the padding bit set (v+16) yields -f(v): what lt/le/gt/ge rely on
     lut = radix.lut_poly("sign")

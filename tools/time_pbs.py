@@ -1,4 +1,4 @@
-"""Quick kernel timing: python tools/time_pbs.py [B ...] (GPU box)."""
+"""Quick kernel timing: python tools/time_pbs.py [--fft] [B ...] (GPU box)."""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -7,10 +7,13 @@ from fhestring_amd.api import MyClientKey
 
 ck = MyClientKey(0xF5E57121)
 ctx = fhestring_amd.Context(0)
+args = [a for a in sys.argv[1:] if a != "--fft"]
+if "--fft" in sys.argv:
+    ctx.set_arithmetic(ctx.ARITH_F64_FFT)
 t = time.time(); ctx.load_server_key(ck.bsk(), ck.ksk()); print("key load %.2fs" % (time.time() - t))
 rng = np.random.default_rng(0)
 luts = rng.integers(0, 2**64, (2, 2048), dtype=np.uint64)
-for B in [int(a) for a in sys.argv[1:]] or [64, 512, 1024, 2048]:
+for B in [int(a) for a in args] or [64, 512, 1024, 2048]:
     cts = rng.integers(0, 2**64, (B, 2049), dtype=np.uint64)
     idx = (np.arange(B) % 2).astype(np.uint32)
     ctx.pbs_batch(cts, idx, luts)
