@@ -47,6 +47,8 @@ void fhs_fft_tables(double *w_re, double *w_im, double *u_re, double *u_im) {
     fhs::build_fft_tables(t);
     std::copy(t.w_re.begin(), t.w_re.end(), w_re);
     std::copy(t.w_im.begin(), t.w_im.end(), w_im);
+    std::fill(u_re, u_re + 16, 0.0);
+    std::fill(u_im, u_im + 16, 0.0);
     std::copy(t.u_re.begin(), t.u_re.end(), u_re);
     std::copy(t.u_im.begin(), t.u_im.end(), u_im);
 }

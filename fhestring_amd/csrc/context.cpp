@@ -162,23 +162,28 @@ int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
             return fail(-3, "ntt_consts.inc does not match the derived twiddle tables (regenerate it)");
     }
     if (arith == 1) {
-        const size_t n = (size_t)LWE_N * 4 * POLY_N;   // 1024 complex per polynomial
-        if (!d_bsk_fft) HIP_TRY(hipMalloc(&d_bsk_fft, n * sizeof(double)), "hipMalloc bsk fft");
-        std::vector<double> host(n);
-        unsigned hc = std::thread::hardware_concurrency();
-        convert_bsk_to_fft(bsk, host.data(), (int)std::min(32u, std::max(1u, hc)));
-        HIP_TRY(hipMemcpy(d_bsk_fft, host.data(), n * sizeof(double), hipMemcpyHostToDevice), "copy bsk fft");
         HostFftTables ft;
         build_fft_tables(ft);
-        std::vector<double> flat;
-        flat.insert(flat.end(), ft.w_re.begin(), ft.w_re.begin() + 64);
-        flat.insert(flat.end(), ft.w_im.begin(), ft.w_im.begin() + 64);
-        flat.insert(flat.end(), ft.u_re.begin(), ft.u_re.end());
-        flat.insert(flat.end(), ft.u_im.begin(), ft.u_im.end());
-        flat.insert(flat.end(), ft.lanetab.begin(), ft.lanetab.end());
-        if (!d_fft_tables) HIP_TRY(hipMalloc(&d_fft_tables, flat.size() * sizeof(double)), "hipMalloc fft tables");
-        HIP_TRY(hipMemcpy(d_fft_tables, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice),
+        {   // the kernel's literal twiddles must equal the libm-derived ones
+            double wr[16], wi[16], ur[3], ui[3];
+            fft_uniform_consts(wr, wi, ur, ui);
+            bool ok = true;
+            for (int k = 1; k < 16; k++) ok = ok && wr[k] == ft.w_re[k] && wi[k] == ft.w_im[k];
+            for (int k = 0; k < 3; k++) ok = ok && ur[k] == ft.u_re[k] && ui[k] == ft.u_im[k];
+            if (!ok) return fail(-3, "fft_consts.inc does not match the libm-derived twiddles (regenerate it)");
+        }
+        if (!d_fft_tables) HIP_TRY(hipMalloc(&d_fft_tables, ft.lanetab.size() * sizeof(double)), "hipMalloc fft tables");
+        HIP_TRY(hipMemcpy(d_fft_tables, ft.lanetab.data(), ft.lanetab.size() * sizeof(double), hipMemcpyHostToDevice),
                 "copy fft tables");
+        const size_t n = (size_t)LWE_N * 4 * POLY_N;   // 1024 complex (2048 doubles) per polynomial
+        if (!d_bsk_fft) HIP_TRY(hipMalloc(&d_bsk_fft, n * sizeof(double)), "hipMalloc bsk fft");
+        uint64_t *d_std = nullptr;
+        HIP_TRY(hipMalloc(&d_std, n * sizeof(uint64_t)), "hipMalloc bsk staging");
+        hipError_t e = hipMemcpy(d_std, bsk, n * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = launch_bsk_to_fft(d_std, d_bsk_fft, d_fft_tables, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_std);
+        HIP_TRY(e, "bsk -> Fourier domain");
     } else if (d_bsk_fft) {   // a key loaded in exact mode invalidates an older Fourier-domain key
         (void)hipFree(d_bsk_fft);
         d_bsk_fft = nullptr;
@@ -204,9 +209,7 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
         BlindRotateFftParams p{};
         p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;
         p.bsk_fft = d_bsk_fft;
-        p.w_re = d_fft_tables; p.w_im = d_fft_tables + 64;
-        p.u_re = d_fft_tables + 128; p.u_im = d_fft_tables + 144;
-        p.lanetab = d_fft_tables + 160;
+        p.lanetab = d_fft_tables;
         p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
         e = launch_blind_rotate_fft(p, s);
     } else {

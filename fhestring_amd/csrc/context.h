@@ -57,7 +57,7 @@ class Context {
     // Select before load_server_key: the Fourier-domain key is only built when the mode asks for it.
     int arith = 0;
     double *d_bsk_fft = nullptr;
-    double *d_fft_tables = nullptr;   // w_re[64] | w_im[64] | u_re[16] | u_im[16] | lanetab[12*64]
+    double *d_fft_tables = nullptr;   // lanetab[12][64]
     int set_arithmetic(int mode);
     // blind rotation in the selected arithmetic (timed as kernel kind 0)
     int blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const uint64_t *d_luts, uint64_t *d_out,

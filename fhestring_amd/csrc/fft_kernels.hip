@@ -2,7 +2,7 @@
 //
 // This is the algorithm CLASS the reference's CPU engine uses (tfhe 0.5.2 + concrete-fft 0.4.0,
 // Cargo.lock:168-179): the negacyclic product through a folded 1024-point complex transform
-// (z[n] = x[n] + i x[n+1024]).  It needs ~3.7x fewer FP64 operations than the exact two-prime NTT of
+// (z[n] = x[n] + i x[n+1024]).  It needs ~4x fewer FP64 operations than the exact two-prime NTT of
 // pbs_kernels.hip but is approximate w.r.t. exact integer arithmetic (53-bit mantissa; the error is
 // far below the scheme's noise, like in the reference).  The exact NTT stays the default and the
 // parity anchor; this mode is selected with fhs_set_arithmetic(ctx, FHS_ARITH_F64_FFT).
@@ -10,11 +10,15 @@
 // IEEE-754 operation order, so the GPU output is still checked bit for bit.
 //
 // Mapping: one workgroup of 2 wavefronts per ciphertext, wavefront j owns GLWE polynomial j:
-// 16 complex points per lane in registers, 4 radix-2 stages in the strided layout (lane = n mod 64,
-// lane-uniform twiddles), one transpose through LDS with the two cross-lane stages fused into the
-// transposed read as a radix-4 step, 4 stages in the contiguous layout (lane = n div 16).
+// 16 complex points per lane in registers.  The 10 radix-2 stages run in three register layouts, each
+// with 4 (or 2) of the index bits in the register number so that every butterfly is in-lane:
+//   A  lane = n mod 64,                    reg = n bits 6-9   stages t = 512..64 (lane-uniform twiddles)
+//   B  lane = 4*(n div 64) + (n mod 4),    reg = n bits 2-5   stages t = 32..4
+//   C  lane = n div 16,                    reg = n bits 0-3   stages t = 2, 1
+// with two transposes through LDS per transform (16-byte accesses, slot n + n/16: conflict free).
 // The twist of the negacyclic fold is merged into the twiddle table
-//   W[m+i] = exp(i*pi/2048 * (1024/2m) * (4*bitrev(i) + 1))     (host: fft_tables.cpp).
+//   W[m+i] = exp(i*pi/2048 * (1024/2m) * (4*bitrev(i) + 1))     (host: fft_tables.cpp)
+// and W[m+i+1] = i * W[m+i] (i even) is applied as a free rotation instead of a second twiddle.
 #include "pbs_kernels.h"
 
 namespace fhs {
@@ -23,9 +27,10 @@ namespace fhs {
 
 namespace {
 
+#include "fft_consts.inc"
+
 constexpr int FM = 1024;                       // complex points
-constexpr int FFT_LDS_DOUBLES = 2176;          // per wave: 1040 complex slots used (same 17 408 B as the NTT path)
-__device__ __forceinline__ int fslot(int n) { return n + (n >> 6); }   // complex slot, 1 pad per 64
+constexpr int FFT_LDS_DOUBLES = 2176;          // per wave: 1088 complex slots (same 17 408 B as the NTT path)
 
 struct cplx { double r, i; };
 __device__ __forceinline__ cplx cmul(cplx a, double wr, double wi) {
@@ -34,170 +39,161 @@ __device__ __forceinline__ cplx cmul(cplx a, double wr, double wi) {
     t.i = __builtin_fma(a.i, wr, a.r * wi);
     return t;
 }
-__device__ __forceinline__ double bcast(double v, int k) {
-    const uint64_t b = __builtin_bit_cast(uint64_t, v);
-    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)b, k);
-    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), k);
-    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
-}
 __device__ __forceinline__ uint32_t fft_mod_switch(uint64_t x) { return (uint32_t)(((x + (1ull << 51)) >> 52) & 4095u); }
 
-// lane-distributed uniform constants: twWr/twWi lane k = Re/Im W[k] (k < 64); twU lanes 0..15 = Re U[k],
-// lanes 16..31 = Im U[k-16]
-#define W_RE(k) bcast(twWr, (k))
-#define W_IM(k) bcast(twWi, (k))
-#define U_RE(k) bcast(twU, (k))
-#define U_IM(k) bcast(twU, 16 + (k))
+// Cooley-Tukey butterfly (forward): (a, b) <- (a + w' b, a - w' b), w' = w or i*w (ROT)
+template <bool ROT> __device__ __forceinline__ void bf_fwd(cplx &a, cplx &b, double wr, double wi) {
+    const cplx p = cmul(b, wr, wi);
+    const cplx u = a;
+    if (!ROT) { a.r = u.r + p.r; a.i = u.i + p.i; b.r = u.r - p.r; b.i = u.i - p.i; }
+    else      { a.r = u.r - p.i; a.i = u.i + p.r; b.r = u.r + p.i; b.i = u.i - p.r; }
+}
+// Gentleman-Sande butterfly (inverse): (a, b) <- (a + b, (a - b) conj(w')), w' = w or i*w (ROT)
+template <bool ROT> __device__ __forceinline__ void bf_inv(cplx &a, cplx &b, double wr, double wi) {
+    const cplx u = a, v = b;
+    a.r = u.r + v.r; a.i = u.i + v.i;
+    cplx d; d.r = u.r - v.r; d.i = u.i - v.i;
+    const cplx q = cmul(d, wr, -wi);
+    if (!ROT) b = q;
+    else { b.r = q.i; b.i = -q.r; }
+}
 
-// forward: z[r] = point (lane + 64 r)  ->  z[c] = value at array index 16*lane + c
-__device__ __forceinline__ void fft_forward(cplx (&z)[16], double *lds, int lane, double twWr, double twWi, double twU,
-                                            const double *__restrict__ lanetab /* [12][64] */) {
-    // per-lane constants (L1-resident table): fused-stage twiddles and the 4 in-lane bases
-    const double war = lanetab[0 * 64 + lane], wai = lanetab[1 * 64 + lane];
-    const double wbr = lanetab[2 * 64 + lane], wbi = lanetab[3 * 64 + lane];
-    double bre[4], bim[4];
+// the 4 lane-uniform stages of layout A (twiddles are scalar immediates)
+template <bool INV> __device__ __forceinline__ void stages_uniform(cplx (&z)[16]) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) { bre[k] = lanetab[(4 + 2 * k) * 64 + lane]; bim[k] = lanetab[(5 + 2 * k) * 64 + lane]; }
-#pragma unroll
-    for (int T = 8; T >= 1; T >>= 1) {
+    for (int s = 0; s < 4; s++) {
+        const int T = INV ? (1 << s) : (8 >> s);
         const int m = 8 / T;
 #pragma unroll
         for (int i = 0; i < m; i++) {
-            const double wr = W_RE(m + i), wi = W_IM(m + i);
+            const int k = m == 1 ? 1 : ((m + i) & ~1);     // W[1] for m = 1, else the even index
+            const double wr = FW_RE[k], wi = FW_IM[k];
 #pragma unroll
             for (int r = 2 * i * T; r < 2 * i * T + T; r++) {
-                const cplx v = cmul(z[r + T], wr, wi);
-                const cplx u = z[r];
-                z[r].r = u.r + v.r; z[r].i = u.i + v.i;
-                z[r + T].r = u.r - v.r; z[r + T].i = u.i - v.i;
+                if (i & 1) { if (INV) bf_inv<true>(z[r], z[r + T], wr, wi); else bf_fwd<true>(z[r], z[r + T], wr, wi); }
+                else       { if (INV) bf_inv<false>(z[r], z[r + T], wr, wi); else bf_fwd<false>(z[r], z[r + T], wr, wi); }
             }
         }
     }
-    {   // fslot(lane + 64 r) == lane + 65 r
-        cplx *wr_ = reinterpret_cast<cplx *>(lds) + lane;
+}
+
+// one in-lane stage of layout B or C: register distance TAU, G = 8/TAU twiddle groups,
+// twiddle of group g = per-lane base * U_G[g] (g even), rotated by i for odd g
+template <bool INV, int TAU> __device__ __forceinline__ void stage_lane(cplx (&z)[16], double br, double bi) {
+    constexpr int G = 8 / TAU;
 #pragma unroll
-        for (int r = 0; r < 16; r++) wr_[65 * r] = z[r];
+    for (int g = 0; g < G; g += 2) {
+        double wr = br, wi = bi;
+        if (g) {
+            // U_G[g] = exp(i*pi*bitrev(g)/G): G=4: g=2 -> pi/4;  G=8: g=2 -> pi/4, g=4 -> pi/8, g=6 -> 3pi/8
+            const int u = (G == 8 && g == 4) ? 1 : (G == 8 && g == 6) ? 2 : 0;
+            cplx b; b.r = br; b.i = bi;
+            const cplx w = cmul(b, FU_RE[u], FU_IM[u]);
+            wr = w.r; wi = w.i;
+        }
+#pragma unroll
+        for (int c = 2 * g * TAU; c < 2 * g * TAU + TAU; c++) {
+            if (INV) bf_inv<false>(z[c], z[c + TAU], wr, wi); else bf_fwd<false>(z[c], z[c + TAU], wr, wi);
+        }
+        if (G > 1) {
+#pragma unroll
+            for (int c = 2 * (g + 1) * TAU; c < 2 * (g + 1) * TAU + TAU; c++) {
+                if (INV) bf_inv<true>(z[c], z[c + TAU], wr, wi); else bf_fwd<true>(z[c], z[c + TAU], wr, wi);
+            }
+        }
+    }
+}
+
+// LDS slots (16-byte complex): point n lives at n + (n >> 4)
+//   layout A: lane + (lane >> 4) + 68 r          layout B: 68 hi + lo + 4 rho + (rho >> 2)        layout C: 17 lane + c
+__device__ __forceinline__ cplx *slotA(double *lds, int lane) { return reinterpret_cast<cplx *>(lds) + lane + (lane >> 4); }
+__device__ __forceinline__ cplx *slotB(double *lds, int lane) { return reinterpret_cast<cplx *>(lds) + 68 * (lane >> 2) + (lane & 3); }
+__device__ __forceinline__ cplx *slotC(double *lds, int lane) { return reinterpret_cast<cplx *>(lds) + 17 * lane; }
+
+// per-lane twiddle bases: rows (re, im) x {B: G=1,2,4,8; C: G=4,8}
+struct LaneTw { double re[6], im[6]; };
+__device__ __forceinline__ void load_lane_tw(LaneTw &t, const double *__restrict__ lanetab, int lane) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) { t.re[k] = lanetab[(2 * k) * 64 + lane]; t.im[k] = lanetab[(2 * k + 1) * 64 + lane]; }
+}
+
+// forward: z[r] = point (lane + 64 r)  ->  z[c] = value at array index 16*lane + c
+__device__ __forceinline__ void fft_forward(cplx (&z)[16], double *lds, int lane, const LaneTw &tw) {
+    stages_uniform<false>(z);
+    {
+        cplx *w = slotA(lds, lane);
+#pragma unroll
+        for (int r = 0; r < 16; r++) w[68 * r] = z[r];
     }
     __builtin_amdgcn_wave_barrier();
     {
-        const int q = lane & 3, gL = lane >> 2;
-        const double s1 = q < 2 ? 1.0 : -1.0, s2 = (q & 1) ? -1.0 : 1.0;
-        const cplx *rd = reinterpret_cast<const cplx *>(lds) + 65 * gL;   // fslot(64 gL + c) == 65 gL + c
+        const cplx *rd = slotB(lds, lane);
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const cplx e0 = rd[c], e1 = rd[c + 16], e2 = rd[c + 32], e3 = rd[c + 48];
-            const cplx t2 = cmul(e2, war, wai), t3 = cmul(e3, war, wai);
-            cplx A, Bv;
-            A.r = __builtin_fma(s1, t2.r, e0.r); A.i = __builtin_fma(s1, t2.i, e0.i);
-            Bv.r = __builtin_fma(s1, t3.r, e1.r); Bv.i = __builtin_fma(s1, t3.i, e1.i);
-            const cplx tb = cmul(Bv, wbr, wbi);
-            z[c].r = __builtin_fma(s2, tb.r, A.r);
-            z[c].i = __builtin_fma(s2, tb.i, A.i);
-        }
+        for (int p = 0; p < 16; p++) z[p] = rd[4 * p + (p >> 2)];
     }
     __builtin_amdgcn_wave_barrier();
-    int lg = 0;
+    stage_lane<false, 8>(z, tw.re[0], tw.im[0]);
+    stage_lane<false, 4>(z, tw.re[1], tw.im[1]);
+    stage_lane<false, 2>(z, tw.re[2], tw.im[2]);
+    stage_lane<false, 1>(z, tw.re[3], tw.im[3]);
+    {
+        cplx *w = slotB(lds, lane);
 #pragma unroll
-    for (int t = 8; t >= 1; t >>= 1, lg++) {
-        const int G = 8 / t;
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            double wr = bre[lg], wi = bim[lg];
-            if (g) {
-                cplx b; b.r = bre[lg]; b.i = bim[lg];
-                const cplx w = cmul(b, U_RE(G + g), U_IM(G + g));
-                wr = w.r; wi = w.i;
-            }
-#pragma unroll
-            for (int c = 2 * g * t; c < 2 * g * t + t; c++) {
-                const cplx v = cmul(z[c + t], wr, wi);
-                const cplx u = z[c];
-                z[c].r = u.r + v.r; z[c].i = u.i + v.i;
-                z[c + t].r = u.r - v.r; z[c + t].i = u.i - v.i;
-            }
-        }
+        for (int p = 0; p < 16; p++) w[4 * p + (p >> 2)] = z[p];
     }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const cplx *rd = slotC(lds, lane);
+#pragma unroll
+        for (int c = 0; c < 16; c++) z[c] = rd[c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    stage_lane<false, 2>(z, tw.re[4], tw.im[4]);
+    stage_lane<false, 1>(z, tw.re[5], tw.im[5]);
 }
 
 // inverse (unscaled): z[c] at array index 16*lane + c  ->  z[r] = point (lane + 64 r)
-__device__ __forceinline__ void fft_inverse(cplx (&z)[16], double *lds, int lane, double twWr, double twWi, double twU,
-                                            const double *__restrict__ lanetab) {
-    double bre[4], bim[4];
+__device__ __forceinline__ void fft_inverse(cplx (&z)[16], double *lds, int lane, const LaneTw &tw) {
+    stage_lane<true, 1>(z, tw.re[5], tw.im[5]);
+    stage_lane<true, 2>(z, tw.re[4], tw.im[4]);
+    {
+        cplx *w = slotC(lds, lane);
 #pragma unroll
-    for (int k = 0; k < 4; k++) { bre[k] = lanetab[(4 + 2 * k) * 64 + lane]; bim[k] = lanetab[(5 + 2 * k) * 64 + lane]; }
-    int lg = 3;
-#pragma unroll
-    for (int t = 1; t <= 8; t <<= 1, lg--) {
-        const int G = 8 / t;
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            double wr = bre[lg], wi = bim[lg];
-            if (g) {
-                cplx b; b.r = bre[lg]; b.i = bim[lg];
-                const cplx w = cmul(b, U_RE(G + g), U_IM(G + g));
-                wr = w.r; wi = w.i;
-            }
-#pragma unroll
-            for (int c = 2 * g * t; c < 2 * g * t + t; c++) {
-                const cplx u = z[c], v = z[c + t];
-                z[c].r = u.r + v.r; z[c].i = u.i + v.i;
-                cplx d; d.r = u.r - v.r; d.i = u.i - v.i;
-                z[c + t] = cmul(d, wr, -wi);                       // conjugate twiddle
-            }
-        }
-    }
-    {   // fslot(16 lane + c) == 16 lane + c + (lane >> 2)
-        cplx *wr_ = reinterpret_cast<cplx *>(lds) + 16 * lane + (lane >> 2);
-#pragma unroll
-        for (int c = 0; c < 16; c++) wr_[c] = z[c];
+        for (int c = 0; c < 16; c++) w[c] = z[c];
     }
     __builtin_amdgcn_wave_barrier();
     {
-        const int q = (lane >> 4) & 3, l4 = lane & 15;
-        const bool odd = q & 1, upper = q >= 2;
-        const double s2 = odd ? -1.0 : 1.0, s1 = upper ? -1.0 : 1.0;
-        const cplx *rd = reinterpret_cast<const cplx *>(lds) + l4;   // fslot(64 r) + l4 == 65 r + l4
+        const cplx *rd = slotB(lds, lane);
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const cplx e0 = rd[65 * r], e1 = rd[65 * r + 16], e2 = rd[65 * r + 32], e3 = rd[65 * r + 48];
-            cplx d01, d23;
-            d01.r = __builtin_fma(s2, e1.r, e0.r); d01.i = __builtin_fma(s2, e1.i, e0.i);
-            d23.r = __builtin_fma(s2, e3.r, e2.r); d23.i = __builtin_fma(s2, e3.i, e2.i);
-            // twiddles stay scalar (readlane); lanes that take the sum branch keep the untwiddled value
-            const cplx p1 = cmul(d01, W_RE(32 + 2 * r), -W_IM(32 + 2 * r));
-            const cplx q1 = cmul(d23, W_RE(32 + 2 * r + 1), -W_IM(32 + 2 * r + 1));
-            const cplx p = odd ? p1 : d01, qv = odd ? q1 : d23;
-            cplx h;
-            h.r = __builtin_fma(s1, qv.r, p.r); h.i = __builtin_fma(s1, qv.i, p.i);
-            const cplx h1 = cmul(h, W_RE(16 + r), -W_IM(16 + r));
-            z[r] = upper ? h1 : h;
-        }
+        for (int p = 0; p < 16; p++) z[p] = rd[4 * p + (p >> 2)];
     }
     __builtin_amdgcn_wave_barrier();
+    stage_lane<true, 1>(z, tw.re[3], tw.im[3]);
+    stage_lane<true, 2>(z, tw.re[2], tw.im[2]);
+    stage_lane<true, 4>(z, tw.re[1], tw.im[1]);
+    stage_lane<true, 8>(z, tw.re[0], tw.im[0]);
+    {
+        cplx *w = slotB(lds, lane);
 #pragma unroll
-    for (int T = 1; T <= 8; T <<= 1) {
-        const int h = 8 / T;
-#pragma unroll
-        for (int i = 0; i < h; i++) {
-            const double wr = W_RE(h + i), wi = -W_IM(h + i);
-#pragma unroll
-            for (int r = 2 * i * T; r < 2 * i * T + T; r++) {
-                const cplx u = z[r], v = z[r + T];
-                z[r].r = u.r + v.r; z[r].i = u.i + v.i;
-                cplx d; d.r = u.r - v.r; d.i = u.i - v.i;
-                z[r + T] = cmul(d, wr, wi);
-            }
-        }
+        for (int p = 0; p < 16; p++) w[4 * p + (p >> 2)] = z[p];
     }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const cplx *rd = slotA(lds, lane);
+#pragma unroll
+        for (int r = 0; r < 16; r++) z[r] = rd[68 * r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    stages_uniform<true>(z);
 }
 
-// torus value (mod 2^64) of an approximately integral double of any magnitude
+// floor(v) mod 2^64 of a double of any magnitude (v is integral whenever |v| >= 2^52)
 __device__ __forceinline__ uint64_t to_torus(double v) {
-    const double k = __builtin_floor(v * 5.421010862427522e-20 + 0.5);           // 2^-64
-    const double rr = __builtin_fma(-k, 18446744073709551616.0, v);              // in [-2^63, 2^63), exact
-    const double hi = __builtin_floor(rr * 2.3283064365386963e-10);              // 2^-32
-    const double lo = __builtin_fma(-hi, 4294967296.0, rr);                      // in [0, 2^32), exact
-    return ((uint64_t)(int64_t)(int32_t)hi << 32) + (uint64_t)(uint32_t)lo;
+    const double f = __builtin_amdgcn_fract(v * 0x1p-64);      // in [0, 1), exact (clamped below 1)
+    const double h = f * 0x1p32;                               // exact
+    const uint32_t hi = (uint32_t)h;                           // truncation = floor
+    const uint32_t lo = (uint32_t)(__builtin_amdgcn_fract(h) * 0x1p32);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 }  // namespace
@@ -212,8 +208,6 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
     uint64_t *my_u = reinterpret_cast<uint64_t *>(my);
 
     const uint64_t *ks = P.ks + (size_t)ct * SMALL_CT;
-    const double twWr = P.w_re[lane], twWi = P.w_im[lane];
-    const double twU = lane < 16 ? P.u_re[lane] : P.u_im[(lane - 16) & 15];
 
     // acc[r] = coefficient (lane + 64 r) of polynomial j (u64 torus); registers r and r+16 form one complex point
     uint64_t acc[32];
@@ -228,8 +222,8 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
             uint64_t v = 0;
             if (j == 1) {
                 const uint32_t n = lane + 64 * r;
-                v = (n >= s) ? lut[n - s] : (uint64_t)0 - lut[n - s + POLY_N];
-                if (neg) v = (uint64_t)0 - v;
+                v = lut[(n - s) & (POLY_N - 1)];
+                if ((n < s) != neg) v = (uint64_t)0 - v;
             }
             acc[r] = v;
         }
@@ -240,6 +234,11 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
         if (a == 0) continue;
         const uint32_t s = a & (POLY_N - 1);
         const bool neg = a >= POLY_N;
+
+        // keep the (loop-invariant) per-lane twiddle loads inside the iteration: 24 registers that are only
+        // live while a transform runs instead of across the whole loop
+        const double *lanetab = P.lanetab;
+        asm volatile("" : "+s"(lanetab));
 
         // rotate, subtract, decompose; fold: z[r] = digit[r] + i * digit[r + 16]
         cplx z[16];
@@ -258,16 +257,23 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
         }
         __builtin_amdgcn_wave_barrier();
 
-        fft_forward(z, my, lane, twWr, twWi, twU, P.lanetab);
-
-        // publish, pointwise: own transform first (row j), then the partner's (row 1-j); column j
+        // Key rows for this iteration: own transform first (row j), then the partner's (row 1-j); column j.
+        // The first HB of the 16 per-lane points are requested before the transform; the others take over
+        // each register pair as it is consumed.
         typedef double __attribute__((ext_vector_type(2))) double2_t;
         const double2_t *b_own = reinterpret_cast<const double2_t *>(P.bsk_fft) + ((((size_t)i * 2 + j) * 2 + j)) * FM + lane;
         const double2_t *b_par = reinterpret_cast<const double2_t *>(P.bsk_fft) + ((((size_t)i * 2 + (1 - j)) * 2 + j)) * FM + lane;
-        constexpr int CH = 2;
-        double2_t bo[CH], bp[CH];
+        constexpr int HB = 4;
+        double2_t bo[HB], bp[HB];
 #pragma unroll
-        for (int k = 0; k < CH; k++) { bo[k] = b_own[k * 64]; bp[k] = b_par[k * 64]; }
+        for (int k = 0; k < HB; k++) { bo[k] = b_own[k * 64]; bp[k] = b_par[k * 64]; }
+
+        {
+            LaneTw tw;
+            load_lane_tw(tw, lanetab, lane);
+            fft_forward(z, my, lane, tw);
+        }
+
         {
             cplx *pub = reinterpret_cast<cplx *>(my) + lane;
 #pragma unroll
@@ -277,32 +283,27 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
         {
             const cplx *par = reinterpret_cast<const cplx *>(partner) + lane;
 #pragma unroll
-            for (int ch = 0; ch < 16 / CH; ch++) {
-                double2_t no[CH], np[CH];
-                if (ch + 1 < 16 / CH) {
-#pragma unroll
-                    for (int k = 0; k < CH; k++) { no[k] = b_own[((ch + 1) * CH + k) * 64]; np[k] = b_par[((ch + 1) * CH + k) * 64]; }
-                }
-#pragma unroll
-                for (int k = 0; k < CH; k++) {
-                    const int c = ch * CH + k;
-                    const cplx g = par[c * 64];
-                    const double fr = z[c].r, fi = z[c].i;
-                    double rr = fr * bo[k].x; rr = __builtin_fma(-fi, bo[k].y, rr);
-                    rr = __builtin_fma(g.r, bp[k].x, rr); rr = __builtin_fma(-g.i, bp[k].y, rr);
-                    double ii = fr * bo[k].y; ii = __builtin_fma(fi, bo[k].x, ii);
-                    ii = __builtin_fma(g.r, bp[k].y, ii); ii = __builtin_fma(g.i, bp[k].x, ii);
-                    z[c].r = rr; z[c].i = ii;
-                }
-                if (ch + 1 < 16 / CH) {
-#pragma unroll
-                    for (int k = 0; k < CH; k++) { bo[k] = no[k]; bp[k] = np[k]; }
-                }
+            for (int c = 0; c < 16; c++) {
+                const int k = c % HB;
+                const cplx g = par[c * 64];
+                const double fr = z[c].r, fi = z[c].i;
+                double rr = fr * bo[k].x; rr = __builtin_fma(-fi, bo[k].y, rr);
+                rr = __builtin_fma(g.r, bp[k].x, rr); rr = __builtin_fma(-g.i, bp[k].y, rr);
+                double ii = fr * bo[k].y; ii = __builtin_fma(fi, bo[k].x, ii);
+                ii = __builtin_fma(g.r, bp[k].y, ii); ii = __builtin_fma(g.i, bp[k].x, ii);
+                z[c].r = rr; z[c].i = ii;
+                if (c + HB < 16) { bo[k] = b_own[(c + HB) * 64]; bp[k] = b_par[(c + HB) * 64]; }
             }
         }
         __syncthreads();
 
-        fft_inverse(z, my, lane, twWr, twWi, twU, P.lanetab);
+        {   // reloaded rather than kept live across the pointwise phase
+            const double *lanetab2 = P.lanetab;
+            asm volatile("" : "+s"(lanetab2));
+            LaneTw tw2;
+            load_lane_tw(tw2, lanetab2, lane);
+            fft_inverse(z, my, lane, tw2);
+        }
 
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -324,10 +325,49 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
     }
 }
 
+// Bootstrapping key -> Fourier domain with the device's own forward transform: one wavefront per polynomial.
+// in: [742*4][2048] u64 standard domain;  out: [742*4][16][64 lanes][2], pre-scaled by 1/1024
+__global__ __launch_bounds__(64) void bsk_to_fft_kernel(const uint64_t *__restrict__ bsk_std, double *__restrict__ out,
+                                                        const double *__restrict__ lanetab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const uint64_t *src = bsk_std + (size_t)blockIdx.x * POLY_N;
+    cplx z[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        // round to the 58-bit torus grid (same rounding as the exact path), signed representative
+        const uint64_t q0 = (src[lane + 64 * r] + (1ull << (BSK_QUANT_BITS - 1))) & ~((1ull << BSK_QUANT_BITS) - 1);
+        const uint64_t q1 = (src[lane + 64 * r + 1024] + (1ull << (BSK_QUANT_BITS - 1))) & ~((1ull << BSK_QUANT_BITS) - 1);
+        // 58 significant bits -> split so that both halves convert exactly, one rounding in the add
+        z[r].r = (double)(int32_t)(q0 >> 32) * 0x1p32 + (double)(uint32_t)q0;
+        z[r].i = (double)(int32_t)(q1 >> 32) * 0x1p32 + (double)(uint32_t)q1;
+    }
+    LaneTw tw;
+    load_lane_tw(tw, lanetab, lane);
+    fft_forward(z, reinterpret_cast<double *>(smem), lane, tw);
+    double *dst = out + (size_t)blockIdx.x * 2 * FM;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        dst[(c * 64 + lane) * 2 + 0] = z[c].r * 0x1p-10;
+        dst[(c * 64 + lane) * 2 + 1] = z[c].i * 0x1p-10;
+    }
+}
+
+void fft_uniform_consts(double *w_re, double *w_im, double *u_re, double *u_im) {
+    for (int k = 0; k < 16; k++) { w_re[k] = FW_RE[k]; w_im[k] = FW_IM[k]; }
+    for (int k = 0; k < 3; k++) { u_re[k] = FU_RE[k]; u_im[k] = FU_IM[k]; }
+}
+
 hipError_t launch_blind_rotate_fft(const BlindRotateFftParams &p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     const size_t lds = (size_t)2 * FFT_LDS_DOUBLES * sizeof(double);
     hipLaunchKernelGGL(blind_rotate_fft_kernel, dim3(p.B), dim3(128), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_bsk_to_fft(const uint64_t *d_bsk_std, double *d_out, const double *d_lanetab, hipStream_t s) {
+    const size_t lds = (size_t)FFT_LDS_DOUBLES * sizeof(double);
+    hipLaunchKernelGGL(bsk_to_fft_kernel, dim3(LWE_N * 4), dim3(64), lds, s, d_bsk_std, d_out, d_lanetab);
     return hipGetLastError();
 }
 

@@ -51,9 +51,7 @@ struct BlindRotateFftParams {
     const uint32_t *lut_idx;
     const uint64_t *luts;
     const double *bsk_fft;    // [742][row 2][col 2][16][64 lanes][2 re,im], pre-scaled by 1/1024
-    const double *w_re, *w_im;   // [64]  W[0..63] (index 0 unused)
-    const double *u_re, *u_im;   // [16]
-    const double *lanetab;       // [12][64]
+    const double *lanetab;    // [12][64] per-lane twiddle bases (fft_tables.cpp)
     uint64_t *out;
     uint64_t *const *out_ptrs;
     int B;
@@ -74,6 +72,10 @@ size_t blind_rotate_lds_bytes();
 hipError_t read_device_ntt_consts(double *fwd_uni /*[64]*/, double *inv_uni /*[128]*/, double *crt);
 hipError_t launch_blind_rotate(const BlindRotateParams &p, hipStream_t s);
 hipError_t launch_blind_rotate_fft(const BlindRotateFftParams &p, hipStream_t s);
+// standard-domain key [742*4][2048] u64 -> Fourier-domain key, with the device's own forward transform
+hipError_t launch_bsk_to_fft(const uint64_t *d_bsk_std, double *d_out, const double *d_lanetab, hipStream_t s);
+// the scalar twiddle literals baked into fft_kernels.hip: W[16] (index 1 and even indices used), U[3]
+void fft_uniform_consts(double *w_re, double *w_im, double *u_re, double *u_im);
 hipError_t launch_ksk_colsum(const uint64_t *d_ksk, uint64_t *d_colsum4 /*[743]*/, hipStream_t s);
 hipError_t launch_keyswitch(const uint64_t *d_in /*[B][2049]*/, const uint64_t *d_ksk, const uint64_t *d_colsum4,
                             uint64_t *d_ks_out /*[B][743]*/, int B, hipStream_t s);

@@ -66,7 +66,7 @@ int fhs_load_server_key(fhs_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk);
 #define FHS_ARITH_F64_FFT 1
 int fhs_set_arithmetic(fhs_ctx *ctx, int arith);
 int fhs_get_arithmetic(const fhs_ctx *ctx);
-/* Diagnostic: the host-derived twiddle tables of the F64_FFT mode (W[1024] re/im, U[16] re/im). */
+/* Diagnostic: the host-derived twiddle tables of the F64_FFT mode (W[1024] re/im; U[16] re/im, 3 used). */
 void fhs_fft_tables(double *w_re, double *w_im, double *u_re, double *u_im);
 
 /* ---- raw batched PBS (the hot path; kernel-level parity tests use these) ----

@@ -235,15 +235,19 @@ static inline u64 f64_to_torus(double v) {                         /* v mod 2^64
 /* ---- mode 3: lane-for-lane mirror of the product's f64-FFT blind-rotation kernel ------------------
  * (fhestring_amd/csrc/fft_kernels.hip).  Folded negacyclic transform: z[n] = x[n] + i x[n+1024],
  * merged-twist Cooley-Tukey over 1024 complex points, twiddle table
- *   W[m+i] = exp(i*pi/2048 * (1024/(2m)) * (4*bitrev_log2m(i) + 1)).
+ *   W[m+i] = exp(i*pi/2048 * (1024/(2m)) * (4*bitrev_log2m(i) + 1)),
+ * W[m+i+1] = i*W[m+i] (i even) applied as an exact rotation.  The 10 radix-2 stages run in three
+ * register layouts (lane, reg) <-> point n, as on the GPU:
+ *   A  n = lane + 64 reg                          stages t = 512..64 (lane-uniform twiddles)
+ *   B  n = 64 (lane >> 2) + 4 reg + (lane & 3)    stages t = 32..4   (per-lane base * U)
+ *   C  n = 16 lane + reg                          stages t = 2, 1    (per-lane base * U)
  * The loops below walk (lane, register) exactly like one wavefront does, with the same IEEE-754
  * operation order (explicit fma, no contraction), so GPU and CPU results are bit-identical.
  * This is the reference's algorithm CLASS (tfhe + concrete-fft, Cargo.lock:168-179); approximate
  * w.r.t. the exact modes 0/1 (differences far below the noise), exact w.r.t. the GPU FFT path. */
 #define FM 1024               /* complex points */
-#define FSLOT(n) ((n) + ((n) >> 6))
 static double fW_re[FM], fW_im[FM];          /* W[1..1023] */
-static double fU_re[16], fU_im[16];          /* U[G+g] = exp(i*pi*bitrev(g)/G), G = 2,4,8 */
+static double fU_re[3], fU_im[3];            /* exp(i*pi/4), exp(i*pi/8), exp(3i*pi/8) */
 static int fmirror_ready = 0;
 static unsigned brev_bits(unsigned x, int bits) {
     unsigned r = 0;
@@ -261,11 +265,9 @@ static void fmirror_init(void) {
                 fW_re[m + i] = cos(PI * e / 2048.0);
                 fW_im[m + i] = sin(PI * e / 2048.0);
             }
-        for (int G = 2, lg = 1; G <= 8; G <<= 1, lg++)
-            for (int g = 0; g < G; g++) {
-                fU_re[G + g] = cos(PI * (double)brev_bits(g, lg) / (double)G);
-                fU_im[G + g] = sin(PI * (double)brev_bits(g, lg) / (double)G);
-            }
+        fU_re[0] = cos(PI * 1.0 / 4.0); fU_im[0] = sin(PI * 1.0 / 4.0);
+        fU_re[1] = cos(PI * 1.0 / 8.0); fU_im[1] = sin(PI * 1.0 / 8.0);
+        fU_re[2] = cos(PI * 3.0 / 8.0); fU_im[2] = sin(PI * 3.0 / 8.0);
         fmirror_ready = 1;
     }
     pthread_mutex_unlock(&g_tab_mu);
@@ -273,135 +275,139 @@ static void fmirror_init(void) {
 void orc_fft_tables(double *w_re, double *w_im, double *u_re, double *u_im) {
     fmirror_init();
     memcpy(w_re, fW_re, sizeof(fW_re)); memcpy(w_im, fW_im, sizeof(fW_im));
+    memset(u_re, 0, 16 * sizeof(double)); memset(u_im, 0, 16 * sizeof(double));
     memcpy(u_re, fU_re, sizeof(fU_re)); memcpy(u_im, fU_im, sizeof(fU_im));
 }
-#define CMUL(tr, ti, ar, ai, wr, wi) do { const double a_r__ = (ar), a_i__ = (ai), w_r__ = (wr), w_i__ = (wi); \
-    (tr) = fma(-a_i__, w_i__, a_r__ * w_r__); (ti) = fma(a_i__, w_r__, a_r__ * w_i__); } while (0)
-
-/* forward: x[2048] real coefficients (as doubles) -> F[lane][c] complex at array index 16*lane + c */
-static void fmirror_forward(const double *x, double (*Fr)[16], double (*Fi)[16]) {
-    static __thread double zr[64][16], zi[64][16], lr[FM + 16], li[FM + 16];
-    for (int l = 0; l < 64; l++)
-        for (int r = 0; r < 16; r++) { zr[l][r] = x[l + 64 * r]; zi[l][r] = x[l + 64 * r + 1024]; }
-    for (int l = 0; l < 64; l++) {
-        for (int T = 8; T >= 1; T >>= 1) {
-            const int m = 8 / T;
-            for (int i = 0; i < m; i++) {
-                const double wr = fW_re[m + i], wi = fW_im[m + i];
-                for (int r = 2 * i * T; r < 2 * i * T + T; r++) {
-                    double vr, vi;
-                    CMUL(vr, vi, zr[l][r + T], zi[l][r + T], wr, wi);
-                    const double ur = zr[l][r], ui = zi[l][r];
-                    zr[l][r] = ur + vr; zi[l][r] = ui + vi;
-                    zr[l][r + T] = ur - vr; zi[l][r + T] = ui - vi;
-                }
+typedef struct { double r, i; } fcplx;
+static inline fcplx fcmul(fcplx a, double wr, double wi) {
+    fcplx t;
+    t.r = fma(-a.i, wi, a.r * wr);
+    t.i = fma(a.i, wr, a.r * wi);
+    return t;
+}
+/* forward butterfly (a, b) <- (a + w' b, a - w' b), w' = w or i*w (rot) */
+static inline void fbf_fwd(fcplx *a, fcplx *b, double wr, double wi, int rot) {
+    const fcplx p = fcmul(*b, wr, wi), u = *a;
+    if (!rot) { a->r = u.r + p.r; a->i = u.i + p.i; b->r = u.r - p.r; b->i = u.i - p.i; }
+    else      { a->r = u.r - p.i; a->i = u.i + p.r; b->r = u.r + p.i; b->i = u.i - p.r; }
+}
+/* inverse butterfly (a, b) <- (a + b, (a - b) conj(w')) */
+static inline void fbf_inv(fcplx *a, fcplx *b, double wr, double wi, int rot) {
+    const fcplx u = *a, v = *b;
+    fcplx d, q;
+    a->r = u.r + v.r; a->i = u.i + v.i;
+    d.r = u.r - v.r; d.i = u.i - v.i;
+    q = fcmul(d, wr, -wi);
+    if (!rot) *b = q;
+    else { b->r = q.i; b->i = -q.r; }
+}
+static void fstages_uniform(fcplx *z, int inv) {
+    for (int s = 0; s < 4; s++) {
+        const int T = inv ? (1 << s) : (8 >> s), m = 8 / T;
+        for (int i = 0; i < m; i++) {
+            const int k = m == 1 ? 1 : ((m + i) & ~1);
+            const double wr = fW_re[k], wi = fW_im[k];
+            for (int r = 2 * i * T; r < 2 * i * T + T; r++) {
+                if (inv) fbf_inv(&z[r], &z[r + T], wr, wi, i & 1); else fbf_fwd(&z[r], &z[r + T], wr, wi, i & 1);
             }
         }
-        for (int r = 0; r < 16; r++) { lr[FSLOT(l + 64 * r)] = zr[l][r]; li[FSLOT(l + 64 * r)] = zi[l][r]; }
     }
-    for (int L = 0; L < 64; L++) {
-        const int q = L & 3, gL = L >> 2;
-        const double war = fW_re[16 + gL], wai = fW_im[16 + gL];
-        const double wbr = fW_re[32 + 2 * gL + (q >> 1)], wbi = fW_im[32 + 2 * gL + (q >> 1)];
-        const double s1 = q < 2 ? 1.0 : -1.0, s2 = (q & 1) ? -1.0 : 1.0;
-        double *yr = Fr[L], *yi = Fi[L];
-        for (int c = 0; c < 16; c++) {
-            const int b = FSLOT(64 * gL + c);               /* members at +16 qq (same 64-block => same pad) */
-            double t2r, t2i, t3r, t3i, tbr, tbi;
-            CMUL(t2r, t2i, lr[b + 32], li[b + 32], war, wai);
-            CMUL(t3r, t3i, lr[b + 48], li[b + 48], war, wai);
-            const double Ar = fma(s1, t2r, lr[b]), Ai = fma(s1, t2i, li[b]);
-            const double Br = fma(s1, t3r, lr[b + 16]), Bi = fma(s1, t3i, li[b + 16]);
-            CMUL(tbr, tbi, Br, Bi, wbr, wbi);
-            yr[c] = fma(s2, tbr, Ar); yi[c] = fma(s2, tbi, Ai);
+}
+/* one in-lane stage: register distance tau, G = 8/tau groups, twiddle = base * U_G[g] (g even), rotated for odd g */
+static void fstage_lane(fcplx *z, int inv, int tau, double br, double bi) {
+    const int G = 8 / tau;
+    for (int g = 0; g < G; g += 2) {
+        double wr = br, wi = bi;
+        if (g) {
+            const int u = (G == 8 && g == 4) ? 1 : (G == 8 && g == 6) ? 2 : 0;
+            fcplx b = {br, bi};
+            const fcplx w = fcmul(b, fU_re[u], fU_im[u]);
+            wr = w.r; wi = w.i;
         }
-        int lg = 0;
-        for (int t = 8; t >= 1; t >>= 1, lg++) {
-            const int G = 8 / t;
-            const double br_ = fW_re[64 * G + G * L], bi_ = fW_im[64 * G + G * L];
-            for (int g = 0; g < G; g++) {
-                double wr = br_, wi = bi_;
-                if (g) CMUL(wr, wi, br_, bi_, fU_re[G + g], fU_im[G + g]);
-                for (int c = 2 * g * t; c < 2 * g * t + t; c++) {
-                    double vr, vi;
-                    CMUL(vr, vi, yr[c + t], yi[c + t], wr, wi);
-                    const double ur = yr[c], ui = yi[c];
-                    yr[c] = ur + vr; yi[c] = ui + vi;
-                    yr[c + t] = ur - vr; yi[c + t] = ui - vi;
-                }
+        for (int c = 2 * g * tau; c < 2 * g * tau + tau; c++) {
+            if (inv) fbf_inv(&z[c], &z[c + tau], wr, wi, 0); else fbf_fwd(&z[c], &z[c + tau], wr, wi, 0);
+        }
+        if (G > 1)
+            for (int c = 2 * (g + 1) * tau; c < 2 * (g + 1) * tau + tau; c++) {
+                if (inv) fbf_inv(&z[c], &z[c + tau], wr, wi, 1); else fbf_fwd(&z[c], &z[c + tau], wr, wi, 1);
             }
-        }
+    }
+}
+#define N_A(l, r) ((l) + 64 * (r))
+#define N_B(l, r) (64 * ((l) >> 2) + 4 * (r) + ((l) & 3))
+#define N_C(l, r) (16 * (l) + (r))
+/* forward: x[2048] real coefficients (as doubles) -> F[lane][c] complex at array index 16*lane + c */
+static void fmirror_forward(const double *x, fcplx (*F)[16]) {
+    static __thread fcplx buf[FM];
+    fcplx z[16];
+    for (int l = 0; l < 64; l++) {
+        for (int r = 0; r < 16; r++) { z[r].r = x[N_A(l, r)]; z[r].i = x[N_A(l, r) + 1024]; }
+        fstages_uniform(z, 0);
+        for (int r = 0; r < 16; r++) buf[N_A(l, r)] = z[r];
+    }
+    for (int l = 0; l < 64; l++) {
+        const int hi = l >> 2;
+        for (int r = 0; r < 16; r++) z[r] = buf[N_B(l, r)];
+        for (int tau = 8, G = 1; tau >= 1; tau >>= 1, G <<= 1)
+            fstage_lane(z, 0, tau, fW_re[16 * G + G * hi], fW_im[16 * G + G * hi]);
+        for (int r = 0; r < 16; r++) F[l][r] = z[r];            /* parked in layout B */
+    }
+    for (int l = 0; l < 64; l++) for (int r = 0; r < 16; r++) buf[N_B(l, r)] = F[l][r];
+    for (int l = 0; l < 64; l++) {
+        for (int c = 0; c < 16; c++) z[c] = buf[N_C(l, c)];
+        fstage_lane(z, 0, 2, fW_re[256 + 4 * l], fW_im[256 + 4 * l]);
+        fstage_lane(z, 0, 1, fW_re[512 + 8 * l], fW_im[512 + 8 * l]);
+        for (int c = 0; c < 16; c++) F[l][c] = z[c];
     }
 }
 /* inverse (unscaled: 1/1024 is folded into the key): T[lane][c] -> x[2048] real coefficients */
-static void fmirror_inverse(double (*Tr)[16], double (*Ti)[16], double *x) {
-    static __thread double lr[FM + 16], li[FM + 16];
-    for (int L = 0; L < 64; L++) {
-        double *yr = Tr[L], *yi = Ti[L];
-        int lg = 3;
-        for (int t = 1; t <= 8; t <<= 1, lg--) {
-            const int G = 8 / t;
-            const double br_ = fW_re[64 * G + G * L], bi_ = fW_im[64 * G + G * L];
-            for (int g = 0; g < G; g++) {
-                double wr = br_, wi = bi_;
-                if (g) CMUL(wr, wi, br_, bi_, fU_re[G + g], fU_im[G + g]);
-                for (int c = 2 * g * t; c < 2 * g * t + t; c++) {
-                    const double ur = yr[c], ui = yi[c], vr = yr[c + t], vi = yi[c + t];
-                    yr[c] = ur + vr; yi[c] = ui + vi;
-                    CMUL(yr[c + t], yi[c + t], ur - vr, ui - vi, wr, -wi);      /* conj twiddle */
-                }
-            }
-        }
-        for (int c = 0; c < 16; c++) { lr[FSLOT(16 * L + c)] = yr[c]; li[FSLOT(16 * L + c)] = yi[c]; }
+static void fmirror_inverse(fcplx (*Tq)[16], double *x) {
+    static __thread fcplx buf[FM];
+    fcplx z[16];
+    for (int l = 0; l < 64; l++) {
+        for (int c = 0; c < 16; c++) z[c] = Tq[l][c];
+        fstage_lane(z, 1, 1, fW_re[512 + 8 * l], fW_im[512 + 8 * l]);
+        fstage_lane(z, 1, 2, fW_re[256 + 4 * l], fW_im[256 + 4 * l]);
+        for (int c = 0; c < 16; c++) buf[N_C(l, c)] = z[c];
     }
     for (int l = 0; l < 64; l++) {
-        const int q = (l >> 4) & 3, l4 = l & 15;
-        const double s2 = (q & 1) ? -1.0 : 1.0, s1 = q >= 2 ? -1.0 : 1.0;
-        double zr[16], zi[16];
-        for (int r = 0; r < 16; r++) {
-            const int b = FSLOT(64 * r) + l4;
-            const double d01r = fma(s2, lr[b + 16], lr[b]), d01i = fma(s2, li[b + 16], li[b]);
-            const double d23r = fma(s2, lr[b + 48], lr[b + 32]), d23i = fma(s2, li[b + 48], li[b + 32]);
-            double pr = d01r, pi_ = d01i, qr = d23r, qi = d23i;
-            if (q & 1) {
-                CMUL(pr, pi_, d01r, d01i, fW_re[32 + 2 * r], -fW_im[32 + 2 * r]);
-                CMUL(qr, qi, d23r, d23i, fW_re[32 + 2 * r + 1], -fW_im[32 + 2 * r + 1]);
-            }
-            const double hr = fma(s1, qr, pr), hi = fma(s1, qi, pi_);
-            zr[r] = hr; zi[r] = hi;
-            if (q >= 2) CMUL(zr[r], zi[r], hr, hi, fW_re[16 + r], -fW_im[16 + r]);
-        }
-        for (int T = 1; T <= 8; T <<= 1) {
-            const int h = 8 / T;
-            for (int i = 0; i < h; i++) {
-                const double wr = fW_re[h + i], wi = -fW_im[h + i];
-                for (int r = 2 * i * T; r < 2 * i * T + T; r++) {
-                    const double ur = zr[r], ui = zi[r], vr = zr[r + T], vi = zi[r + T];
-                    zr[r] = ur + vr; zi[r] = ui + vi;
-                    CMUL(zr[r + T], zi[r + T], ur - vr, ui - vi, wr, wi);
-                }
-            }
-        }
-        for (int r = 0; r < 16; r++) { x[l + 64 * r] = zr[r]; x[l + 64 * r + 1024] = zi[r]; }
+        const int hi = l >> 2;
+        for (int r = 0; r < 16; r++) z[r] = buf[N_B(l, r)];
+        for (int tau = 1, G = 8; tau <= 8; tau <<= 1, G >>= 1)
+            fstage_lane(z, 1, tau, fW_re[16 * G + G * hi], fW_im[16 * G + G * hi]);
+        for (int r = 0; r < 16; r++) Tq[l][r] = z[r];           /* parked in layout B */
+    }
+    for (int l = 0; l < 64; l++) for (int r = 0; r < 16; r++) buf[N_B(l, r)] = Tq[l][r];
+    for (int l = 0; l < 64; l++) {
+        for (int r = 0; r < 16; r++) z[r] = buf[N_A(l, r)];
+        fstages_uniform(z, 1);
+        for (int r = 0; r < 16; r++) { x[N_A(l, r)] = z[r].r; x[N_A(l, r) + 1024] = z[r].i; }
     }
 }
-/* torus value of an (approximately) integral double of any magnitude < 2^116, mod 2^64 */
+/* v_fract_f64: x - floor(x), clamped below 1 */
+static inline double ffract(double x) {
+    const double r = x - floor(x);
+    return r < 1.0 ? r : 0x1.fffffffffffffp-1;
+}
+/* floor(v) mod 2^64 of a double of any magnitude (v is integral whenever |v| >= 2^52) */
 static inline u64 fmirror_to_torus(double v) {
-    const double k = floor(v * 5.421010862427522e-20 + 0.5);                  /* 2^-64 */
-    const double rr = fma(-k, 18446744073709551616.0, v);                     /* in [-2^63, 2^63), exact */
-    const double hi = floor(rr * 2.3283064365386963e-10);                     /* 2^-32 */
-    const double lo = fma(-hi, 4294967296.0, rr);                             /* in [0, 2^32), exact */
-    return ((u64)(i64)(int32_t)hi << 32) + (u64)(uint32_t)lo;
+    const double f = ffract(v * 0x1p-64);
+    const double h = f * 0x1p32;
+    const uint32_t hi = (uint32_t)h;
+    const uint32_t lo = (uint32_t)(ffract(h) * 0x1p32);
+    return ((u64)hi << 32) | lo;
 }
 /* BSK polynomial -> Fourier domain in the kernel's layout [c][lane] (re, im), pre-scaled by 1/1024 */
 static void fmirror_bsk_poly(const u64 *src, double *dst /* [16][64][2] */) {
-    static __thread double x[POLY_N], Fr[64][16], Fi[64][16];
-    for (int n = 0; n < POLY_N; n++) x[n] = (double)(i64)src[n];
-    fmirror_forward(x, Fr, Fi);
+    static __thread double x[POLY_N];
+    static __thread fcplx F[64][16];
+    for (int n = 0; n < POLY_N; n++)   /* 58 significant bits: both halves convert exactly, one rounding in the add */
+        x[n] = (double)(int32_t)(src[n] >> 32) * 0x1p32 + (double)(uint32_t)src[n];
+    fmirror_forward(x, F);
     for (int L = 0; L < 64; L++)
         for (int c = 0; c < 16; c++) {
-            dst[(c * 64 + L) * 2 + 0] = Fr[L][c] * 0.0009765625;
-            dst[(c * 64 + L) * 2 + 1] = Fi[L][c] * 0.0009765625;
+            dst[(c * 64 + L) * 2 + 0] = F[L][c].r * 0x1p-10;
+            dst[(c * 64 + L) * 2 + 1] = F[L][c].i * 0x1p-10;
         }
 }
 void orc_fft_bsk_convert(const u64 *bsk_quantised, double *out /* [742*4][16][64][2] */) {
@@ -654,10 +660,11 @@ static void blind_rotate(const orc_server_key *k, const u32 *ms, const u64 *lut,
             for (int n = 0; n < POLY_N; n++) dig[c * POLY_N + n] = pbs_digit(rot[n] - acc[c * POLY_N + n]);
         }
         if (mode == 3) {
-            static __thread double xx[POLY_N], Fr[2][64][16], Fi[2][64][16], Tr[64][16], Ti[64][16], xo[POLY_N];
+            static __thread double xx[POLY_N], xo[POLY_N];
+            static __thread fcplx F[2][64][16], Tq[64][16];
             for (int c = 0; c < 2; c++) {
                 for (int n = 0; n < POLY_N; n++) xx[n] = (double)dig[c * POLY_N + n];
-                fmirror_forward(xx, Fr[c], Fi[c]);
+                fmirror_forward(xx, F[c]);
             }
             for (int col = 0; col < 2; col++) {
                 /* wave `col` multiplies its own transform first (row = col), then the partner's */
@@ -665,14 +672,14 @@ static void blind_rotate(const orc_server_key *k, const u32 *ms, const u64 *lut,
                 const double *bp = k->bsk_fm + ((((size_t)i * 2 + (1 - col)) * 2 + col)) * 2 * FM;
                 for (int L = 0; L < 64; L++)
                     for (int c = 0; c < 16; c++) {
-                        const double fr = Fr[col][L][c], fi = Fi[col][L][c], gr = Fr[1 - col][L][c], gi = Fi[1 - col][L][c];
+                        const double fr = F[col][L][c].r, fi = F[col][L][c].i, gr = F[1 - col][L][c].r, gi = F[1 - col][L][c].i;
                         const double b0r = bo[(c * 64 + L) * 2], b0i = bo[(c * 64 + L) * 2 + 1];
                         const double b1r = bp[(c * 64 + L) * 2], b1i = bp[(c * 64 + L) * 2 + 1];
                         double rr = fr * b0r; rr = fma(-fi, b0i, rr); rr = fma(gr, b1r, rr); rr = fma(-gi, b1i, rr);
                         double ii = fr * b0i; ii = fma(fi, b0r, ii); ii = fma(gr, b1i, ii); ii = fma(gi, b1r, ii);
-                        Tr[L][c] = rr; Ti[L][c] = ii;
+                        Tq[L][c].r = rr; Tq[L][c].i = ii;
                     }
-                fmirror_inverse(Tr, Ti, xo);
+                fmirror_inverse(Tq, xo);
                 for (int n = 0; n < POLY_N; n++) acc[col * POLY_N + n] += fmirror_to_torus(xo[n]);
             }
         } else if (mode == 2) {

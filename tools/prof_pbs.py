@@ -3,10 +3,14 @@ import sys
 import numpy as np
 sys.path.insert(0, ".")
 from fhestring_amd.api import MyClientKey, Context
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+fft = "--fft" in sys.argv
+argv = [a for a in sys.argv if a != "--fft"]
+B = int(argv[1]) if len(argv) > 1 else 512
+reps = int(argv[2]) if len(argv) > 2 else 2
 ck = MyClientKey(1)
 ctx = Context(0)
+if fft:
+    ctx.set_arithmetic(ctx.ARITH_F64_FFT)
 ctx.load_server_key(ck.bsk(), ck.ksk())
 rng = np.random.default_rng(0)
 cts = rng.integers(0, 2**64, (B, 2049), dtype=np.uint64)
