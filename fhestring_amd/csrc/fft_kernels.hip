@@ -41,12 +41,19 @@ __device__ __forceinline__ cplx cmul(cplx a, double wr, double wi) {
 }
 __device__ __forceinline__ uint32_t fft_mod_switch(uint64_t x) { return (uint32_t)(((x + (1ull << 51)) >> 52) & 4095u); }
 
-// Cooley-Tukey butterfly (forward): (a, b) <- (a + w' b, a - w' b), w' = w or i*w (ROT)
+// Cooley-Tukey butterfly (forward): (a, b) <- (a + w' b, a - w' b), w' = w or i*w (ROT), in 6 fused
+// operations: the sum is accumulated straight onto a, the difference is 2a - sum
 template <bool ROT> __device__ __forceinline__ void bf_fwd(cplx &a, cplx &b, double wr, double wi) {
-    const cplx p = cmul(b, wr, wi);
     const cplx u = a;
-    if (!ROT) { a.r = u.r + p.r; a.i = u.i + p.i; b.r = u.r - p.r; b.i = u.i - p.i; }
-    else      { a.r = u.r - p.i; a.i = u.i + p.r; b.r = u.r + p.i; b.i = u.i - p.r; }
+    if (!ROT) {
+        a.r = __builtin_fma(-b.i, wi, __builtin_fma(b.r, wr, u.r));
+        a.i = __builtin_fma(b.i, wr, __builtin_fma(b.r, wi, u.i));
+    } else {
+        a.r = __builtin_fma(-b.i, wr, __builtin_fma(-b.r, wi, u.r));
+        a.i = __builtin_fma(-b.i, wi, __builtin_fma(b.r, wr, u.i));
+    }
+    b.r = __builtin_fma(2.0, u.r, -a.r);
+    b.i = __builtin_fma(2.0, u.i, -a.i);
 }
 // Gentleman-Sande butterfly (inverse): (a, b) <- (a + b, (a - b) conj(w')), w' = w or i*w (ROT)
 template <bool ROT> __device__ __forceinline__ void bf_inv(cplx &a, cplx &b, double wr, double wi) {
@@ -229,6 +236,8 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
         }
     }
 
+#pragma unroll
+    for (int r = 0; r < 32; r++) my_u[lane + 64 * r] = acc[r];
     for (int i = 0; i < LWE_N; i++) {
         const uint32_t a = fft_mod_switch(ks[i]);
         if (a == 0) continue;
@@ -242,8 +251,6 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
 
         // rotate, subtract, decompose; fold: z[r] = digit[r] + i * digit[r + 16]
         cplx z[16];
-#pragma unroll
-        for (int r = 0; r < 32; r++) my_u[lane + 64 * r] = acc[r];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 32; r++) {
@@ -305,10 +312,14 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
             fft_inverse(z, my, lane, tw2);
         }
 
+        // update, and stage the new accumulator in LDS for the next iteration's rotated read (the store
+        // burst overlaps the conversions instead of stalling the start of the next iteration)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             acc[r] += to_torus(z[r].r);
+            my_u[lane + 64 * r] = acc[r];
             acc[r + 16] += to_torus(z[r].i);
+            my_u[lane + 64 * (r + 16)] = acc[r + 16];
         }
     }
 

@@ -285,11 +285,19 @@ static inline fcplx fcmul(fcplx a, double wr, double wi) {
     t.i = fma(a.i, wr, a.r * wi);
     return t;
 }
-/* forward butterfly (a, b) <- (a + w' b, a - w' b), w' = w or i*w (rot) */
+/* forward butterfly (a, b) <- (a + w' b, a - w' b), w' = w or i*w (rot): sum accumulated onto a with two
+ * fused operations per component, difference = 2a - sum */
 static inline void fbf_fwd(fcplx *a, fcplx *b, double wr, double wi, int rot) {
-    const fcplx p = fcmul(*b, wr, wi), u = *a;
-    if (!rot) { a->r = u.r + p.r; a->i = u.i + p.i; b->r = u.r - p.r; b->i = u.i - p.i; }
-    else      { a->r = u.r - p.i; a->i = u.i + p.r; b->r = u.r + p.i; b->i = u.i - p.r; }
+    const fcplx u = *a, v = *b;
+    if (!rot) {
+        a->r = fma(-v.i, wi, fma(v.r, wr, u.r));
+        a->i = fma(v.i, wr, fma(v.r, wi, u.i));
+    } else {
+        a->r = fma(-v.i, wr, fma(-v.r, wi, u.r));
+        a->i = fma(-v.i, wi, fma(v.r, wr, u.i));
+    }
+    b->r = fma(2.0, u.r, -a->r);
+    b->i = fma(2.0, u.i, -a->i);
 }
 /* inverse butterfly (a, b) <- (a + b, (a - b) conj(w')) */
 static inline void fbf_inv(fcplx *a, fcplx *b, double wr, double wi, int rot) {
