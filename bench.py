@@ -45,6 +45,15 @@ def parse():
     ap.add_argument("--dist-mode", choices=["windows", "levels"], default="windows",
                     help="N>1: 'windows' shards the match windows (1 all-gather of 1 char per rank); 'levels' "
                          "replicates the string and splits every PBS level (1 all-gather per level)")
+    ap.add_argument("--arith", choices=["fft", "exact"], default="fft",
+                    help="arithmetic of the negacyclic products in blind rotation: 'fft' = f64 complex FFT (the "
+                         "reference engine's algorithm class, fhs_set_arithmetic(FHS_ARITH_F64_FFT)); 'exact' = "
+                         "two-prime exact NTT (library default).  The other one is timed too (secondary section)")
+    ap.add_argument("--pipelines", type=int, default=3,
+                    help="independent contexts (own HIP stream, scratch and block pool) per GPU; step k runs on "
+                         "pipeline k mod P, so the narrow tail levels of one step overlap the wide first level of the "
+                         "next (1 = strictly one step after the other)")
+    ap.add_argument("--skip-secondary", action="store_true", help="do not time the other arithmetic")
     ap.add_argument("--skip-single-op", action="store_true",
                     help="do not run the extra single-op latency section (profiling: every launch is then timed)")
     return ap.parse_args()
@@ -137,20 +146,52 @@ def main():
     rnd = random.Random(SEED)
     strings, pattern = synth_strings(args.strings, args.chars * world, m, rnd)
     ck = MyClientKey(SEED)                      # same seed on every rank -> identical keys
-    sk = MyServerKey.from_client_key(ck, local_rank)
-    sk.set_mode(1 if args.mode == "fused" else 0)
-    if args.dist_mode == "levels" and world > 1:
-        sk.enable_level_parallel(rank, world, dist, torch)
-        job = ShardedContains(sk, 0, 1, None, torch)                     # every rank holds the whole string
-    else:
-        job = ShardedContains(sk, rank, world, dist, torch)
-    shards = [job.upload_shard(ck, s, args.chars, m) for s in strings]   # resident before timing
-    sk.flush()
+    P = max(1, args.pipelines)
+    sks = [MyServerKey.from_client_key(ck, local_rank, arith=1) for _ in range(P)]   # Fourier-domain key as well
+    sk = sks[0]
+    ARITH = {"fft": sk.ctx.ARITH_F64_FFT, "exact": sk.ctx.ARITH_EXACT_NTT}
+    jobs, shard_sets = [], []
+    for x in sks:
+        x.ctx.set_arithmetic(ARITH[args.arith])
+        x.set_mode(1 if args.mode == "fused" else 0)
+        if args.dist_mode == "levels" and world > 1:
+            x.enable_level_parallel(rank, world, dist, torch)
+            jb = ShardedContains(x, 0, 1, None, torch)                   # every rank holds the whole string
+        else:
+            jb = ShardedContains(x, rank, world, dist, torch)
+        jobs.append(jb)
+        shard_sets.append([jb.upload_shard(ck, s, args.chars, m) for s in strings])   # resident before timing
+        x.flush()
+    job, shards = jobs[0], shard_sets[0]
+    step_no = [0]
 
     def step():
-        outs = [job.run(sh, pattern, op=args.op) for sh in shards]
-        sk.flush()
+        k = step_no[0] % P
+        step_no[0] += 1
+        outs = [jobs[k].run(sh, pattern, op=args.op) for sh in shard_sets[k]]
+        sks[k].flush(wait=(P == 1))          # P > 1: enqueue only; sync() below waits for every stream
         return outs
+
+    def all_stats(reset=False):
+        tot = {}
+        for x in sks:
+            for key, v in x.stats(reset=reset).items():
+                tot[key] = max(tot.get(key, 0), v) if key == "max_level_width" else tot.get(key, 0) + v
+        return tot
+
+    def all_timing(reset=False):
+        ms = n = units = ks = 0.0
+        for x in sks:
+            kt = x.ctx.kernel_timing(reset=reset)
+            ms += kt["blind_rotate_ms"] * kt["n_blind_rotate"]
+            n += kt["n_blind_rotate"]
+            units += kt["pbs_in_launches"]
+            ks += kt["keyswitch_ms"] * kt["n_keyswitch"]
+        return {"blind_rotate_ms": ms / max(1, n), "n_blind_rotate": n, "pbs_in_launches": units}
+
+    def set_arith(a):
+        for x in sks:
+            x.ctx.set_arithmetic(ARITH[a])
 
     def sync():
         torch.cuda.synchronize()
@@ -161,16 +202,16 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    sk.stats(reset=True)
-    sk.ctx.kernel_timing(reset=True)
+    all_stats(reset=True)
+    all_timing(reset=True)
     t0 = time.perf_counter()
     outs = None
     for _ in range(args.steps):
         outs = step()
     sync()
     dt = time.perf_counter() - t0
-    st = sk.stats()
-    kt = sk.ctx.kernel_timing()
+    st = all_stats()
+    kt = all_timing()
 
     # latency of ONE op on one string (same workload, batch of 1), outside the timed region above
     single_ms = None
@@ -187,32 +228,62 @@ def main():
         single_ms = (time.perf_counter() - t1) / 3 * 1e3
 
     # correctness of what was timed (decrypt-level, against python str semantics)
-    for s, o in zip(strings, outs):
-        got = ck.decrypt_char(o)
-        want = int(pattern in s) if args.op == "contains" else (s.find(pattern) if pattern in s else 255)
-        assert got == want, ("bench result mismatch", got, want)
+    def check(results):
+        for s, o in zip(strings, results):
+            got = ck.decrypt_char(o)
+            want = int(pattern in s) if args.op == "contains" else (s.find(pattern) if pattern in s else 255)
+            assert got == want, ("bench result mismatch", got, want)
+    check(outs)
+
+    # the other arithmetic on the same workload (secondary figure, fewer steps)
+    secondary = None
+    if not args.skip_secondary:
+        other = "exact" if args.arith == "fft" else "fft"
+        set_arith(other)
+        for _ in range(P):
+            step()
+        sync()
+        all_stats(reset=True)
+        all_timing(reset=True)
+        n2 = max(1, min(args.steps, 2))
+        t2 = time.perf_counter()
+        for _ in range(n2):
+            outs2 = step()
+        sync()
+        dt2 = time.perf_counter() - t2
+        check(outs2)
+        st2, kt2 = all_stats(), all_timing()
+        secondary = {"arithmetic": other, "pbs_local": float(st2["pbs_executed"]), "dt": dt2, "steps": n2,
+                     "blind_rotate_ms": kt2["blind_rotate_ms"]}
+        set_arith(args.arith)
 
     pbs_local = st["pbs_executed"]
     if dist is not None:
-        tt = torch.tensor([dt, float(pbs_local)], dtype=torch.float64, device="cuda")
+        sec = [secondary["dt"], secondary["pbs_local"]] if secondary else [0.0, 0.0]
+        tt = torch.tensor([dt, float(pbs_local)] + sec, dtype=torch.float64, device="cuda")
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         dt = float(tmax[0])
         pbs_total = float(tt[1])
+        if secondary:
+            secondary["dt"], secondary["pbs_total"] = float(tmax[2]), float(tt[3])
     else:
         pbs_total = float(pbs_local)
+        if secondary:
+            secondary["pbs_total"] = secondary["pbs_local"]
 
     if rank == 0:
         n_br = max(1, kt["n_blind_rotate"])
         br_ms = kt["blind_rotate_ms"]                      # average launch duration (HIP events)
         pbs_per_launch = kt["pbs_in_launches"] / n_br
         achieved = pbs_per_launch * ALGO_BYTES_PER_PBS / (br_ms * 1e-3) / 1e9 if br_ms > 0 else 0.0
+        kernel = "blind_rotate_fft_kernel" if args.arith == "fft" else "blind_rotate_kernel"
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("blind_rotate_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(kernel + "_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -226,10 +297,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u64",
+            "dtype": "f64" if args.arith == "fft" else "u64",
             "data": "synthetic",
             "config": {"workload": "%s_clear, %d-char FheString per GPU (+1 NUL pad), clear pattern m=%d, "
-                                   "%d string(s)/step, %s DAG" % (args.op, args.chars, m, args.strings, args.mode),
+                                   "%d string(s)/step, %s DAG, %s arithmetic"
+                                   % (args.op, args.chars, m, args.strings, args.mode,
+                                      "f64-FFT" if args.arith == "fft" else "exact-NTT"),
+                       "pipelines": P,
                        "parallelism": ("windows sharded over %d GPU(s), 1 all-gather" % world)
                        if args.dist_mode == "windows" else
                        ("every PBS level split over %d GPU(s), 1 all-gather per level" % world)},
@@ -240,20 +314,28 @@ def main():
             "max_level_width": st["max_level_width"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "blind_rotate_kernel", "avg_launch_ms": br_ms,
+                         "kernel": kernel, "avg_launch_ms": br_ms,
                          "avg_pbs_per_launch": pbs_per_launch,
                          "note": "algorithmic bytes 109559824 B/PBS x PBS per launch / HIP-event launch time; "
-                                 "the kernel is FP64/int VALU-bound by construction (DESIGN.md)"},
-            "parity": "GPU bit-exact vs own CPU oracle; decrypt-exact vs reference test vectors; "
+                                 "the kernel is FP64 VALU-bound by construction (DESIGN.md)"},
+            "parity": "GPU bit-exact vs own CPU oracle in both arithmetics (exact NTT vs oracle mode 0, f64 FFT vs its "
+                      "lane-for-lane mirror, oracle mode 3); decrypt-exact vs reference test vectors; "
                       "ciphertext-level parity with tfhe-rs unpinned",
         }
+        if secondary:
+            line["other_arithmetic"] = {
+                "arithmetic": "exact-NTT (u64, library default)" if secondary["arithmetic"] == "exact" else "f64-FFT",
+                "value": secondary["pbs_total"] / secondary["dt"], "unit": "PBS/s", "steps": secondary["steps"],
+                "ms_per_step": secondary["dt"] / secondary["steps"] * 1e3,
+                "avg_blind_rotate_launch_ms": secondary["blind_rotate_ms"]}
         if args.cpu_pbs != 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_pbs)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    sk.close()
+    for x in sks:
+        x.close()
 
 
 if __name__ == "__main__":

@@ -74,6 +74,8 @@ def _declare(L):
     L.fhs_release.restype = i
     L.fhs_flush.argtypes = [vp]
     L.fhs_flush.restype = i
+    L.fhs_flush_async.argtypes = [vp]
+    L.fhs_flush_async.restype = i
     L.fhs_download.argtypes = [vp, h, vp]
     L.fhs_download.restype = i
     L.fhs_export_device.argtypes = [vp, h, vp]

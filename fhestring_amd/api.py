@@ -162,8 +162,8 @@ class MyClientKey:
         self._L.fhs_client_secret_keys(self._h, _ptr(lwe), _ptr(glwe))
         return lwe, glwe
 
-    def get_server_key(self, device_id=0):                               # client_key.rs:37-39
-        return MyServerKey.from_client_key(self, device_id)
+    def get_server_key(self, device_id=0, arith=0):                      # client_key.rs:37-39
+        return MyServerKey.from_client_key(self, device_id, arith)
 
     def encrypt_char_raw(self, v):
         out = np.zeros((4, BIG_CT), np.uint64)
@@ -321,20 +321,23 @@ class MyServerKey:
         self._stats = None
 
     @classmethod
-    def from_client_key(cls, client_key, device_id=0):
+    def from_client_key(cls, client_key, device_id=0, arith=0):
         ctx = Context(device_id)
+        ctx.set_arithmetic(arith)
         ctx.load_server_key(client_key.bsk(), client_key.ksk())
         return cls(ctx)
 
     @classmethod
-    def from_key_file(cls, path, device_id=0):
+    def from_key_file(cls, path, device_id=0, arith=0):
         ctx = Context(device_id)
+        ctx.set_arithmetic(arith)
         ctx._check(ctx._L.fhs_load_server_key_file(ctx._h, str(path).encode()))
         return cls(ctx)
 
     @classmethod
-    def from_raw_keys(cls, bsk, ksk, device_id=0):
+    def from_raw_keys(cls, bsk, ksk, device_id=0, arith=0):
         ctx = Context(device_id)
+        ctx.set_arithmetic(arith)
         ctx.load_server_key(bsk, ksk)
         return cls(ctx)
 
@@ -363,10 +366,17 @@ class MyServerKey:
         self.flush()
         self.ctx._check(self.ctx._L.fhs_export_device(self.ctx._h, ch.h, C.c_void_p(d_ptr)))
 
-    def flush(self):
+    def flush(self, wait=True):
+        """Run every pending PBS level.  wait=False only enqueues the launches (fhs_flush_async)."""
         if getattr(self, "_dist", None) is not None:
             return self._dist.flush()
-        self.ctx._check(self.ctx._L.fhs_flush(self.ctx._h))
+        if wait:
+            self.ctx._check(self.ctx._L.fhs_flush(self.ctx._h))
+        else:
+            self.ctx._check(self.ctx._L.fhs_flush_async(self.ctx._h))
+
+    def stream_sync(self):
+        self.ctx._check(self.ctx._L.fhs_stream_sync(self.ctx._h))
 
     def enable_level_parallel(self, rank, world, dist, torch):
         """Level-parallel multi-GPU mode (fhestring_amd.parallel.LevelParallel): every rank records the

@@ -126,6 +126,10 @@ int fhs_flush(fhs_ctx *c) {
     if (hipStreamSynchronize(c->eng.ctx.stream) != hipSuccess) return c->eng.ctx.fail(FHS_ERR_HIP, "stream sync failed");
     return FHS_OK;
 }
+int fhs_flush_async(fhs_ctx *c) {
+    if (!c) return FHS_ERR_ARG;
+    return c->eng.flush();
+}
 int fhs_download(fhs_ctx *c, fhs_char_t a, uint64_t *blocks) {
     if (!ok(c, a) || !blocks) return bad(c);
     const Bid *b = c->eng.char_blocks(a);

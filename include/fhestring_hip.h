@@ -108,6 +108,10 @@ fhs_char_t fhs_is_lowercase(fhs_ctx *ctx, fhs_char_t a);                /* :146-
 fhs_char_t fhs_clone(fhs_ctx *ctx, fhs_char_t a);                       /* #[derive(Clone)] :7 */
 int fhs_release(fhs_ctx *ctx, fhs_char_t a);
 int fhs_flush(fhs_ctx *ctx);                                             /* run every pending level */
+/* Same, but only enqueues the launches on the context's HIP stream and returns (fhs_stream_sync, a download
+ * or the next fhs_flush waits).  Lets several contexts on one GPU overlap: the narrow tail levels of one
+ * operation run beside the wide first level of the next (bench.py --pipelines). */
+int fhs_flush_async(fhs_ctx *ctx);
 int fhs_download(fhs_ctx *ctx, fhs_char_t a, uint64_t *blocks /*[4][2049]*/);
 /* device-to-device import/export of one char (multi-GPU gather of partial results) */
 int fhs_export_device(fhs_ctx *ctx, fhs_char_t a, uint64_t *d_blocks /*[4][2049] device*/);

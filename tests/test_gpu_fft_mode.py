@@ -84,6 +84,39 @@ def test_fft_mode_string_ops():
     ck.close()
 
 
+@pytest.fixture(scope="module")
+def product_fft():
+    import fhestring_amd
+    from fhestring_amd.api import MyClientKey
+    ck = MyClientKey(0xF5E57121)
+    sk = ck.get_server_key(0, arith=fhestring_amd.Context.ARITH_F64_FFT)
+    sk.set_mode(1)
+    yield ck, sk
+    sk.close()
+    ck.close()
+
+
+def _golden():
+    from golden_util import load_vectors
+    return load_vectors()
+
+
+@pytest.mark.parametrize("v", _golden(), ids=[v["name"] for v in _golden()])
+def test_golden_vectors_in_fft_arithmetic(product_fft, v):
+    """The reference's own test literals through the fused DAGs with the f64-FFT arithmetic."""
+    from golden_util import run_vector, check_vector
+    ck, sk = product_fft
+    assert sk.ctx.arithmetic == sk.ctx.ARITH_F64_FFT
+    sk.trivial_char = sk.trivial
+    env = (sk, lambda t, pad: ck.encrypt(t, pad, None, sk), lambda t: ck.encrypt_no_padding(t, sk),
+           lambda c: ck.encrypt_char(c, sk), ck.decrypt, ck.decrypt_char)
+    if "expected_panic" in v:
+        with pytest.raises(OverflowError, match=v["expected_panic"]):
+            run_vector(v, *env)
+        return
+    check_vector(v, run_vector(v, *env))
+
+
 def test_fft_needs_key_built_for_it(oracle_keys):
     import fhestring_amd
     ctx = fhestring_amd.Context(0)
