@@ -243,6 +243,11 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
         if (a == 0) continue;
         const uint32_t s = a & (POLY_N - 1);
         const bool neg = a >= POLY_N;
+        // Wave priority follows the distance to the next workgroup barrier: the partner wave (on another SIMD,
+        // beside a wave of another workgroup) is parked there until this one arrives.  Forward transform 1,
+        // pointwise phase between the two barriers 2, inverse transform and update (no barrier ahead) 0:
+        // measured -4..-10 % kernel time against equal priorities.
+        __builtin_amdgcn_s_setprio(1);
 
         // keep the (loop-invariant) per-lane twiddle loads inside the iteration: 24 registers that are only
         // live while a transform runs instead of across the whole loop
@@ -287,6 +292,7 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
             for (int c = 0; c < 16; c++) pub[c * 64] = z[c];
         }
         __syncthreads();
+        __builtin_amdgcn_s_setprio(2);
         {
             const cplx *par = reinterpret_cast<const cplx *>(partner) + lane;
 #pragma unroll
@@ -303,6 +309,7 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
             }
         }
         __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
 
         {   // reloaded rather than kept live across the pointwise phase
             const double *lanetab2 = P.lanetab;

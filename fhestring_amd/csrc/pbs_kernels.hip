@@ -312,14 +312,19 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
 
         // ---- rotate, subtract, decompose (closest multiple of 2^41 -> signed 23-bit digit) ----
         double x[32];
+        // wave priority: the short phases that end at a workgroup barrier run at 2 (three other waves are parked
+        // until this one arrives), the long barrier-free transforms at 0 / 1 (measured -2..-4 % kernel time)
+        __builtin_amdgcn_s_setprio(2);
         if (q == 0) phase_digits<0>(x, acc, s_base, sib_w, lane, s, neg);
         else phase_digits<1>(x, acc, s_base, sib_w, lane, s, neg);
         __syncthreads();
         if (q == 0) phase_other_digits<0>(x, my, lane);
         else phase_other_digits<1>(x, my, lane);
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_setprio(0);
 
         ntt_forward(x, my, lane, twA, fwd_lane, p, pinv);
+        __builtin_amdgcn_s_setprio(2);
 
         // ---- publish, pointwise multiply-accumulate with GGSW_i ----
         // key layout [32/2][64 lanes][2]: one 16-byte load per lane covers coefficients (c, c+1)
@@ -358,8 +363,10 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
             }
         }
         __syncthreads();
+        __builtin_amdgcn_s_setprio(1);
 
         ntt_inverse(x, my, lane, twA, twB, inv_lane, p, pinv);
+        __builtin_amdgcn_s_setprio(2);
 
         // ---- exchange residues, CRT for the owned half, restage the accumulator ----
         if (q == 0) phase_publish_residues<0>(x, my, lane);
