@@ -1,6 +1,7 @@
 #include "context.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <thread>
 
 namespace fhs {
@@ -104,16 +105,15 @@ void Context::shutdown() {
     out_buf.release();
     lutidx_buf.release();
     luts_buf.release();
-    if (d_ksk) (void)hipFree(d_ksk);
-    if (d_colsum4) (void)hipFree(d_colsum4);
-    d_colsum4 = nullptr;
+    if (d_ksk_planes) (void)hipFree(d_ksk_planes);
+    d_ksk_planes = nullptr;
+    dig_buf.release();
     if (d_bsk_ntt) (void)hipFree(d_bsk_ntt);
     if (d_tables) (void)hipFree(d_tables);
     if (d_bsk_fft) (void)hipFree(d_bsk_fft);
     if (d_fft_tables) (void)hipFree(d_fft_tables);
     d_bsk_fft = nullptr;
     d_fft_tables = nullptr;
-    d_ksk = nullptr;
     d_bsk_ntt = nullptr;
     d_tables = nullptr;
     if (stream) (void)hipStreamDestroy(stream);
@@ -125,12 +125,17 @@ int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
     HIP_TRY(hipSetDevice(device), "hipSetDevice");
     const size_t ksk_bytes = (size_t)BIG_N * KS_LEVEL * SMALL_CT * sizeof(uint64_t);
     const size_t bsk_ntt_doubles = (size_t)LWE_N * 4 * 2 * POLY_N;
-    if (!d_ksk) HIP_TRY(hipMalloc(&d_ksk, ksk_bytes), "hipMalloc ksk");
     if (!d_bsk_ntt) HIP_TRY(hipMalloc(&d_bsk_ntt, bsk_ntt_doubles * sizeof(double)), "hipMalloc bsk");
-    HIP_TRY(hipMemcpy(d_ksk, ksk, ksk_bytes, hipMemcpyHostToDevice), "copy ksk");
-    if (!d_colsum4) HIP_TRY(hipMalloc(&d_colsum4, SMALL_CT * sizeof(uint64_t)), "hipMalloc colsum");
-    HIP_TRY(launch_ksk_colsum(d_ksk, d_colsum4, stream), "ksk colsum launch");
-    HIP_TRY(hipStreamSynchronize(stream), "ksk colsum");
+    {   // the KSK is only kept as byte planes in MFMA fragment order (ks_kernels.hip)
+        uint64_t *d_ksk = nullptr;
+        HIP_TRY(hipMalloc(&d_ksk, ksk_bytes), "hipMalloc ksk staging");
+        hipError_t e = hipMemcpy(d_ksk, ksk, ksk_bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess && !d_ksk_planes) e = hipMalloc(&d_ksk_planes, ks_planes_bytes());
+        if (e == hipSuccess) e = launch_ksk_to_planes(d_ksk, d_ksk_planes, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_ksk);
+        HIP_TRY(e, "ksk -> byte planes");
+    }
     {
         std::vector<double> host(bsk_ntt_doubles);
         unsigned hc = std::thread::hardware_concurrency();
@@ -192,6 +197,18 @@ int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
     return 0;
 }
 
+int Context::keyswitch(const uint64_t *d_in, size_t B, hipStream_t s) {
+    if (dig_buf.cap < ks_digits_bytes((int)B)) {
+        HIP_TRY(hipStreamSynchronize(s), "sync");
+        HIP_TRY(dig_buf.reserve(ks_digits_bytes((int)B)), "hipMalloc digits");
+    }
+    timer.begin(1, B, s);
+    hipError_t e = launch_keyswitch_mfma(d_in, d_ksk_planes, dig_buf.as<int8_t>(), ks_buf.as<uint64_t>(), (int)B, s);
+    timer.end(s);
+    if (e != hipSuccess) return hip_fail(e, "keyswitch launch");
+    return 0;
+}
+
 int Context::set_arithmetic(int mode) {
     if (mode != 0 && mode != 1) return fail(-1, "unknown arithmetic mode");
     if (mode == 1 && key_loaded && !d_bsk_fft)
@@ -230,9 +247,7 @@ int Context::pbs_batch_device(const uint64_t *d_in, const uint32_t *d_lut_idx, c
     if (B == 0) return 0;
     if (B > (size_t)1 << 24) return fail(-1, "batch too large");
     HIP_TRY(ks_buf.reserve(B * SMALL_CT * sizeof(uint64_t)), "hipMalloc ks");
-    timer.begin(1, B, s);
-    HIP_TRY(launch_keyswitch(d_in, d_ksk, d_colsum4, ks_buf.as<uint64_t>(), (int)B, s), "keyswitch launch");
-    timer.end(s);
+    if (int rc = keyswitch(d_in, B, s)) return rc;
     if (int rc = blind_rotate(ks_buf.as<uint64_t>(), d_lut_idx, d_luts, d_out, nullptr, B, s)) return rc;
     return 0;
 }
@@ -268,8 +283,7 @@ int Context::ks_ms_batch_host(const uint64_t *in, uint32_t *ms_out, size_t B) {
     HIP_TRY(ms_buf.reserve(B * SMALL_CT * 4), "hipMalloc");
     HIP_TRY(ks_buf.reserve(B * SMALL_CT * 8), "hipMalloc");
     HIP_TRY(hipMemcpyAsync(in_buf.ptr, in, B * BIG_CT * 8, hipMemcpyHostToDevice, stream), "H2D");
-    HIP_TRY(launch_keyswitch(in_buf.as<uint64_t>(), d_ksk, d_colsum4, ks_buf.as<uint64_t>(), (int)B, stream),
-            "keyswitch launch");
+    if (int rc = keyswitch(in_buf.as<uint64_t>(), B, stream)) return rc;
     HIP_TRY(launch_modswitch(ks_buf.as<uint64_t>(), ms_buf.as<uint32_t>(), (int)B, stream), "modswitch launch");
     HIP_TRY(hipMemcpyAsync(ms_out, ms_buf.ptr, B * SMALL_CT * 4, hipMemcpyDeviceToHost, stream), "D2H");
     HIP_TRY(hipStreamSynchronize(stream), "sync");

@@ -46,8 +46,7 @@ class Context {
     bool key_loaded = false;
 
     // key material on device
-    uint64_t *d_ksk = nullptr;
-    uint64_t *d_colsum4 = nullptr;   // 4 * column sums of the KSK (biased-digit correction)
+    int8_t *d_ksk_planes = nullptr;  // KSK as 8 byte planes in MFMA fragment order (ks_kernels.hip)
     double *d_bsk_ntt = nullptr;
     double *d_tables = nullptr;   // fwd_uni | fwd_lane | inv_uni | inv_lane
     NttTables tw{};
@@ -59,11 +58,14 @@ class Context {
     double *d_bsk_fft = nullptr;
     double *d_fft_tables = nullptr;   // lanetab[12][64]
     int set_arithmetic(int mode);
+    // keyswitch of a dense batch into ks_buf (timed as kernel kind 1); ks_buf must hold B rows
+    int keyswitch(const uint64_t *d_in, size_t B, hipStream_t s);
     // blind rotation in the selected arithmetic (timed as kernel kind 0)
     int blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const uint64_t *d_luts, uint64_t *d_out,
                      uint64_t *const *d_out_ptrs, size_t B, hipStream_t s);
 
     // scratch
+    DevBuf dig_buf;                  // keyswitch digits of the current batch
     DevBuf ks_buf, ms_buf, in_buf, out_buf, lutidx_buf, luts_buf;
     KernelTimer timer;
 

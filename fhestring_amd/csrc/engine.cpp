@@ -316,11 +316,7 @@ int Engine::exec_level(size_t k, size_t lo, size_t hi, uint64_t *dense_out) {
     uint64_t *const *d_out = reinterpret_cast<uint64_t *const *>(dp + plan_.off_out) + lp.first + lo;
     hipError_t e = launch_lincomb(d_desc, d_terms, batch_in_.as<uint64_t>(), (int)cnt, ctx.stream);
     if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
-    ctx.timer.begin(1, cnt, ctx.stream);
-    e = launch_keyswitch(batch_in_.as<uint64_t>(), ctx.d_ksk, ctx.d_colsum4, ctx.ks_buf.as<uint64_t>(), (int)cnt,
-                         ctx.stream);
-    ctx.timer.end(ctx.stream);
-    if (e != hipSuccess) return ctx.hip_fail(e, "keyswitch launch");
+    if (int rc = ctx.keyswitch(batch_in_.as<uint64_t>(), cnt, ctx.stream)) return rc;
     if (int rc = ctx.blind_rotate(ctx.ks_buf.as<uint64_t>(), d_lut, d_luts_, dense_out, dense_out ? nullptr : d_out, cnt,
                                   ctx.stream))
         return rc;

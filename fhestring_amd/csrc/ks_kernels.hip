@@ -1,0 +1,156 @@
+// Keyswitch (big LWE key -> small LWE key) on the matrix cores (gfx950 only).
+//
+//   ks[ct][j] = b * [j == 742] - sum_{i < 2048, l < 5} d(ct, i, l) * KSK[i][l][j]      (mod 2^64)
+//
+// is an integer matrix product (B x 10240) x (10240 x 743) whose left entries are balanced base-8 digits
+// (d in [-4, 3]).  The 64-bit right entries are split into 8 balanced signed bytes,
+// KSK = sum_b s_b * 2^(8b) (mod 2^64, s_b in [-128, 127]), so the product becomes 8 i8 x i8 -> i32 GEMMs
+// (|S_b| <= 4 * 128 * 10240 < 2^23: no overflow) that share the digit operand, and
+// ks = body - sum_b (S_b << 8b) is exact in wrapping 64-bit arithmetic.
+// One wavefront owns a 32-ciphertext x 32-column tile for all 8 byte planes (8 x 16 accumulator registers)
+// and walks K in steps of 32 with v_mfma_i32_32x32x32_i8.  Both operands are stored in fragment order
+// ([tile][k-step][lane][16 bytes]) so that every operand load is one coalesced 1-KB access and no LDS is
+// needed; the 4 wavefronts of a workgroup share the key fragments through L1.
+// Replaces tfhe's keyswitch inside shortint::ServerKey::apply_lookup_table.
+#include "pbs_kernels.h"
+
+namespace fhs {
+
+namespace {
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int KS_K = BIG_N * KS_LEVEL;          // 10240
+constexpr int KS_STEPS = KS_K / 32;             // 320 k-steps of 32
+constexpr int KS_COL_TILES = 24;                // 24 x 32 = 768 >= 743 columns
+constexpr int KS_PLANES = 8;
+
+// byte offset of k inside a row-tile's fragment stream: [k-step][lane = 32*(k%32/16) + r][k%16]
+__device__ __forceinline__ size_t frag_off(int r, int k) {
+    return ((size_t)(k >> 5) * 64 + ((k >> 4) & 1) * 32 + r) * 16 + (k & 15);
+}
+}  // namespace
+
+// digits of a batch in fragment order: dig[tile][320][64][16]; rows >= B are zero
+__global__ __launch_bounds__(256) void ks_digits_kernel(const uint64_t *__restrict__ in, int8_t *__restrict__ dig, int B) {
+    const int ct = blockIdx.x;
+    int8_t *dst = dig + (size_t)(ct >> 5) * KS_STEPS * 1024;
+    const int r = ct & 31;
+    for (int i = threadIdx.x; i < BIG_N; i += 256) {
+        int d[KS_LEVEL];
+#pragma unroll
+        for (int l = 0; l < KS_LEVEL; l++) d[l] = 0;
+        if (ct < B) {
+            const uint64_t a = in[(size_t)ct * BIG_CT + i];
+            uint32_t v = (uint32_t)((a + (1ull << 48)) >> 49);   // closest representable on 15 bits
+#pragma unroll
+            for (int l = KS_LEVEL - 1; l >= 0; l--) {            // least significant level first
+                int x = (int)(v & 7u);
+                v >>= 3;
+                if (x >= 4) { x -= 8; v += 1; }
+                d[l] = x;
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < KS_LEVEL; l++) dst[frag_off(r, i * KS_LEVEL + l)] = (int8_t)d[l];
+    }
+}
+
+// KSK [10240][743] u64 -> planes[8][24 col tiles][320][64][16] balanced signed bytes (columns >= 743 are zero)
+__global__ __launch_bounds__(256) void ksk_to_planes_kernel(const uint64_t *__restrict__ ksk, int8_t *__restrict__ planes) {
+    const int k = blockIdx.x;                    // 0..10239
+    for (int j = threadIdx.x; j < KS_COL_TILES * 32; j += 256) {
+        uint64_t w = j < SMALL_CT ? ksk[(size_t)k * SMALL_CT + j] : 0;
+        const size_t off = (size_t)(j >> 5) * KS_STEPS * 1024 + frag_off(j & 31, k);
+#pragma unroll
+        for (int b = 0; b < KS_PLANES; b++) {
+            const int8_t s = (int8_t)(w & 0xff);
+            w = (w - (uint64_t)(int64_t)s) >> 8;     // exact: the low byte is cleared before the shift
+            planes[(size_t)b * KS_COL_TILES * KS_STEPS * 1024 + off] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void keyswitch_mfma_kernel(const int8_t *__restrict__ dig, const int8_t *__restrict__ planes,
+                                                             const uint64_t *__restrict__ in, uint64_t *__restrict__ ks_out,
+                                                             int B, int steps_per_split) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    // the 4 wavefronts of a workgroup take 4 ciphertext tiles of the SAME column tile: the 8 key-byte
+    // fragments (8 KB per k-step, the heavy stream) are then shared through L1, the digit fragments are not
+    const int tile = blockIdx.x * 4 + wave;                // 32 ciphertexts
+    const int cg = blockIdx.y;                             // 32 columns
+    const v4i *ap = reinterpret_cast<const v4i *>(dig + (size_t)tile * KS_STEPS * 1024) + lane;
+    const v4i *bp = reinterpret_cast<const v4i *>(planes + (size_t)cg * KS_STEPS * 1024) + lane;
+    constexpr size_t PLANE_V4 = (size_t)KS_COL_TILES * KS_STEPS * 64;   // v4i elements per plane
+
+    v16i acc[KS_PLANES];
+#pragma unroll
+    for (int b = 0; b < KS_PLANES; b++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[b][e] = 0;
+
+    // split-K over gridDim.z (small batches): partial sums are combined with 64-bit atomics on a zeroed output
+    const int ks0 = blockIdx.z * steps_per_split, ks1 = ks0 + steps_per_split;
+    v4i a = ap[(size_t)ks0 * 64];
+    v4i bb[KS_PLANES];
+#pragma unroll
+    for (int b = 0; b < KS_PLANES; b++) bb[b] = bp[b * PLANE_V4 + (size_t)ks0 * 64];
+    for (int ks = ks0; ks < ks1; ks++) {
+        const int nx = ks + 1 < ks1 ? ks + 1 : ks;         // last step reloads itself (keeps the loop branch-free)
+        const v4i a_n = ap[(size_t)nx * 64];
+        v4i b_n[KS_PLANES];
+#pragma unroll
+        for (int b = 0; b < KS_PLANES; b++) b_n[b] = bp[b * PLANE_V4 + (size_t)nx * 64];
+#pragma unroll
+        for (int b = 0; b < KS_PLANES; b++) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bb[b], acc[b], 0, 0, 0);
+        a = a_n;
+#pragma unroll
+        for (int b = 0; b < KS_PLANES; b++) bb[b] = b_n[b];
+    }
+
+    // C/D layout of the 32x32 shapes: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int col = cg * 32 + (lane & 31);
+    if (col >= SMALL_CT) return;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int ct = tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (ct >= B) continue;
+        uint64_t v = 0;
+#pragma unroll
+        for (int b = 0; b < KS_PLANES; b++) v += (uint64_t)(int64_t)acc[b][e] << (8 * b);
+        uint64_t o = (uint64_t)0 - v;
+        if (col == LWE_N && blockIdx.z == 0) o += in[(size_t)ct * BIG_CT + BIG_N];
+        if (gridDim.z == 1) ks_out[(size_t)ct * SMALL_CT + col] = o;
+        else atomicAdd(reinterpret_cast<unsigned long long *>(ks_out + (size_t)ct * SMALL_CT + col), (unsigned long long)o);
+    }
+}
+
+size_t ks_planes_bytes() { return (size_t)KS_PLANES * KS_COL_TILES * KS_STEPS * 1024; }
+size_t ks_digits_bytes(int B) { return (size_t)((B + 127) / 128) * 4 * KS_STEPS * 1024; }   // whole groups of 4 tiles
+
+hipError_t launch_ksk_to_planes(const uint64_t *d_ksk, int8_t *d_planes, hipStream_t s) {
+    hipLaunchKernelGGL(ksk_to_planes_kernel, dim3(KS_K), dim3(256), 0, s, d_ksk, d_planes);
+    return hipGetLastError();
+}
+
+hipError_t launch_keyswitch_mfma(const uint64_t *d_in, const int8_t *d_planes, int8_t *d_dig, uint64_t *d_ks_out, int B,
+                                 hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    const int tiles = (B + 31) / 32;
+    hipLaunchKernelGGL(ks_digits_kernel, dim3(((tiles + 3) / 4) * 128), dim3(256), 0, s, d_in, d_dig, B);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int splits = 1;                                   // fill the 256 CUs when the batch is small
+    const int tgroups = (tiles + 3) / 4;
+    while (splits < 16 && tgroups * KS_COL_TILES * splits < 256) splits *= 2;
+    if (splits > 1) {
+        e = hipMemsetAsync(d_ks_out, 0, (size_t)B * SMALL_CT * 8, s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(keyswitch_mfma_kernel, dim3(tgroups, KS_COL_TILES, splits), dim3(256), 0, s, d_dig, d_planes,
+                       d_in, d_ks_out, B, KS_STEPS / splits);
+    return hipGetLastError();
+}
+
+}  // namespace fhs

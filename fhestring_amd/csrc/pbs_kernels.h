@@ -76,9 +76,12 @@ hipError_t launch_blind_rotate_fft(const BlindRotateFftParams &p, hipStream_t s)
 hipError_t launch_bsk_to_fft(const uint64_t *d_bsk_std, double *d_out, const double *d_lanetab, hipStream_t s);
 // the scalar twiddle literals baked into fft_kernels.hip: W[16] (index 1 and even indices used), U[3]
 void fft_uniform_consts(double *w_re, double *w_im, double *u_re, double *u_im);
-hipError_t launch_ksk_colsum(const uint64_t *d_ksk, uint64_t *d_colsum4 /*[743]*/, hipStream_t s);
-hipError_t launch_keyswitch(const uint64_t *d_in /*[B][2049]*/, const uint64_t *d_ksk, const uint64_t *d_colsum4,
-                            uint64_t *d_ks_out /*[B][743]*/, int B, hipStream_t s);
+// matrix-core keyswitch (ks_kernels.hip): KSK as 8 planes of balanced signed bytes in MFMA fragment order
+size_t ks_planes_bytes();
+size_t ks_digits_bytes(int B);
+hipError_t launch_ksk_to_planes(const uint64_t *d_ksk, int8_t *d_planes, hipStream_t s);
+hipError_t launch_keyswitch_mfma(const uint64_t *d_in /*[B][2049]*/, const int8_t *d_planes, int8_t *d_dig /*scratch*/,
+                                 uint64_t *d_ks_out /*[B][743]*/, int B, hipStream_t s);
 hipError_t launch_modswitch(const uint64_t *d_ks, uint32_t *d_ms /*[B][743]*/, int B, hipStream_t s);
 hipError_t launch_lincomb(const LinDesc *d_desc, const LinTerm *d_terms, uint64_t *d_out /*[n][2049]*/,
                           int n, hipStream_t s);

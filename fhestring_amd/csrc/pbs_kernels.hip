@@ -415,92 +415,8 @@ hipError_t launch_blind_rotate(const BlindRotateParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------
-// keyswitch (big key -> small key):  ks[ct][j] = b*[j==742] - sum_{i,l} d(ct,i,l) * KSK[i][l][j]
-// A (B x 10240) x (10240 x 743) product with 3-bit digits and u64 wrapping accumulation.
-//  * digits are used biased, d' = d + 4 in [0,8): ks = b + 4*colsum[j] - sum d' * KSK, so the MAC is
-//    an unsigned 3-bit x 64-bit multiply-add with a wave-uniform (SGPR) multiplier;
-//  * one thread owns one output column for a tile of KS_CT_TILE ciphertexts (a streamed KSK row is
-//    reused 16x from registers), the digit tile is staged in LDS;
-//  * the 2048 mask coefficients are split over gridDim.z workgroups (split-K) whose partial sums
-//    are combined with 64-bit atomics, so small batches still fill the GPU.
-// The modulus switch to Z_4096 happens where the value is consumed (blind_rotate_kernel).
-// ------------------------------------------------------------------------------------------
-constexpr int KS_CT_TILE = 16;
-constexpr int KS_COLS = 256;
-constexpr int KS_MAX_ROWS = 512;   // rows of the mask handled by one workgroup (<= 2048 / splits)
-
-__global__ __launch_bounds__(256) void keyswitch_kernel(const uint64_t *__restrict__ in,
-                                                        const uint64_t *__restrict__ ksk,
-                                                        const uint64_t *__restrict__ colsum4,   // 4 * sum_{i,l} KSK[i][l][j]
-                                                        uint64_t *__restrict__ ks_out,          // [B][743], zeroed
-                                                        int B, int rows_per_split) {
-    __shared__ uint16_t digs[KS_CT_TILE][KS_MAX_ROWS];   // 5 biased base-8 digits, 3 bits each
-    const int ct0 = blockIdx.x * KS_CT_TILE;
-    const int col = blockIdx.y * KS_COLS + threadIdx.x;
-    const int row0 = blockIdx.z * rows_per_split;
-    const int nct = min(KS_CT_TILE, B - ct0);
-    for (int e = threadIdx.x; e < KS_CT_TILE * rows_per_split; e += 256) {
-        const int c = e / rows_per_split, i = e % rows_per_split;
-        uint16_t packed = 0x4924;   // all digits zero (biased 4 in each 3-bit field)
-        if (c < nct) {
-            const uint64_t a = in[(size_t)(ct0 + c) * BIG_CT + row0 + i];
-            uint32_t v = (uint32_t)((a + (1ull << 48)) >> 49);   // closest representable on 15 bits
-            packed = 0;
-#pragma unroll
-            for (int l = KS_LEVEL - 1; l >= 0; l--) {            // least significant level first
-                int d = (int)(v & 7u);
-                v >>= 3;
-                if (d >= 4) { d -= 8; v += 1; }
-                packed |= (uint16_t)((d + 4) << (3 * l));
-            }
-        }
-        digs[c][i] = packed;
-    }
-    __syncthreads();
-    if (col >= SMALL_CT) return;
-    uint64_t acc[KS_CT_TILE];
-#pragma unroll
-    for (int c = 0; c < KS_CT_TILE; c++) acc[c] = 0;
-    const uint64_t *kp = ksk + ((size_t)row0 * KS_LEVEL) * SMALL_CT + col;
-    for (int i = 0; i < rows_per_split; i++) {
-        uint64_t k[KS_LEVEL];
-#pragma unroll
-        for (int l = 0; l < KS_LEVEL; l++) k[l] = kp[((size_t)i * KS_LEVEL + l) * SMALL_CT];
-#pragma unroll
-        for (int c = 0; c < KS_CT_TILE; c++) {
-            const uint32_t pk = __builtin_amdgcn_readfirstlane((uint32_t)digs[c][i]);
-#pragma unroll
-            for (int l = 0; l < KS_LEVEL; l++) acc[c] += (uint64_t)((pk >> (3 * l)) & 7u) * k[l];
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < KS_CT_TILE; c++) {
-        if (c < nct) {
-            uint64_t v = (uint64_t)0 - acc[c];
-            if (blockIdx.z == 0) {
-                v += colsum4[col];
-                if (col == LWE_N) v += in[(size_t)(ct0 + c) * BIG_CT + BIG_N];
-            }
-            atomicAdd(reinterpret_cast<unsigned long long *>(ks_out + (size_t)(ct0 + c) * SMALL_CT + col),
-                      (unsigned long long)v);
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void ksk_colsum_kernel(const uint64_t *__restrict__ ksk,
-                                                         uint64_t *__restrict__ colsum4) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= SMALL_CT) return;
-    uint64_t s = 0;
-    for (int r = 0; r < BIG_N * KS_LEVEL; r++) s += ksk[(size_t)r * SMALL_CT + col];
-    colsum4[col] = s * 4;
-}
-hipError_t launch_ksk_colsum(const uint64_t *d_ksk, uint64_t *d_colsum4, hipStream_t s) {
-    hipLaunchKernelGGL(ksk_colsum_kernel, dim3((SMALL_CT + 255) / 256), dim3(256), 0, s, d_ksk, d_colsum4);
-    return hipGetLastError();
-}
-
+// keyswitch: ks_kernels.hip (matrix cores).  The modulus switch to Z_4096 happens where the value is consumed
+// (blind-rotation kernels); modswitch_kernel only serves fhs_keyswitch_modswitch_batch.
 __global__ __launch_bounds__(256) void modswitch_kernel(const uint64_t *__restrict__ ks, uint32_t *__restrict__ ms,
                                                         size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -510,21 +426,6 @@ hipError_t launch_modswitch(const uint64_t *d_ks, uint32_t *d_ms, int B, hipStre
     const size_t n = (size_t)B * SMALL_CT;
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(modswitch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_ks, d_ms, n);
-    return hipGetLastError();
-}
-
-hipError_t launch_keyswitch(const uint64_t *d_in, const uint64_t *d_ksk, const uint64_t *d_colsum4,
-                            uint64_t *d_ks_out, int B, hipStream_t s) {
-    if (B <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(d_ks_out, 0, (size_t)B * SMALL_CT * 8, s);
-    if (e != hipSuccess) return e;
-    const int tiles = (B + KS_CT_TILE - 1) / KS_CT_TILE;
-    const int colb = (SMALL_CT + KS_COLS - 1) / KS_COLS;
-    int splits = 4;                                   // rows_per_split <= KS_MAX_ROWS
-    while (splits < 64 && tiles * colb * splits < 768) splits *= 2;
-    dim3 grid(tiles, colb, splits);
-    hipLaunchKernelGGL(keyswitch_kernel, grid, dim3(256), 0, s, d_in, d_ksk, d_colsum4, d_ks_out, B,
-                       BIG_N / splits);
     return hipGetLastError();
 }
 
