@@ -168,7 +168,7 @@ def main():
     def step():
         k = step_no[0] % P
         step_no[0] += 1
-        outs = [jobs[k].run(sh, pattern, op=args.op) for sh in shard_sets[k]]
+        outs = jobs[k].run_batch(shard_sets[k], pattern, op=args.op)   # N > 1: one stream-ordered all-gather
         sks[k].flush(wait=(P == 1))          # P > 1: enqueue only; sync() below waits for every stream
         return outs
 

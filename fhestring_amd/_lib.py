@@ -80,6 +80,10 @@ def _declare(L):
     L.fhs_download.restype = i
     L.fhs_export_device.argtypes = [vp, h, vp]
     L.fhs_export_device.restype = i
+    L.fhs_export_device_async.argtypes = [vp, h, vp]
+    L.fhs_export_device_async.restype = i
+    L.fhs_stream_handle.argtypes = [vp]
+    L.fhs_stream_handle.restype = vp
     L.fhs_set_arithmetic.argtypes = [vp, i]
     L.fhs_set_arithmetic.restype = i
     L.fhs_get_arithmetic.argtypes = [vp]

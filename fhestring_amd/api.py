@@ -366,6 +366,13 @@ class MyServerKey:
         self.flush()
         self.ctx._check(self.ctx._L.fhs_export_device(self.ctx._h, ch.h, C.c_void_p(d_ptr)))
 
+    def export_device_async(self, ch, d_ptr):
+        """Stream-ordered export (no host wait); pair with stream_handle() to order foreign work after it."""
+        self.ctx._check(self.ctx._L.fhs_export_device_async(self.ctx._h, ch.h, C.c_void_p(d_ptr)))
+
+    def stream_handle(self):
+        return int(self.ctx._L.fhs_stream_handle(self.ctx._h) or 0)
+
     def flush(self, wait=True):
         """Run every pending PBS level.  wait=False only enqueues the launches (fhs_flush_async)."""
         if getattr(self, "_dist", None) is not None:

@@ -149,6 +149,17 @@ int fhs_export_device(fhs_ctx *c, fhs_char_t a, uint64_t *d_blocks) {
     return FHS_OK;
 }
 
+int fhs_export_device_async(fhs_ctx *c, fhs_char_t a, uint64_t *d_blocks) {
+    if (!ok(c, a) || !d_blocks) return bad(c);
+    const Bid *b = c->eng.char_blocks(a);
+    for (int i = 0; i < 4; i++) {
+        int rc = c->eng.copy_block_to_device(b[i], d_blocks + (size_t)i * FHS_BIG_CT, false);
+        if (rc) return rc;
+    }
+    return FHS_OK;
+}
+void *fhs_stream_handle(fhs_ctx *c) { return c ? reinterpret_cast<void *>(c->eng.ctx.stream) : nullptr; }
+
 int fhs_set_mode(fhs_ctx *c, int mode) {
     if (!c || (mode != FHS_MODE_AS_WRITTEN && mode != FHS_MODE_FUSED)) return bad(c);
     c->eng.mode = mode;

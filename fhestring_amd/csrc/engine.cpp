@@ -391,22 +391,24 @@ int Engine::read_block(Bid b, uint64_t *host_out) {
     return 0;
 }
 
-int Engine::copy_block_to_device(Bid b, uint64_t *d_out) {
+int Engine::copy_block_to_device(Bid b, uint64_t *d_out, bool wait) {
     (void)hipSetDevice(ctx.device);
     int rc = flush();
     if (rc) return rc;
     hipError_t e;
     if (nodes_[b].kind == BlockNode::TRIV) {
-        e = hipMemsetAsync(d_out, 0, BIG_CT * 8, ctx.stream);
+        // body = triv << 59: only its high word is non-zero, written by a 32-bit memset (no host buffer in flight)
         const uint64_t body = (uint64_t)nodes_[b].triv << DELTA_LOG;
-        if (e == hipSuccess) e = hipMemcpyAsync(d_out + BIG_N, &body, 8, hipMemcpyHostToDevice, ctx.stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx.stream);
+        e = hipMemsetAsync(d_out, 0, BIG_CT * 8, ctx.stream);
+        if (e == hipSuccess)
+            e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(reinterpret_cast<uint32_t *>(d_out + BIG_N) + 1),
+                                  (int)(uint32_t)(body >> 32), 1, ctx.stream);
     } else {
         if (nodes_[b].kind == BlockNode::LIN && (rc = materialize_lin(b))) return rc;
         if (nodes_[b].kind != BlockNode::MAT) return ctx.fail(-3, "internal: block not materialised");
         e = hipMemcpyAsync(d_out, nodes_[b].dev, BIG_CT * 8, hipMemcpyDeviceToDevice, ctx.stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx.stream);
     }
+    if (e == hipSuccess && wait) e = hipStreamSynchronize(ctx.stream);
     if (e != hipSuccess) return ctx.hip_fail(e, "export");
     return 0;
 }

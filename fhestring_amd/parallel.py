@@ -71,6 +71,36 @@ class ShardedContains:
         return sk.flags_or(parts)
 
 
+    def run_batch(self, shards, clear_pattern, op="contains", force_exchange=False):
+        """contains() on several independent strings with ONE exchange: the local flags of all strings are
+        evaluated in one DAG flush, exported stream-ordered, gathered with one all-gather of len(shards) chars per
+        rank issued on the context's own HIP stream (no host synchronisation anywhere, so consecutive batches on
+        different contexts overlap), and OR-ed in one level."""
+        sk = self.sk
+        if (self.world == 1 and not force_exchange) or op != "contains":   # force_exchange: 1-rank RCCL test
+            return [self.run(sh, clear_pattern, op=op) for sh in shards]
+        torch = self.torch
+        if not (torch.cuda.is_available() and sk.device_resident and self.dist.get_backend() == "nccl"):
+            return [self.run(sh, clear_pattern, op=op) for sh in shards]   # host-staged path (tests)
+        n = len(shards)
+        local = [sk.contains_clear(sh, clear_pattern) if len(sh) >= len(clear_pattern) else sk.trivial(0)
+                 for sh in shards]
+        if getattr(self, "_ext", None) is None:
+            self._ext = torch.cuda.ExternalStream(sk.stream_handle())
+        with torch.cuda.stream(self._ext):
+            mine = torch.empty(n * CHAR_WORDS, dtype=torch.int64, device="cuda")
+            allp = torch.empty(self.world * n * CHAR_WORDS, dtype=torch.int64, device="cuda")
+            for k, l in enumerate(local):
+                sk.export_device_async(l, mine.data_ptr() + 8 * CHAR_WORDS * k)    # first call flushes the DAG
+            self.dist.all_gather_into_tensor(allp, mine)   # RCCL over xGMI: world x n x 65 568 B, stream-ordered
+        outs = []
+        for k in range(n):
+            parts = [sk.import_device(allp.data_ptr() + 8 * CHAR_WORDS * (r * n + k)) for r in range(self.world)]
+            outs.append(sk.flags_or(parts))
+        self._keep = (mine, allp)      # device buffers stay referenced until the next batch replaces them
+        return outs
+
+
 class LevelParallel:
     """Generic multi-GPU execution of ANY op: the ranks hold the same ciphertexts, record the same DAG
     and split every PBS level; one all-gather of the level's outputs (width x 16 392 B) per level.

@@ -115,6 +115,11 @@ int fhs_flush_async(fhs_ctx *ctx);
 int fhs_download(fhs_ctx *ctx, fhs_char_t a, uint64_t *blocks /*[4][2049]*/);
 /* device-to-device import/export of one char (multi-GPU gather of partial results) */
 int fhs_export_device(fhs_ctx *ctx, fhs_char_t a, uint64_t *d_blocks /*[4][2049] device*/);
+/* Stream-ordered variant: flushes asynchronously and enqueues the copies on the context's stream, no host wait.
+ * fhs_stream_handle returns that hipStream_t so a caller can order its own work (e.g. an RCCL all-gather issued
+ * under torch.cuda.ExternalStream) after the export and before a following fhs_import_device. */
+int fhs_export_device_async(fhs_ctx *ctx, fhs_char_t a, uint64_t *d_blocks /*[4][2049] device*/);
+void *fhs_stream_handle(fhs_ctx *ctx);
 fhs_char_t fhs_import_device(fhs_ctx *ctx, const uint64_t *d_blocks);
 
 /* ---- MyServerKey string methods (src/server_key/mod.rs, trim.rs) --------------

@@ -85,3 +85,48 @@ def test_level_parallel_two_ranks_one_gpu(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
     rcs = [p.wait(timeout=900) for p in procs]
     assert rcs == [0, 0]
+
+
+RCCL_WORKER = r'''
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["FHS_ROOT"])
+from fhestring_amd.api import MyClientKey, MyServerKey
+from fhestring_amd.parallel import ShardedContains
+
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+ck = MyClientKey(0xF5E57121)
+sks = [MyServerKey.from_client_key(ck, 0, arith=1) for _ in range(2)]      # two pipelines, like bench.py
+strings = ["the quick brown fox jumps over", "a lazy dog sleeps under the sun", "abcabcabcabdabcabcabcabdabcabc"]
+pat = "n fo"
+jobs, shards = [], []
+for sk in sks:
+    sk.set_mode(1)
+    jobs.append(ShardedContains(sk, 0, 1, dist, torch))
+    shards.append([jobs[-1].upload_shard(ck, s, len(s), len(pat)) for s in strings])
+    sk.flush()
+outs = []
+for step in range(4):                       # nothing below waits on the host until the final synchronize
+    k = step % 2
+    outs.append(jobs[k].run_batch(shards[k], pat, force_exchange=True))
+    sks[k].flush(wait=False)
+torch.cuda.synchronize()
+ok = all([ck.decrypt_char(o) for o in res] == [int(pat in s) for s in strings] for res in outs)
+dist.barrier()
+dist.destroy_process_group()
+for sk in sks:
+    sk.close()
+sys.exit(0 if ok else 3)
+'''
+
+
+def test_stream_ordered_rccl_exchange_one_rank(tmp_path):
+    """The N>1 bench path (export -> RCCL all-gather on the context's own HIP stream -> import -> OR, pipelined
+    over two contexts without any host wait) with a 1-rank nccl group: the most of it one GPU can exercise."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, FHS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="1", RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.Popen([sys.executable, str(script)], env=env)
+    assert p.wait(timeout=500) == 0
