@@ -120,8 +120,12 @@ __device__ __forceinline__ cplx *slotC(double *lds, int lane) { return reinterpr
 // per-lane twiddle bases: rows (re, im) x {B: G=1,2,4,8; C: G=4,8}
 struct LaneTw { double re[6], im[6]; };
 __device__ __forceinline__ void load_lane_tw(LaneTw &t, const double *__restrict__ lanetab, int lane) {
+    // global address space spelled out: after the opaque asm in the caller the pointer would otherwise be generic
+    // and the loads flat (which also count on the LDS counter)
+    typedef const __attribute__((address_space(1))) double *gptr_t;
+    gptr_t g = (gptr_t)lanetab;
 #pragma unroll
-    for (int k = 0; k < 6; k++) { t.re[k] = lanetab[(2 * k) * 64 + lane]; t.im[k] = lanetab[(2 * k + 1) * 64 + lane]; }
+    for (int k = 0; k < 6; k++) { t.re[k] = g[(2 * k) * 64 + lane]; t.im[k] = g[(2 * k + 1) * 64 + lane]; }
 }
 
 // forward: z[r] = point (lane + 64 r)  ->  z[c] = value at array index 16*lane + c
@@ -194,12 +198,14 @@ __device__ __forceinline__ void fft_inverse(cplx (&z)[16], double *lds, int lane
     stages_uniform<true>(z);
 }
 
-// floor(v) mod 2^64 of a double of any magnitude (v is integral whenever |v| >= 2^52)
-__device__ __forceinline__ uint64_t to_torus(double v) {
-    const double f = __builtin_amdgcn_fract(v * 0x1p-64);      // in [0, 1), exact (clamped below 1)
-    const double h = f * 0x1p32;                               // exact
+// floor(v) mod 2^64 of a double of any magnitude (v is integral whenever |v| >= 2^52).
+// c64 = 2^-64 and c32 = 2^32 arrive in scalar registers the compiler cannot see through: a literal power of two
+// becomes v_ldexp_f64, which issues slower than the v_mul_f64 it replaces.
+__device__ __forceinline__ uint64_t to_torus(double v, double c64, double c32) {
+    const double f = __builtin_amdgcn_fract(v * c64);          // in [0, 1), exact (clamped below 1)
+    const double h = f * c32;                                  // exact
     const uint32_t hi = (uint32_t)h;                           // truncation = floor
-    const uint32_t lo = (uint32_t)(__builtin_amdgcn_fract(h) * 0x1p32);
+    const uint32_t lo = (uint32_t)(__builtin_amdgcn_fract(h) * c32);
     return ((uint64_t)hi << 32) | lo;
 }
 
@@ -215,6 +221,8 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
     uint64_t *my_u = reinterpret_cast<uint64_t *>(my);
 
     const uint64_t *ks = P.ks + (size_t)ct * SMALL_CT;
+    double c64 = 0x1p-64, c32 = 0x1p32;
+    asm volatile("" : "+s"(c64), "+s"(c32));
 
     // acc[r] = coefficient (lane + 64 r) of polynomial j (u64 torus); registers r and r+16 form one complex point
     uint64_t acc[32];
@@ -323,9 +331,9 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
         // burst overlaps the conversions instead of stalling the start of the next iteration)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            acc[r] += to_torus(z[r].r);
+            acc[r] += to_torus(z[r].r, c64, c32);
             my_u[lane + 64 * r] = acc[r];
-            acc[r + 16] += to_torus(z[r].i);
+            acc[r + 16] += to_torus(z[r].i, c64, c32);
             my_u[lane + 64 * (r + 16)] = acc[r + 16];
         }
     }
