@@ -177,8 +177,10 @@ int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
             for (int k = 0; k < 3; k++) ok = ok && ur[k] == ft.u_re[k] && ui[k] == ft.u_im[k];
             if (!ok) return fail(-3, "fft_consts.inc does not match the libm-derived twiddles (regenerate it)");
         }
-        if (!d_fft_tables) HIP_TRY(hipMalloc(&d_fft_tables, ft.lanetab.size() * sizeof(double)), "hipMalloc fft tables");
-        HIP_TRY(hipMemcpy(d_fft_tables, ft.lanetab.data(), ft.lanetab.size() * sizeof(double), hipMemcpyHostToDevice),
+        std::vector<double> flat(ft.lanetab);
+        flat.insert(flat.end(), ft.weff.begin(), ft.weff.end());
+        if (!d_fft_tables) HIP_TRY(hipMalloc(&d_fft_tables, flat.size() * sizeof(double)), "hipMalloc fft tables");
+        HIP_TRY(hipMemcpy(d_fft_tables, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice),
                 "copy fft tables");
         const size_t n = (size_t)LWE_N * 4 * POLY_N;   // 1024 complex (2048 doubles) per polynomial
         if (!d_bsk_fft) HIP_TRY(hipMalloc(&d_bsk_fft, n * sizeof(double)), "hipMalloc bsk fft");
@@ -227,8 +229,11 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
         p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;
         p.bsk_fft = d_bsk_fft;
         p.lanetab = d_fft_tables;
+        p.weff = d_fft_tables + 12 * 64;
         p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
-        e = launch_blind_rotate_fft(p, s);
+        static const int force = getenv("FHS_FFT_WAVES") ? atoi(getenv("FHS_FFT_WAVES")) : 0;
+        const bool four = force ? force == 4 : B <= (size_t)fft4_max_batch;
+        e = four ? launch_blind_rotate_fft4(p, s) : launch_blind_rotate_fft(p, s);
     } else {
         BlindRotateParams p{};
         p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;

@@ -56,7 +56,8 @@ class Context {
     // Select before load_server_key: the Fourier-domain key is only built when the mode asks for it.
     int arith = 0;
     double *d_bsk_fft = nullptr;
-    double *d_fft_tables = nullptr;   // lanetab[12][64]
+    double *d_fft_tables = nullptr;   // lanetab[12][64] | weff[1024][2]
+    int fft4_max_batch = 512;         // batches up to this size use the 4-wavefront kernel (lower latency)
     int set_arithmetic(int mode);
     // keyswitch of a dense batch into ks_buf (timed as kernel kind 1); ks_buf must hold B rows
     int keyswitch(const uint64_t *d_in, size_t B, hipStream_t s);

@@ -1,0 +1,306 @@
+// f64-FFT blind rotation with 4 wavefronts per ciphertext (gfx950 only).
+//
+// Same arithmetic as fft_kernels.hip (same butterflies on the same values in the same order: the CPU mirror,
+// oracle mode 3, checks both bit for bit) but each GLWE polynomial is spread over a PAIR of wavefronts, 8 complex
+// points and 16 accumulator words per lane.  Half the work per wavefront halves the latency of one PBS, which is
+// what a narrow dependency level pays, and at 128 registers per lane four wavefronts share a SIMD.
+//
+//   wave w = 2*j + h: polynomial j, half h = bit 9 of the point index n.  The first (last, for the inverse) radix-2
+//   stage t = 512 pairs the two halves and is done through one exchange in LDS; the other 9 stages are a 512-point
+//   transform inside one wavefront in three register layouts (3 index bits in the register number each):
+//     A'  n' = lane + 64 r                      stages t = 256, 128, 64  (wave-uniform twiddles)
+//     B'  n' = 64 (lane >> 3) + 8 r + (lane & 7)  stages t = 32, 16, 8
+//     C'  n' = 8 lane + r                       stages t = 4, 2, 1
+//   with two in-wave transposes through the wavefront's private 8.7 KB of LDS.
+// Per-lane twiddles come from the effective table built by fft_tables.cpp (weff): the values the 2-wavefront kernel
+// derives on the fly, so nothing is re-rounded differently here.
+#include "fft_device.h"
+
+namespace fhs {
+
+#pragma clang fp contract(off)
+
+namespace {
+using namespace fftdev;
+
+constexpr int F4_WAVE_BYTES = 8704;                 // 544 slots of 16 B per wavefront (4 x 8704 = 34 816 B per WG)
+__device__ __forceinline__ int pslot(int n) { return n + (n >> 4); }     // n < 512 -> < 544
+
+typedef const __attribute__((address_space(1))) double *gdptr_t;
+struct tw_t { double r, i; };
+__device__ __forceinline__ tw_t ld_tw(gdptr_t weff, int idx) {
+    typedef double __attribute__((ext_vector_type(2))) d2;
+    const d2 v = *reinterpret_cast<const __attribute__((address_space(1))) d2 *>(weff + 2 * idx);
+    tw_t t; t.r = v.x; t.i = v.y;
+    return t;
+}
+
+// one in-lane stage on 8 registers: distance TAU, groups of 2*TAU registers; group g uses twA (g = 0), i*twA (1),
+// twB (2), i*twB (3)
+template <bool INV, int TAU> __device__ __forceinline__ void stage8(cplx (&z)[8], tw_t a, tw_t b) {
+    constexpr int G = 4 / TAU;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const tw_t w = g < 2 ? a : b;
+#pragma unroll
+        for (int c = 2 * g * TAU; c < 2 * g * TAU + TAU; c++) {
+            if (g & 1) { if (INV) bf_inv<true>(z[c], z[c + TAU], w.r, w.i); else bf_fwd<true>(z[c], z[c + TAU], w.r, w.i); }
+            else       { if (INV) bf_inv<false>(z[c], z[c + TAU], w.r, w.i); else bf_fwd<false>(z[c], z[c + TAU], w.r, w.i); }
+        }
+    }
+}
+// the three wave-uniform stages of layout A' (every group has its own explicit twiddle, no rotation)
+template <bool INV> __device__ __forceinline__ void stagesA(cplx (&z)[8], tw_t w2, const tw_t (&w4)[2], const tw_t (&w8)[4]) {
+    if (!INV) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) bf_fwd<false>(z[r], z[r + 4], w2.r, w2.i);
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int r = 4 * g; r < 4 * g + 2; r++) bf_fwd<false>(z[r], z[r + 2], w4[g].r, w4[g].i);
+#pragma unroll
+        for (int g = 0; g < 4; g++) bf_fwd<false>(z[2 * g], z[2 * g + 1], w8[g].r, w8[g].i);
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; g++) bf_inv<false>(z[2 * g], z[2 * g + 1], w8[g].r, w8[g].i);
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int r = 4 * g; r < 4 * g + 2; r++) bf_inv<false>(z[r], z[r + 2], w4[g].r, w4[g].i);
+#pragma unroll
+        for (int r = 0; r < 4; r++) bf_inv<false>(z[r], z[r + 4], w2.r, w2.i);
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void blind_rotate_fft4_kernel(BlindRotateFftParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ct = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = w >> 1, h = w & 1;
+    cplx *mine = reinterpret_cast<cplx *>(smem + w * F4_WAVE_BYTES);
+    const cplx *pair = reinterpret_cast<const cplx *>(smem + (w ^ 1) * F4_WAVE_BYTES);     // other half, same polynomial
+    const cplx *other = reinterpret_cast<const cplx *>(smem + (w ^ 2) * F4_WAVE_BYTES);    // same half, other polynomial
+    uint64_t *stage = reinterpret_cast<uint64_t *>(smem + j * 2 * F4_WAVE_BYTES);          // 2048 words of polynomial j
+
+    const uint64_t *ks = P.ks + (size_t)ct * SMALL_CT;
+    double c64 = 0x1p-64, c32 = 0x1p32;
+    asm volatile("" : "+s"(c64), "+s"(c32));
+    const gdptr_t weff0 = (gdptr_t)P.weff;
+
+    // wave-uniform twiddles of the cross stage and of layout A' (scalar registers)
+    const tw_t w1 = ld_tw(weff0, 1), w2 = ld_tw(weff0, 2 + h);
+    const tw_t w4[2] = {ld_tw(weff0, 4 + 2 * h), ld_tw(weff0, 5 + 2 * h)};
+    const tw_t w8[4] = {ld_tw(weff0, 8 + 4 * h), ld_tw(weff0, 9 + 4 * h), ld_tw(weff0, 10 + 4 * h), ld_tw(weff0, 11 + 4 * h)};
+    const int eB = 8 * h + (lane >> 3);             // bits 9..6 of n in layout B'
+    const int eC = 64 * h + lane;                   // bits 9..3 of n in layout C'
+
+    // acc[r]: coefficient k(r) = 512 h + lane + 64 (r & 7) + 1024 (r >> 3) of polynomial j
+    const uint32_t k0 = 512 * h + lane;
+    uint64_t acc[16];
+    {
+        const uint32_t b = fft_mod_switch(ks[LWE_N]);
+        const uint32_t a = (2 * POLY_N - b) & (2 * POLY_N - 1);
+        const uint32_t s = a & (POLY_N - 1);
+        const bool neg = a >= POLY_N;
+        const uint64_t *lut = P.luts + (size_t)P.lut_idx[ct] * POLY_N;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            uint64_t v = 0;
+            if (j == 1) {
+                const uint32_t n = k0 + 64 * (r & 7) + 1024 * (r >> 3);
+                v = lut[(n - s) & (POLY_N - 1)];
+                if ((n < s) != neg) v = (uint64_t)0 - v;
+            }
+            acc[r] = v;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) stage[k0 + 64 * (r & 7) + 1024 * (r >> 3)] = acc[r];
+
+    for (int i = 0; i < LWE_N; i++) {
+        const uint32_t a = fft_mod_switch(ks[i]);
+        if (a == 0) continue;
+        const uint32_t s = a & (POLY_N - 1);
+        const bool neg = a >= POLY_N;
+        gdptr_t weff = weff0;
+        asm volatile("" : "+s"(weff));               // keep the per-lane twiddle loads inside the iteration
+
+        // ---- rotate, subtract, decompose: z[r] = digit(k(r)) + i digit(k(r) + 1024) -------------------------------
+        __syncthreads();                              // staged accumulator of both halves visible
+        cplx z[8];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t n = k0 + 64 * (r & 7) + 1024 * (r >> 3);
+            uint64_t v = stage[(n - s) & (POLY_N - 1)];
+            if ((n < s) != neg) v = (uint64_t)0 - v;
+            const uint64_t d = v - acc[r];
+            const int32_t dig = (int32_t)((uint32_t)(d >> 32) + 0x100u) >> 9;
+            if (r < 8) z[r].r = (double)dig; else z[r - 8].i = (double)dig;
+        }
+        __syncthreads();                              // all rotated reads done before the area is reused
+
+        // key rows of this iteration: own transform first (row j), then the partner polynomial's (row 1-j), column j;
+        // point n = 8 (64 h + lane) + c sits at [c16 = 8 (lane & 1) + c][L = 32 h + (lane >> 1)] of the key layout
+        typedef double __attribute__((ext_vector_type(2))) double2_t;
+        const size_t koff = (size_t)(8 * (lane & 1)) * 64 + 32 * h + (lane >> 1);
+        const double2_t *b_own = reinterpret_cast<const double2_t *>(P.bsk_fft) + ((((size_t)i * 2 + j) * 2 + j)) * FM + koff;
+        const double2_t *b_par = reinterpret_cast<const double2_t *>(P.bsk_fft) + ((((size_t)i * 2 + (1 - j)) * 2 + j)) * FM + koff;
+        constexpr int HB = 2;
+        double2_t bo[HB], bp[HB];
+#pragma unroll
+        for (int k = 0; k < HB; k++) { bo[k] = b_own[k * 64]; bp[k] = b_par[k * 64]; }
+
+        // ---- forward transform -------------------------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+        {   // stage t = 512 across the two halves: (a, b) = (lower, upper) point, this half keeps its own output
+#pragma unroll
+            for (int r = 0; r < 8; r++) mine[pslot(lane + 64 * r)] = z[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                cplx o = pair[pslot(lane + 64 * r)];
+                if (h == 0) bf_fwd<false>(z[r], o, w1.r, w1.i);      // wave-uniform branch
+                else bf_fwd<false>(o, z[r], w1.r, w1.i);
+            }
+            __syncthreads();                          // the partner has read this half's points
+        }
+        stagesA<false>(z, w2, w4, w8);
+#pragma unroll
+        for (int r = 0; r < 8; r++) mine[pslot(lane + 64 * r)] = z[r];
+        __builtin_amdgcn_wave_barrier();
+        {
+            const cplx *rd = mine + pslot(64 * (lane >> 3)) + (lane & 7);     // pslot(64 a + 8 r + b) = 68 a + 8 r + (r >> 1) + b
+#pragma unroll
+            for (int r = 0; r < 8; r++) z[r] = rd[8 * r + (r >> 1)];
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const tw_t t32 = ld_tw(weff, 16 + eB), t16 = ld_tw(weff, 32 + 2 * eB);
+            const tw_t t8a = ld_tw(weff, 64 + 4 * eB), t8b = ld_tw(weff, 64 + 4 * eB + 2);
+            stage8<false, 4>(z, t32, t32);
+            stage8<false, 2>(z, t16, t16);
+            stage8<false, 1>(z, t8a, t8b);
+        }
+        {
+            cplx *wr = mine + pslot(64 * (lane >> 3)) + (lane & 7);
+#pragma unroll
+            for (int r = 0; r < 8; r++) wr[8 * r + (r >> 1)] = z[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const cplx *rd = mine + 8 * lane + (lane >> 1);                   // pslot(8 lane + c) = 8 lane + c + (lane >> 1)
+#pragma unroll
+            for (int c = 0; c < 8; c++) z[c] = rd[c];
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const tw_t t4 = ld_tw(weff, 128 + eC), t2 = ld_tw(weff, 256 + 2 * eC);
+            const tw_t t1a = ld_tw(weff, 512 + 4 * eC), t1b = ld_tw(weff, 512 + 4 * eC + 2);
+            stage8<false, 4>(z, t4, t4);
+            stage8<false, 2>(z, t2, t2);
+            stage8<false, 1>(z, t1a, t1b);
+        }
+
+        // ---- publish, pointwise multiply-accumulate with GGSW_i -------------------------------------------------
+#pragma unroll
+        for (int c = 0; c < 8; c++) mine[c * 64 + lane] = z[c];
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int k = c % HB;
+            const cplx g = other[c * 64 + lane];
+            const double fr = z[c].r, fi = z[c].i;
+            double rr = fr * bo[k].x; rr = __builtin_fma(-fi, bo[k].y, rr);
+            rr = __builtin_fma(g.r, bp[k].x, rr); rr = __builtin_fma(-g.i, bp[k].y, rr);
+            double ii = fr * bo[k].y; ii = __builtin_fma(fi, bo[k].x, ii);
+            ii = __builtin_fma(g.r, bp[k].y, ii); ii = __builtin_fma(g.i, bp[k].x, ii);
+            z[c].r = rr; z[c].i = ii;
+            if (c + HB < 8) { bo[k] = b_own[(c + HB) * 64]; bp[k] = b_par[(c + HB) * 64]; }
+        }
+        __syncthreads();                              // the other polynomial has read this wave's transform
+        __builtin_amdgcn_s_setprio(0);
+
+        // ---- inverse transform -------------------------------------------------------------------------------
+        {
+            const tw_t t4 = ld_tw(weff, 128 + eC), t2 = ld_tw(weff, 256 + 2 * eC);
+            const tw_t t1a = ld_tw(weff, 512 + 4 * eC), t1b = ld_tw(weff, 512 + 4 * eC + 2);
+            stage8<true, 1>(z, t1a, t1b);
+            stage8<true, 2>(z, t2, t2);
+            stage8<true, 4>(z, t4, t4);
+        }
+        {
+            cplx *wr = mine + 8 * lane + (lane >> 1);
+#pragma unroll
+            for (int c = 0; c < 8; c++) wr[c] = z[c];
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const cplx *rd = mine + pslot(64 * (lane >> 3)) + (lane & 7);
+#pragma unroll
+            for (int r = 0; r < 8; r++) z[r] = rd[8 * r + (r >> 1)];
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const tw_t t32 = ld_tw(weff, 16 + eB), t16 = ld_tw(weff, 32 + 2 * eB);
+            const tw_t t8a = ld_tw(weff, 64 + 4 * eB), t8b = ld_tw(weff, 64 + 4 * eB + 2);
+            stage8<true, 1>(z, t8a, t8b);
+            stage8<true, 2>(z, t16, t16);
+            stage8<true, 4>(z, t32, t32);
+        }
+        {
+            cplx *wr = mine + pslot(64 * (lane >> 3)) + (lane & 7);
+#pragma unroll
+            for (int r = 0; r < 8; r++) wr[8 * r + (r >> 1)] = z[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; r++) z[r] = mine[pslot(lane + 64 * r)];
+        __builtin_amdgcn_wave_barrier();
+        stagesA<true>(z, w2, w4, w8);
+        {   // stage t = 512 across the two halves
+#pragma unroll
+            for (int r = 0; r < 8; r++) mine[pslot(lane + 64 * r)] = z[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                cplx o = pair[pslot(lane + 64 * r)];
+                if (h == 0) bf_inv<false>(z[r], o, w1.r, w1.i);
+                else bf_inv<false>(o, z[r], w1.r, w1.i);
+            }
+            __syncthreads();                          // the partner has read this half's points
+        }
+
+        // ---- back to the torus, update and restage the accumulator -------------------------------------------
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            acc[r] += to_torus(z[r].r, c64, c32);
+            stage[k0 + 64 * r] = acc[r];
+            acc[r + 8] += to_torus(z[r].i, c64, c32);
+            stage[k0 + 64 * r + 1024] = acc[r + 8];
+        }
+    }
+
+    uint64_t *out = P.out_ptrs ? P.out_ptrs[ct] : P.out + (size_t)ct * BIG_CT;
+    if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int n = k0 + 64 * (r & 7) + 1024 * (r >> 3);
+            if (n == 0) out[0] = acc[r];
+            else out[POLY_N - n] = (uint64_t)0 - acc[r];
+        }
+    } else if (k0 == 0) {
+        out[BIG_N] = acc[0];
+    }
+}
+
+hipError_t launch_blind_rotate_fft4(const BlindRotateFftParams &p, hipStream_t s) {
+    if (p.B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(blind_rotate_fft4_kernel, dim3(p.B), dim3(256), 4 * F4_WAVE_BYTES, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace fhs

@@ -7,6 +7,8 @@
 
 namespace fhs {
 
+#pragma clang fp contract(off)
+
 namespace {
 constexpr int FM = 1024;
 unsigned brev(unsigned x, int bits) {
@@ -40,6 +42,31 @@ void build_fft_tables(HostFftTables &t) {
         t.lanetab[9 * 64 + L] = t.w_im[256 + 4 * L];
         t.lanetab[10 * 64 + L] = t.w_re[512 + 8 * L];
         t.lanetab[11 * 64 + L] = t.w_im[512 + 8 * L];
+    }
+    // effective twiddles (see fft_tables.h)
+    t.weff.assign(2 * FM, 0.0);
+    auto put = [&](int idx, double re, double im) { t.weff[2 * idx] = re; t.weff[2 * idx + 1] = im; };
+    auto cmul = [](double ar, double ai, double wr, double wi, double &tr, double &ti) {
+        tr = std::fma(-ai, wi, ar * wr);
+        ti = std::fma(ai, wr, ar * wi);
+    };
+    put(1, t.w_re[1], t.w_im[1]);
+    for (int m = 2; m < FM; m <<= 1) {
+        // group size G: lane-uniform stages (m < 16) pair (even, odd = rotated); in-lane stages of layout B
+        // (16 <= m < 256) use G = m / 16, of layout C (m >= 256) G = m / 64
+        const int G = m < 16 ? 2 : (m < 256 ? m / 16 : m / 64);
+        for (int base = m; base < 2 * m; base += G) {
+            double vr = 0, vi = 0;
+            for (int g = 0; g < G; g++) {
+                if (g == 0) { vr = t.w_re[base]; vi = t.w_im[base]; }
+                else if (g & 1) { const double r = vr; vr = -vi; vi = r; }            // i * previous
+                else {
+                    const int u = (G == 8 && g == 4) ? 1 : (G == 8 && g == 6) ? 2 : 0;
+                    cmul(t.w_re[base], t.w_im[base], t.u_re[u], t.u_im[u], vr, vi);
+                }
+                put(base + g, vr, vi);
+            }
+        }
     }
 }
 

@@ -11,6 +11,11 @@ struct HostFftTables {
     // [12][64] per-lane bases, rows (re, im) of: layout B  W[16G + G*(lane>>2)], G = 1,2,4,8;
     //                                            layout C  W[256 + 4*lane], W[512 + 8*lane]
     std::vector<double> lanetab;
+    // [1024][2] (re, im): the EFFECTIVE twiddle of every index, i.e. exactly the value the 2-wavefront kernel
+    // uses for it: table value where it loads one, base * U where it derives one (same fma order), exact
+    // rotation by i for odd offsets.  The 4-wavefront kernel loads its per-lane twiddles from this table, which is
+    // what keeps the two kernels bit-identical.
+    std::vector<double> weff;
 };
 void build_fft_tables(HostFftTables &t);
 

@@ -51,7 +51,8 @@ struct BlindRotateFftParams {
     const uint32_t *lut_idx;
     const uint64_t *luts;
     const double *bsk_fft;    // [742][row 2][col 2][16][64 lanes][2 re,im], pre-scaled by 1/1024
-    const double *lanetab;    // [12][64] per-lane twiddle bases (fft_tables.cpp)
+    const double *lanetab;    // [12][64] per-lane twiddle bases (fft_tables.cpp), 2-wavefront kernel
+    const double *weff;       // [1024][2] effective twiddles (fft_tables.cpp), 4-wavefront kernel
     uint64_t *out;
     uint64_t *const *out_ptrs;
     int B;
@@ -71,7 +72,8 @@ struct LinTerm {
 size_t blind_rotate_lds_bytes();
 hipError_t read_device_ntt_consts(double *fwd_uni /*[64]*/, double *inv_uni /*[128]*/, double *crt);
 hipError_t launch_blind_rotate(const BlindRotateParams &p, hipStream_t s);
-hipError_t launch_blind_rotate_fft(const BlindRotateFftParams &p, hipStream_t s);
+hipError_t launch_blind_rotate_fft(const BlindRotateFftParams &p, hipStream_t s);    // 2 wavefronts per ciphertext
+hipError_t launch_blind_rotate_fft4(const BlindRotateFftParams &p, hipStream_t s);   // 4 wavefronts per ciphertext
 // standard-domain key [742*4][2048] u64 -> Fourier-domain key, with the device's own forward transform
 hipError_t launch_bsk_to_fft(const uint64_t *d_bsk_std, double *d_out, const double *d_lanetab, hipStream_t s);
 // the scalar twiddle literals baked into fft_kernels.hip: W[16] (index 1 and even indices used), U[3]
