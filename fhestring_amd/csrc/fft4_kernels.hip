@@ -74,7 +74,8 @@ template <bool INV> __device__ __forceinline__ void stagesA(cplx (&z)[8], tw_t w
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void blind_rotate_fft4_kernel(BlindRotateFftParams P) {
+// used for batches <= 512 (at most 2 workgroups per CU): aim for 2 waves per SIMD and spend registers on latency
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blind_rotate_fft4_kernel(BlindRotateFftParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ct = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -86,8 +87,6 @@ __global__ __launch_bounds__(256) void blind_rotate_fft4_kernel(BlindRotateFftPa
     uint64_t *stage = reinterpret_cast<uint64_t *>(smem + j * 2 * F4_WAVE_BYTES);          // 2048 words of polynomial j
 
     const uint64_t *ks = P.ks + (size_t)ct * SMALL_CT;
-    double c64 = 0x1p-64, c32 = 0x1p32;
-    asm volatile("" : "+s"(c64), "+s"(c32));
     const gdptr_t weff0 = (gdptr_t)P.weff;
 
     // wave-uniform twiddles of the cross stage and of layout A' (scalar registers)
@@ -118,7 +117,8 @@ __global__ __launch_bounds__(256) void blind_rotate_fft4_kernel(BlindRotateFftPa
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; r++) stage[k0 + 64 * (r & 7) + 1024 * (r >> 3)] = acc[r];
+    for (int r = 0; r < 16; r++) stage[64 + k0 + 64 * (r & 7) + 1024 * (r >> 3)] = acc[r];
+    if (h == 1) stage[lane] = acc[15];                // row 31 again in front of row 0 (see the rotated read)
 
     for (int i = 0; i < LWE_N; i++) {
         const uint32_t a = fft_mod_switch(ks[i]);
@@ -131,11 +131,17 @@ __global__ __launch_bounds__(256) void blind_rotate_fft4_kernel(BlindRotateFftPa
         // ---- rotate, subtract, decompose: z[r] = digit(k(r)) + i digit(k(r) + 1024) -------------------------------
         __syncthreads();                              // staged accumulator of both halves visible
         cplx z[8];
+        // as in fft_kernels.hip: lane rotation by s mod 64 (per-lane base), row rotation by s div 64 (scalar offset per
+        // register; this wave's register r is row 8 h + (r & 7) + 16 (r >> 3)), borrowing lanes one row lower
+        const uint32_t sl = s & 63, sh = s >> 6;
+        const bool borrow = (uint32_t)lane < sl;
+        const uint64_t *vbase = stage + (((uint32_t)lane - sl) & 63) + (borrow ? 0 : 64);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const uint32_t n = k0 + 64 * (r & 7) + 1024 * (r >> 3);
-            uint64_t v = stage[(n - s) & (POLY_N - 1)];
-            if ((n < s) != neg) v = (uint64_t)0 - v;
+            const uint32_t row = 8 * h + (r & 7) + 16 * (r >> 3);
+            uint64_t v = vbase[64 * ((row - sh) & 31)];
+            const bool wrapped = (row < sh) || (row == sh && borrow);
+            if (wrapped != neg) v = (uint64_t)0 - v;
             const uint64_t d = v - acc[r];
             const int32_t dig = (int32_t)((uint32_t)(d >> 32) + 0x100u) >> 9;
             if (r < 8) z[r].r = (double)dig; else z[r - 8].i = (double)dig;
@@ -277,10 +283,11 @@ __global__ __launch_bounds__(256) void blind_rotate_fft4_kernel(BlindRotateFftPa
         // ---- back to the torus, update and restage the accumulator -------------------------------------------
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            acc[r] += to_torus(z[r].r, c64, c32);
-            stage[k0 + 64 * r] = acc[r];
-            acc[r + 8] += to_torus(z[r].i, c64, c32);
-            stage[k0 + 64 * r + 1024] = acc[r + 8];
+            acc[r] += to_torus(z[r].r);
+            stage[64 + k0 + 64 * r] = acc[r];
+            acc[r + 8] += to_torus(z[r].i);
+            stage[64 + k0 + 64 * r + 1024] = acc[r + 8];
+            if (r == 7 && h == 1) stage[lane] = acc[15];
         }
     }
 

@@ -47,15 +47,19 @@ template <bool ROT> __device__ __forceinline__ void bf_inv(cplx &a, cplx &b, dou
     else { b.r = q.i; b.i = -q.r; }
 }
 
-// floor(v) mod 2^64 of a double of any magnitude (v is integral whenever |v| >= 2^52).
-// c64 = 2^-64 and c32 = 2^32 arrive in scalar registers the compiler cannot see through: a literal power of two
-// becomes v_ldexp_f64, which issues slower than the v_mul_f64 it replaces.
-__device__ __forceinline__ uint64_t to_torus(double v, double c64, double c32) {
-    const double f = __builtin_amdgcn_fract(v * c64);          // in [0, 1), exact (clamped below 1)
-    const double h = f * c32;                                  // exact
-    const uint32_t hi = (uint32_t)h;                           // truncation = floor
-    const uint32_t lo = (uint32_t)(__builtin_amdgcn_fract(h) * c32);
-    return ((uint64_t)hi << 32) | lo;
+// Torus value (mod 2^64) of t * 2^64, where t is the inverse transform's output: the Fourier-domain key carries
+// the factor 2^-64 (beside 1/1024), so the accumulator increment is the fractional part of t.  fract is exact;
+// 1 + f puts that fraction into the 52 mantissa bits of a double in [1, 2] (one rounding at 2^-52, i.e. 2^12 torus
+// units, far below the noise), which two 32-bit shifts move to the top of the 64-bit word.
+__device__ __forceinline__ uint64_t to_torus(double t) {
+    const double g = 1.0 + __builtin_amdgcn_fract(t);
+    const uint64_t b = __builtin_bit_cast(uint64_t, g);
+    typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+    const u32x2 w = __builtin_bit_cast(u32x2, b);
+    u32x2 o;
+    o.x = w.x << 12;
+    o.y = __builtin_amdgcn_alignbit(w.y, w.x, 20);
+    return __builtin_bit_cast(uint64_t, o);                    // (b << 12) mod 2^64
 }
 
 }  // namespace fftdev

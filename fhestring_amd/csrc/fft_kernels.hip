@@ -173,8 +173,6 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
     uint64_t *my_u = reinterpret_cast<uint64_t *>(my);
 
     const uint64_t *ks = P.ks + (size_t)ct * SMALL_CT;
-    double c64 = 0x1p-64, c32 = 0x1p32;
-    asm volatile("" : "+s"(c64), "+s"(c32));
 
     // acc[r] = coefficient (lane + 64 r) of polynomial j (u64 torus); registers r and r+16 form one complex point
     uint64_t acc[32];
@@ -197,7 +195,8 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
     }
 
 #pragma unroll
-    for (int r = 0; r < 32; r++) my_u[lane + 64 * r] = acc[r];
+    for (int r = 0; r < 32; r++) my_u[64 + lane + 64 * r] = acc[r];
+    my_u[lane] = acc[31];                             // row 31 again in front of row 0 (see the rotated read)
     for (int i = 0; i < LWE_N; i++) {
         const uint32_t a = fft_mod_switch(ks[i]);
         if (a == 0) continue;
@@ -217,12 +216,17 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
         // rotate, subtract, decompose; fold: z[r] = digit[r] + i * digit[r + 16]
         cplx z[16];
         __builtin_amdgcn_wave_barrier();
+        // coefficient n = lane + 64 r comes from m = (n - s) mod 2048: a lane rotation by s mod 64 (one per-lane base
+        // address) and a row rotation by s div 64 (a scalar offset per register); lanes that borrow read one row
+        // lower, which for row 0 is the copy of row 31 kept in front of it.  The sign flips where the index wrapped.
+        const uint32_t sl = s & 63, sh = s >> 6;
+        const bool borrow = (uint32_t)lane < sl;
+        const uint64_t *vbase = my_u + (((uint32_t)lane - sl) & 63) + (borrow ? 0 : 64);
 #pragma unroll
         for (int r = 0; r < 32; r++) {
-            const uint32_t n = lane + 64 * r;
-            const uint32_t m = (n - s) & (POLY_N - 1);
-            uint64_t v = my_u[m];
-            if ((n < s) != neg) v = (uint64_t)0 - v;
+            uint64_t v = vbase[64 * ((r - sh) & 31)];
+            const bool wrapped = ((uint32_t)r < sh) || ((uint32_t)r == sh && borrow);
+            if (wrapped != neg) v = (uint64_t)0 - v;
             const uint64_t d = v - acc[r];
             const int32_t dig = (int32_t)((uint32_t)(d >> 32) + 0x100u) >> 9;
             if (r < 16) z[r].r = (double)dig; else z[r - 16].i = (double)dig;
@@ -283,10 +287,11 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
         // burst overlaps the conversions instead of stalling the start of the next iteration)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            acc[r] += to_torus(z[r].r, c64, c32);
-            my_u[lane + 64 * r] = acc[r];
-            acc[r + 16] += to_torus(z[r].i, c64, c32);
-            my_u[lane + 64 * (r + 16)] = acc[r + 16];
+            acc[r] += to_torus(z[r].r);
+            my_u[64 + lane + 64 * r] = acc[r];
+            acc[r + 16] += to_torus(z[r].i);
+            my_u[64 + lane + 64 * (r + 16)] = acc[r + 16];
+            if (r == 15) my_u[lane] = acc[31];
         }
     }
 
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
 }
 
 // Bootstrapping key -> Fourier domain with the device's own forward transform: one wavefront per polynomial.
-// in: [742*4][2048] u64 standard domain;  out: [742*4][16][64 lanes][2], pre-scaled by 1/1024
+// in: [742*4][2048] u64 standard domain;  out: [742*4][16][64 lanes][2], pre-scaled by 2^-74 (1/1024 for the transform pair, 2^-64 for the torus conversion)
 __global__ __launch_bounds__(64) void bsk_to_fft_kernel(const uint64_t *__restrict__ bsk_std, double *__restrict__ out,
                                                         const double *__restrict__ lanetab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -326,8 +331,8 @@ __global__ __launch_bounds__(64) void bsk_to_fft_kernel(const uint64_t *__restri
     double *dst = out + (size_t)blockIdx.x * 2 * FM;
 #pragma unroll
     for (int c = 0; c < 16; c++) {
-        dst[(c * 64 + lane) * 2 + 0] = z[c].r * 0x1p-10;
-        dst[(c * 64 + lane) * 2 + 1] = z[c].i * 0x1p-10;
+        dst[(c * 64 + lane) * 2 + 0] = z[c].r * 0x1p-74;
+        dst[(c * 64 + lane) * 2 + 1] = z[c].i * 0x1p-74;
     }
 }
 

@@ -50,7 +50,7 @@ struct BlindRotateFftParams {
     const uint64_t *ks;
     const uint32_t *lut_idx;
     const uint64_t *luts;
-    const double *bsk_fft;    // [742][row 2][col 2][16][64 lanes][2 re,im], pre-scaled by 1/1024
+    const double *bsk_fft;    // [742][row 2][col 2][16][64 lanes][2 re,im], pre-scaled by 2^-74 (1/1024 and 2^-64)
     const double *lanetab;    // [12][64] per-lane twiddle bases (fft_tables.cpp), 2-wavefront kernel
     const double *weff;       // [1024][2] effective twiddles (fft_tables.cpp), 4-wavefront kernel
     uint64_t *out;

@@ -397,15 +397,15 @@ static inline double ffract(double x) {
     const double r = x - floor(x);
     return r < 1.0 ? r : 0x1.fffffffffffffp-1;
 }
-/* floor(v) mod 2^64 of a double of any magnitude (v is integral whenever |v| >= 2^52) */
-static inline u64 fmirror_to_torus(double v) {
-    const double f = ffract(v * 0x1p-64);
-    const double h = f * 0x1p32;
-    const uint32_t hi = (uint32_t)h;
-    const uint32_t lo = (uint32_t)(ffract(h) * 0x1p32);
-    return ((u64)hi << 32) | lo;
+/* torus value (mod 2^64) of t * 2^64: the Fourier-domain key carries 2^-64, so the increment is the fractional
+ * part of the inverse transform's output; 1 + f moves it into the 52 mantissa bits (one rounding at 2^-52) */
+static inline u64 fmirror_to_torus(double t) {
+    const double g = 1.0 + ffract(t);
+    u64 b;
+    memcpy(&b, &g, 8);
+    return b << 12;
 }
-/* BSK polynomial -> Fourier domain in the kernel's layout [c][lane] (re, im), pre-scaled by 1/1024 */
+/* BSK polynomial -> Fourier domain in the kernel's layout [c][lane] (re, im), pre-scaled by 2^-74 (1/1024 and 2^-64) */
 static void fmirror_bsk_poly(const u64 *src, double *dst /* [16][64][2] */) {
     static __thread double x[POLY_N];
     static __thread fcplx F[64][16];
@@ -414,8 +414,8 @@ static void fmirror_bsk_poly(const u64 *src, double *dst /* [16][64][2] */) {
     fmirror_forward(x, F);
     for (int L = 0; L < 64; L++)
         for (int c = 0; c < 16; c++) {
-            dst[(c * 64 + L) * 2 + 0] = F[L][c].r * 0x1p-10;
-            dst[(c * 64 + L) * 2 + 1] = F[L][c].i * 0x1p-10;
+            dst[(c * 64 + L) * 2 + 0] = F[L][c].r * 0x1p-74;
+            dst[(c * 64 + L) * 2 + 1] = F[L][c].i * 0x1p-74;
         }
 }
 void orc_fft_bsk_convert(const u64 *bsk_quantised, double *out /* [742*4][16][64][2] */) {
