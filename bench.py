@@ -26,6 +26,10 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_PBS = 109_559_824      # BSK + KSK + in + out + LUT, canonical u64
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
+# FP64 work of one PBS in blind_rotate_fft_kernel, counted in its compiled loop body (gfx950 ISA): 768 FMA + 604
+# other v_*_f64 per wave-iteration = 2140 flop per lane x 64 lanes x 2 waves x 742 iterations
+FFT_FLOP_PER_PBS = 2140 * 64 * 2 * 742
+FP64_VALU_PEAK_TFLOPS = 78.6          # half of the 157.3 TF FP32 vector peak: one FP64 FMA per 16 lanes per clock per SIMD
 SEED = 0xF5E57121
 
 
@@ -316,12 +320,22 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel, "avg_launch_ms": br_ms,
                          "avg_pbs_per_launch": pbs_per_launch,
-                         "note": "algorithmic bytes 109559824 B/PBS x PBS per launch / HIP-event launch time; "
-                                 "the kernel is FP64 VALU-bound by construction (DESIGN.md)"},
+                         "note": "algorithmic bytes 109559824 B/PBS x PBS per launch / HIP-event launch time; a batch "
+                                 "shares one key stream out of L2/Infinity Cache, so this figure can exceed the HBM peak "
+                                 "(traffic = measured fabric-side bytes per launch); the kernel is FP64-VALU-bound "
+                                 "(fp64_valu, DESIGN.md section 4)"},
             "parity": "GPU bit-exact vs own CPU oracle in both arithmetics (exact NTT vs oracle mode 0, f64 FFT vs its "
                       "lane-for-lane mirror, oracle mode 3); decrypt-exact vs reference test vectors; "
                       "ciphertext-level parity with tfhe-rs unpinned",
         }
+        if args.arith == "fft" and br_ms > 0:
+            tf = pbs_per_launch * FFT_FLOP_PER_PBS / (br_ms * 1e-3) / 1e12
+            line["roofline"]["fp64_valu"] = {
+                "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                "note": "the resource that actually binds: %d FP64 flop per PBS (static count of the kernel's loop; "
+                        "56 %% of its FP64 instructions are FMAs, so back-to-back FP64 issue would read 0.78 here and the "
+                        "460 integer/conversion instructions per iteration lower that further; narrow levels cannot fill "
+                        "the GPU and pull the per-launch average down)" % FFT_FLOP_PER_PBS}
         if secondary:
             line["other_arithmetic"] = {
                 "arithmetic": "exact-NTT (u64, library default)" if secondary["arithmetic"] == "exact" else "f64-FFT",

@@ -8,11 +8,12 @@ pytestmark = pytest.mark.gpu
 SEED = 0xF5E57121
 
 
-@pytest.fixture(scope="module")
-def product():
+@pytest.fixture(scope="module", params=["exact_ntt", "f64_fft"])
+def product(request):
+    """Both arithmetics of blind rotation (fhs_set_arithmetic): the library default and the one bench.py times."""
     from fhestring_amd.api import MyClientKey
     ck = MyClientKey(SEED)
-    sk = ck.get_server_key()
+    sk = ck.get_server_key(0, arith=1 if request.param == "f64_fft" else 0)
     sk.set_mode(1)
     yield ck, sk
     sk.close()
