@@ -86,6 +86,8 @@ def _declare(L):
     L.fhs_stream_handle.restype = vp
     L.fhs_set_arithmetic.argtypes = [vp, i]
     L.fhs_set_arithmetic.restype = i
+    L.fhs_set_fft4_max_batch.argtypes = [vp, i]
+    L.fhs_set_fft4_max_batch.restype = i
     L.fhs_get_arithmetic.argtypes = [vp]
     L.fhs_get_arithmetic.restype = i
     dp = C.POINTER(C.c_double)

@@ -52,6 +52,10 @@ class Context:
         """fhs_set_arithmetic: ARITH_EXACT_NTT (default) or ARITH_F64_FFT (select before load_server_key)."""
         self._check(self._L.fhs_set_arithmetic(self._h, int(arith)))
 
+    def set_fft4_max_batch(self, n):
+        """fhs_set_fft4_max_batch: batches <= n use the 4-wavefront FFT kernel (default 512)."""
+        self._check(self._L.fhs_set_fft4_max_batch(self._h, int(n)))
+
     @property
     def arithmetic(self):
         return int(self._L.fhs_get_arithmetic(self._h))

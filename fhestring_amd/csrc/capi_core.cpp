@@ -42,6 +42,12 @@ int fhs_set_arithmetic(fhs_ctx *ctx, int arith) {
     return ctx->eng.ctx.set_arithmetic(arith);
 }
 int fhs_get_arithmetic(const fhs_ctx *ctx) { return ctx ? ctx->eng.ctx.arith : FHS_ERR_ARG; }
+int fhs_set_fft4_max_batch(fhs_ctx *ctx, int max_batch) {
+    if (!ctx || max_batch < 0) return FHS_ERR_ARG;
+    if (int rc = ctx->eng.flush()) return rc;
+    ctx->eng.ctx.fft4_max_batch = max_batch;
+    return FHS_OK;
+}
 void fhs_fft_tables(double *w_re, double *w_im, double *u_re, double *u_im) {
     fhs::HostFftTables t;
     fhs::build_fft_tables(t);

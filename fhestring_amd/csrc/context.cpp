@@ -231,8 +231,7 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
         p.lanetab = d_fft_tables;
         p.weff = d_fft_tables + 12 * 64;
         p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
-        static const int force = getenv("FHS_FFT_WAVES") ? atoi(getenv("FHS_FFT_WAVES")) : 0;
-        const bool four = force ? force == 4 : B <= (size_t)fft4_max_batch;
+        const bool four = B <= (size_t)fft4_max_batch;
         e = four ? launch_blind_rotate_fft4(p, s) : launch_blind_rotate_fft(p, s);
     } else {
         BlindRotateParams p{};

@@ -66,6 +66,10 @@ int fhs_load_server_key(fhs_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk);
 #define FHS_ARITH_F64_FFT 1
 int fhs_set_arithmetic(fhs_ctx *ctx, int arith);
 int fhs_get_arithmetic(const fhs_ctx *ctx);
+/* Tuning knob of the F64_FFT arithmetic: batches of at most `max_batch` ciphertexts run on the 4-wavefront kernel
+ * (lower latency), larger ones on the 2-wavefront kernel (higher throughput).  Default 512; 0 = never, a huge value
+ * = always.  Both kernels produce identical bits. */
+int fhs_set_fft4_max_batch(fhs_ctx *ctx, int max_batch);
 /* Diagnostic: the host-derived twiddle tables of the F64_FFT mode (W[1024] re/im; U[16] re/im, 3 used). */
 void fhs_fft_tables(double *w_re, double *w_im, double *u_re, double *u_im);
 

@@ -32,19 +32,41 @@ def test_tables_match_oracle(fft_ctx):
     assert np.array_equal(t[2], u_re) and np.array_equal(t[3], u_im)
 
 
+@pytest.mark.parametrize("kernel", ["waves2", "waves4"])
 @pytest.mark.parametrize("B", [1, 5, 32])
-def test_fft_pbs_bit_exact_vs_mirror(fft_ctx, oracle_keys, oracle_sk, B):
+def test_fft_pbs_bit_exact_vs_mirror(fft_ctx, oracle_keys, oracle_sk, B, kernel):
+    """Both FFT kernels (2 and 4 wavefronts per ciphertext) against the one CPU mirror, every output word."""
     from oracle import radix
+    fft_ctx.set_fft4_max_batch(0 if kernel == "waves2" else 1 << 30)
     msgs, cts = _inputs(oracle_keys, B, 900 + B)
     names = ["msg", "carry", "eq_biv", "sign", "cmp_le"]
     luts = np.stack([radix.lut_poly(n) for n in names])
     idx = (np.arange(B) % len(names)).astype(np.uint32)
     assert fft_ctx.arithmetic == fft_ctx.ARITH_F64_FFT
     got = fft_ctx.pbs_batch(cts, idx, luts)
+    fft_ctx.set_fft4_max_batch(512)
     want = oracle_sk.pbs_batch(cts, idx, luts, mode=3)
     assert np.array_equal(got, want)
     for b in range(B):
         assert oracle_keys.decrypt_block(got[b]) == radix.lut_eval(names[idx[b]], int(msgs[b]))
+
+
+def test_fft_kernels_agree_on_a_wide_batch(fft_ctx, oracle_keys):
+    """1100 ciphertexts (two scheduling rounds of the 2-wavefront kernel) incl. trivial and all-zero inputs:
+    the two kernels must agree on every word (the mirror is too slow for this size; the cases above pin both)."""
+    from oracle import core, radix
+    rng = np.random.default_rng(4)
+    base = np.stack([oracle_keys.encrypt_block(int(m)) for m in rng.integers(0, 32, 60)] +
+                    [core.trivial_block(m) for m in (0, 7, 15)] + [np.zeros(core.BIG_CT, np.uint64)])
+    cts = base[rng.integers(0, len(base), 1100)]
+    luts = np.stack([radix.lut_poly(n) for n in ("msg", "carry", "sign")])
+    idx = rng.integers(0, 3, 1100).astype(np.uint32)
+    fft_ctx.set_fft4_max_batch(0)
+    a = fft_ctx.pbs_batch(cts, idx, luts)
+    fft_ctx.set_fft4_max_batch(1 << 30)
+    b = fft_ctx.pbs_batch(cts, idx, luts)
+    fft_ctx.set_fft4_max_batch(512)
+    assert np.array_equal(a, b)
 
 
 def test_fft_noise_close_to_exact(fft_ctx, oracle_keys, oracle_sk):

@@ -7,7 +7,10 @@ from fhestring_amd.api import MyClientKey
 
 ck = MyClientKey(0xF5E57121)
 ctx = fhestring_amd.Context(0)
-args = [a for a in sys.argv[1:] if a != "--fft"]
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+for a in sys.argv[1:]:
+    if a.startswith("--fft4-max="):
+        ctx.set_fft4_max_batch(int(a.split("=")[1]))
 if "--fft" in sys.argv:
     ctx.set_arithmetic(ctx.ARITH_F64_FFT)
 t = time.time(); ctx.load_server_key(ck.bsk(), ck.ksk()); print("key load %.2fs" % (time.time() - t))
