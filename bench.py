@@ -318,7 +318,8 @@ def main():
             "max_level_width": st["max_level_width"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel, "avg_launch_ms": br_ms,
+                         "compulsory_bytes_per_launch": 109_494_272 + pbs_per_launch * 65_552,   # one key
+                         "kernel": kernel, "avg_launch_ms": br_ms,                               # sweep shared by B PBS
                          "avg_pbs_per_launch": pbs_per_launch,
                          "note": "algorithmic bytes 109559824 B/PBS x PBS per launch / HIP-event launch time; a batch "
                                  "shares one key stream out of L2/Infinity Cache, so this figure can exceed the HBM peak "
