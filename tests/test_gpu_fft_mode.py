@@ -51,6 +51,32 @@ def test_fft_pbs_bit_exact_vs_mirror(fft_ctx, oracle_keys, oracle_sk, B, kernel)
         assert oracle_keys.decrypt_block(got[b]) == radix.lut_eval(names[idx[b]], int(msgs[b]))
 
 
+def test_fft_output_noise_margin(fft_ctx, oracle_keys):
+    """1024 bootstraps in FFT arithmetic: every output decrypts correctly and its phase error stays below 2^54.5,
+    i.e. 3.5 bits under the decoding threshold Delta/2 = 2^58 (the exact path measures the same 2^53-2^54: the
+    keyswitch and modulus switch dominate, not the transform)."""
+    from oracle import core, radix
+    rng = np.random.default_rng(11)
+    msgs = rng.integers(0, 16, 1024)
+    cts = np.stack([oracle_keys.encrypt_block(int(m)) for m in msgs])
+    luts = radix.lut_poly("msg")[None]
+    idx = np.zeros(1024, np.uint32)
+    errs = {}
+    for name, arith in (("fft", fft_ctx.ARITH_F64_FFT), ("exact", fft_ctx.ARITH_EXACT_NTT)):
+        fft_ctx.set_arithmetic(arith)
+        out = fft_ctx.pbs_batch(cts, idx, luts)
+        worst = 0
+        for b in range(1024):
+            want = radix.lut_eval("msg", int(msgs[b]))
+            assert oracle_keys.decrypt_block(out[b]) == want
+            e = (int(oracle_keys.phase(out[b])) - (want << core.DELTA_LOG)) & (2**64 - 1)
+            worst = max(worst, min(e, 2**64 - e))
+        errs[name] = worst
+    fft_ctx.set_arithmetic(fft_ctx.ARITH_F64_FFT)
+    assert errs["fft"] < 2**54.5 and errs["exact"] < 2**54.5, errs
+    assert errs["fft"] < 2 * errs["exact"] + 2**52, errs
+
+
 def test_fft_kernels_agree_on_a_wide_batch(fft_ctx, oracle_keys):
     """1100 ciphertexts (two scheduling rounds of the 2-wavefront kernel) incl. trivial and all-zero inputs:
     the two kernels must agree on every word (the mirror is too slow for this size; the cases above pin both)."""
