@@ -184,14 +184,17 @@ def main():
         return tot
 
     def all_timing(reset=False):
-        ms = n = units = ks = 0.0
+        ms = n = units = n4 = ms4 = u4 = 0.0
         for x in sks:
             kt = x.ctx.kernel_timing(reset=reset)
             ms += kt["blind_rotate_ms"] * kt["n_blind_rotate"]
             n += kt["n_blind_rotate"]
             units += kt["pbs_in_launches"]
-            ks += kt["keyswitch_ms"] * kt["n_keyswitch"]
-        return {"blind_rotate_ms": ms / max(1, n), "n_blind_rotate": n, "pbs_in_launches": units}
+            ms4 += kt["fft4_ms"] * kt["n_fft4"]
+            n4 += kt["n_fft4"]
+            u4 += kt["pbs_in_fft4"]
+        return {"blind_rotate_ms": ms / max(1, n), "n_blind_rotate": n, "pbs_in_launches": units,
+                "fft4_ms": ms4 / max(1, n4), "n_fft4": n4, "pbs_in_fft4": u4}
 
     def set_arith(a):
         for x in sks:
@@ -320,6 +323,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "compulsory_bytes_per_launch": 109_494_272 + pbs_per_launch * 65_552,   # one key
                          "kernel": kernel, "avg_launch_ms": br_ms,                               # sweep shared by B PBS
+                         "launches": n_br,
                          "avg_pbs_per_launch": pbs_per_launch,
                          "note": "algorithmic bytes 109559824 B/PBS x PBS per launch / HIP-event launch time; a batch "
                                  "shares one key stream out of L2/Infinity Cache, so this figure can exceed the HBM peak "
@@ -329,14 +333,20 @@ def main():
                       "lane-for-lane mirror, oracle mode 3); decrypt-exact vs reference test vectors; "
                       "ciphertext-level parity with tfhe-rs unpinned",
         }
+        if kt["n_fft4"]:
+            line["roofline"]["narrow_levels"] = {
+                "kernel": "blind_rotate_fft4_kernel", "launches": kt["n_fft4"], "avg_launch_ms": kt["fft4_ms"],
+                "avg_pbs_per_launch": kt["pbs_in_fft4"] / kt["n_fft4"],
+                "note": "dependency levels of <= 512 ciphertexts run on the 4-wavefront kernel (latency, not "
+                        "throughput); not part of the figures above"}
         if args.arith == "fft" and br_ms > 0:
             tf = pbs_per_launch * FFT_FLOP_PER_PBS / (br_ms * 1e-3) / 1e12
             line["roofline"]["fp64_valu"] = {
                 "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
                 "note": "the resource that actually binds: %d FP64 flop per PBS (static count of the kernel's loop; "
                         "56 %% of its FP64 instructions are FMAs, so back-to-back FP64 issue would read 0.78 here and the "
-                        "460 integer/conversion instructions per iteration lower that further; narrow levels cannot fill "
-                        "the GPU and pull the per-launch average down)" % FFT_FLOP_PER_PBS}
+                        "460 integer/conversion instructions per iteration lower that further; with several pipelines "
+                        "the launch durations include time shared with other launches)" % FFT_FLOP_PER_PBS}
         if secondary:
             line["other_arithmetic"] = {
                 "arithmetic": "exact-NTT (u64, library default)" if secondary["arithmetic"] == "exact" else "f64-FFT",

@@ -52,6 +52,8 @@ def _declare(L):
     L.fhs_kernel_timing.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.fhs_kernel_timing.restype = i
+    L.fhs_kernel_timing_kind.argtypes = [vp, i, C.POINTER(C.c_double), u64p, u64p]
+    L.fhs_kernel_timing_kind.restype = i
     h = C.c_uint64                     # fhs_char_t
     hp = C.POINTER(C.c_uint64)
     L.fhs_trivial.argtypes = [vp, u8]

@@ -93,10 +93,18 @@ class Context:
     def kernel_timing(self, reset=False):
         br, ks = C.c_double(), C.c_double()
         nb, nk, units = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        narrow = self.kernel_timing_kind(2)                     # read before a reset
         self._check(self._L.fhs_kernel_timing(self._h, int(reset), C.byref(br), C.byref(ks), C.byref(nb),
                                               C.byref(nk), C.byref(units)))
         return {"blind_rotate_ms": br.value, "keyswitch_ms": ks.value, "n_blind_rotate": nb.value,
-                "n_keyswitch": nk.value, "pbs_in_launches": units.value}
+                "n_keyswitch": nk.value, "pbs_in_launches": units.value,
+                "fft4_ms": narrow[0], "n_fft4": narrow[1], "pbs_in_fft4": narrow[2]}
+
+    def kernel_timing_kind(self, kind):
+        """(average ms, launches, PBS) of one kernel class: 0 wide blind rotation, 1 keyswitch, 2 4-wavefront FFT."""
+        ms, n, u = C.c_double(), C.c_uint64(), C.c_uint64()
+        self._check(self._L.fhs_kernel_timing_kind(self._h, int(kind), C.byref(ms), C.byref(n), C.byref(u)))
+        return ms.value, n.value, u.value
 
 
 # ---------------------------------------------------------------------------------------------

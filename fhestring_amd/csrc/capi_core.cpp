@@ -102,4 +102,14 @@ int fhs_kernel_timing(fhs_ctx *ctx, int reset, double *blind_rotate_ms, double *
     return FHS_OK;
 }
 
+int fhs_kernel_timing_kind(fhs_ctx *ctx, int kind, double *avg_ms, uint64_t *launches, uint64_t *pbs_in_launches) {
+    if (!ctx || kind < 0 || kind > 2) return FHS_ERR_ARG;
+    auto &t = ctx->eng.ctx.timer;
+    t.resolve();
+    if (avg_ms) *avg_ms = t.n[kind] ? t.ms[kind] / (double)t.n[kind] : 0.0;
+    if (launches) *launches = t.n[kind];
+    if (pbs_in_launches) *pbs_in_launches = t.units[kind];
+    return FHS_OK;
+}
+
 }  // extern "C"

@@ -65,9 +65,7 @@ void KernelTimer::resolve() {
 }
 void KernelTimer::reset() {
     resolve();
-    ms[0] = ms[1] = 0;
-    n[0] = n[1] = 0;
-    units[0] = units[1] = 0;
+    for (int k = 0; k < 3; k++) { ms[k] = 0; n[k] = 0; units[k] = 0; }
 }
 void KernelTimer::destroy() {
     resolve();
@@ -222,7 +220,8 @@ int Context::set_arithmetic(int mode) {
 int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const uint64_t *d_luts, uint64_t *d_out,
                           uint64_t *const *d_out_ptrs, size_t B, hipStream_t s) {
     hipError_t e;
-    timer.begin(0, B, s);
+    const bool four = arith == 1 && B <= (size_t)fft4_max_batch;
+    timer.begin(four ? 2 : 0, B, s);
     if (arith == 1) {
         if (!d_bsk_fft) return fail(-3, "Fourier-domain key not loaded");
         BlindRotateFftParams p{};
@@ -231,7 +230,6 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
         p.lanetab = d_fft_tables;
         p.weff = d_fft_tables + 12 * 64;
         p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
-        const bool four = B <= (size_t)fft4_max_batch;
         e = four ? launch_blind_rotate_fft4(p, s) : launch_blind_rotate_fft(p, s);
     } else {
         BlindRotateParams p{};

@@ -26,9 +26,11 @@ struct KernelTimer {
     struct Pending { hipEvent_t e0, e1; int kind; uint64_t units; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
-    double ms[2] = {0, 0};        // 0 = blind rotation, 1 = keyswitch
-    uint64_t n[2] = {0, 0};
-    uint64_t units[2] = {0, 0};   // PBS covered by the timed launches
+    // 0 = blind rotation (exact NTT kernel, or the 2-wavefront FFT kernel), 1 = keyswitch,
+    // 2 = blind rotation on the 4-wavefront FFT kernel (batches <= fft4_max_batch)
+    double ms[3] = {0, 0, 0};
+    uint64_t n[3] = {0, 0, 0};
+    uint64_t units[3] = {0, 0, 0};   // PBS covered by the timed launches
     bool enabled = true;
     hipEvent_t get();
     void begin(int kind, uint64_t units, hipStream_t s);

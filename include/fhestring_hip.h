@@ -88,6 +88,10 @@ int fhs_pbs_batch_device(fhs_ctx *ctx, const uint64_t *d_in, const uint32_t *d_l
  * reset, measured with HIP events on the launch stream; and number of launches timed. */
 int fhs_kernel_timing(fhs_ctx *ctx, int reset, double *blind_rotate_ms, double *keyswitch_ms,
                       uint64_t *n_blind_rotate, uint64_t *n_keyswitch, uint64_t *pbs_in_launches);
+/* Per kernel class: kind 0 = blind rotation on the exact-NTT kernel or the 2-wavefront FFT kernel (fhs_kernel_timing
+ * reports this one), 1 = keyswitch, 2 = blind rotation on the 4-wavefront FFT kernel (batches <= fft4_max_batch).
+ * Does not reset. */
+int fhs_kernel_timing_kind(fhs_ctx *ctx, int kind, double *avg_ms, uint64_t *launches, uint64_t *pbs_in_launches);
 
 /* ---- FheAsciiChar boundary ops (lazy DAG nodes) ------------------------------
  * Each constructor mirrors one method of src/ciphertext/fheasciichar.rs and returns a
