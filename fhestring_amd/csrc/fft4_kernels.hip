@@ -1,7 +1,7 @@
 // f64-FFT blind rotation with 4 wavefronts per ciphertext (gfx950 only).
 //
 // Same arithmetic as fft_kernels.hip (same butterflies on the same values in the same order: the CPU mirror,
-// oracle mode 3, checks both bit for bit) but each GLWE polynomial is spread over a PAIR of wavefronts, 8 complex
+// mode 3 of the CPU oracle, checks both bit for bit) but each GLWE polynomial is spread over a PAIR of wavefronts, 8 complex
 // points and 16 accumulator words per lane.  Half the work per wavefront halves the latency of one PBS, which is
 // what a narrow dependency level pays, and at 128 registers per lane four wavefronts share a SIMD.
 //

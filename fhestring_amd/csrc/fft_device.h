@@ -1,6 +1,6 @@
 // Device helpers shared by the f64-FFT blind-rotation kernels (fft_kernels.hip: 2 wavefronts per ciphertext,
 // fft4_kernels.hip: 4 wavefronts per ciphertext).  Both kernels perform the same butterflies on the same values in
-// the same order, so one CPU mirror (oracle mode 3) checks either bit for bit.
+// the same order, so one CPU mirror (mode 3 of the CPU oracle) checks either bit for bit.
 #pragma once
 #include "pbs_kernels.h"
 

@@ -1,4 +1,5 @@
 """Host-side cost of one bench step (DAG build, plan + enqueue) against the GPU time it waits for: python tools/host_time.py (GPU box)."""
+import sys, time, random
 sys.path.insert(0, ".")
 import torch
 from fhestring_amd.api import MyClientKey, MyServerKey
