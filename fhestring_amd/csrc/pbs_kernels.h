@@ -87,8 +87,6 @@ hipError_t launch_keyswitch_mfma(const uint64_t *d_in /*[B][2049]*/, const int8_
 hipError_t launch_modswitch(const uint64_t *d_ks, uint32_t *d_ms /*[B][743]*/, int B, hipStream_t s);
 hipError_t launch_lincomb(const LinDesc *d_desc, const LinTerm *d_terms, uint64_t *d_out /*[n][2049]*/,
                           int n, hipStream_t s);
-// gathers scattered blocks into a dense batch: out[i] = *src[i]
-hipError_t launch_gather_blocks(const uint64_t *const *d_src, uint64_t *d_out, int n, hipStream_t s);
 hipError_t launch_scatter_blocks(const uint64_t *d_in, uint64_t *const *d_dst, int n, hipStream_t s);
 
 }  // namespace fhs

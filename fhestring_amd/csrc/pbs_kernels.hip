@@ -430,7 +430,7 @@ hipError_t launch_modswitch(const uint64_t *d_ks, uint32_t *d_ms, int B, hipStre
 }
 
 // ------------------------------------------------------------------------------------------
-// linear layer: out[k] = sum_t coef*src + const (u64 wrapping); gather / scatter of blocks
+// linear layer: out[k] = sum_t coef*src + const (u64 wrapping); scatter of a dense level into blocks
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lincomb_kernel(const LinDesc *__restrict__ desc,
                                                       const LinTerm *__restrict__ terms,
@@ -452,22 +452,11 @@ hipError_t launch_lincomb(const LinDesc *d_desc, const LinTerm *d_terms, uint64_
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void gather_blocks_kernel(const uint64_t *const *__restrict__ src,
-                                                            uint64_t *__restrict__ out) {
-    const uint64_t *s = src[blockIdx.x];
-    uint64_t *o = out + (size_t)blockIdx.x * BIG_CT;
-    for (int e = threadIdx.x; e < BIG_CT; e += 256) o[e] = s[e];
-}
 __global__ __launch_bounds__(256) void scatter_blocks_kernel(const uint64_t *__restrict__ in,
                                                              uint64_t *const *__restrict__ dst) {
     uint64_t *o = dst[blockIdx.x];
     const uint64_t *s = in + (size_t)blockIdx.x * BIG_CT;
     for (int e = threadIdx.x; e < BIG_CT; e += 256) o[e] = s[e];
-}
-hipError_t launch_gather_blocks(const uint64_t *const *d_src, uint64_t *d_out, int n, hipStream_t s) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gather_blocks_kernel, dim3(n), dim3(256), 0, s, d_src, d_out);
-    return hipGetLastError();
 }
 hipError_t launch_scatter_blocks(const uint64_t *d_in, uint64_t *const *d_dst, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
