@@ -51,6 +51,33 @@ def test_fft_pbs_bit_exact_vs_mirror(fft_ctx, oracle_keys, oracle_sk, B, kernel)
         assert oracle_keys.decrypt_block(got[b]) == radix.lut_eval(names[idx[b]], int(msgs[b]))
 
 
+def test_char_ops_bit_exact_vs_oracle_in_fft_arithmetic(oracle_keys, oracle_sk):
+    """FheAsciiChar boundary ops through the lazy engine in FFT arithmetic: every output block equals the oracle
+    engine's (same decompositions, PBS through the mirror, mode 3) bit for bit, and decrypts to u8 arithmetic."""
+    import fhestring_amd
+    from fhestring_amd.api import MyServerKey
+    from oracle import radix
+    sk = MyServerKey.from_raw_keys(oracle_keys.bsk, oracle_keys.ksk, arith=fhestring_amd.Context.ARITH_F64_FFT)
+    sk.set_mode(0)
+    eng = radix.Engine(oracle_sk, mode=3)
+    want, got, exp = [], [], []
+    for a, b in [(0x61, 0x7A), (0x00, 0xFF), (0xC3, 0xC3), (0x80, 0x7F)]:
+        cta, ctb = oracle_keys.encrypt_char(a), oracle_keys.encrypt_char(b)
+        oa, ob = radix.CipherChar.from_cts(cta, eng), radix.CipherChar.from_cts(ctb, eng)
+        ga, gb = sk.upload_char(cta), sk.upload_char(ctb)
+        for name, ref in [("eq", int(a == b)), ("lt", int(a < b)), ("ge", int(a >= b)), ("bitand", a & b),
+                          ("bitor", a | b), ("add", (a + b) & 255), ("sub", (a - b) & 255)]:
+            want.append(getattr(oa, name)(ob)); got.append(getattr(ga, name)(gb)); exp.append(ref)
+        want.append(oa.ne(ob).if_then_else(oa, ob)); got.append(ga.ne(gb).if_then_else(ga, gb)); exp.append(a if a != b else b)
+    eng.materialize([blk for ch in want for blk in ch.b])
+    for w, g, e in zip(want, got, exp):
+        gc = g.download()
+        assert np.array_equal(gc, w.cts())
+        assert oracle_keys.decrypt_char(gc) == e
+    assert sk.stats()["pbs_executed"] == eng.pbs_count
+    sk.close()
+
+
 def test_fft_output_noise_margin(fft_ctx, oracle_keys):
     """1024 bootstraps in FFT arithmetic: every output decrypts correctly and its phase error stays below 2^54.5,
     i.e. 3.5 bits under the decoding threshold Delta/2 = 2^58 (the exact path measures the same 2^53-2^54: the
