@@ -134,9 +134,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        # FHS_BENCH_BACKEND=gloo rehearses the multi-rank logic with several ranks on ONE GPU (exchange staged through
+        # the host, fhestring_amd/parallel.py); the real run is nccl = RCCL over xGMI, one rank per GPU
+        backend = os.environ.get("FHS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = 0
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
@@ -267,7 +274,8 @@ def main():
     pbs_local = st["pbs_executed"]
     if dist is not None:
         sec = [secondary["dt"], secondary["pbs_local"]] if secondary else [0.0, 0.0]
-        tt = torch.tensor([dt, float(pbs_local)] + sec, dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt, float(pbs_local)] + sec, dtype=torch.float64,
+                          device="cuda" if dist.get_backend() == "nccl" else "cpu")
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
