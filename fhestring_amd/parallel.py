@@ -80,8 +80,10 @@ class ShardedContains:
         if (self.world == 1 and not force_exchange) or op != "contains":   # force_exchange: 1-rank RCCL test
             return [self.run(sh, clear_pattern, op=op) for sh in shards]
         torch = self.torch
-        if not (torch.cuda.is_available() and sk.device_resident and self.dist.get_backend() == "nccl"):
-            return [self.run(sh, clear_pattern, op=op) for sh in shards]   # host-staged path (tests)
+        import os
+        if not (torch.cuda.is_available() and sk.device_resident and self.dist.get_backend() == "nccl") \
+                or os.environ.get("FHS_SYNC_EXCHANGE"):
+            return [self.run(sh, clear_pattern, op=op) for sh in shards]   # host-synchronised path (tests, fallback)
         n = len(shards)
         local = [sk.contains_clear(sh, clear_pattern) if len(sh) >= len(clear_pattern) else sk.trivial(0)
                  for sh in shards]
