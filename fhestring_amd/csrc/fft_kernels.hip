@@ -28,8 +28,21 @@ namespace fhs {
 namespace {
 using namespace fftdev;
 
+// Hook called by a stage right after the butterfly on registers (a, b): the transposes use it to send finished
+// points to LDS while the next butterflies run (the store path needs ~13 cycles per 16-byte wave store, 16 of them in
+// one burst would stall the wave); the scheduling barrier lets arithmetic move across it but pins the stores.
+struct no_hook { __device__ __forceinline__ void operator()(int, int) const {} };
+struct store_hook {
+    cplx *base; const cplx *z; int m0, m1;               // slot of register r = m0 * r + (r >> 2) * m1
+    __device__ __forceinline__ void operator()(int a, int b) const {
+        base[m0 * a + (a >> 2) * m1] = z[a];
+        base[m0 * b + (b >> 2) * m1] = z[b];
+        __builtin_amdgcn_sched_barrier(0x7);              // ALU may cross, memory operations may not
+    }
+};
+
 // the 4 lane-uniform stages of layout A (twiddles are scalar immediates)
-template <bool INV> __device__ __forceinline__ void stages_uniform(cplx (&z)[16]) {
+template <bool INV, class Hook> __device__ __forceinline__ void stages_uniform(cplx (&z)[16], const Hook &hook) {
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int T = INV ? (1 << s) : (8 >> s);
@@ -42,6 +55,7 @@ template <bool INV> __device__ __forceinline__ void stages_uniform(cplx (&z)[16]
             for (int r = 2 * i * T; r < 2 * i * T + T; r++) {
                 if (i & 1) { if (INV) bf_inv<true>(z[r], z[r + T], wr, wi); else bf_fwd<true>(z[r], z[r + T], wr, wi); }
                 else       { if (INV) bf_inv<false>(z[r], z[r + T], wr, wi); else bf_fwd<false>(z[r], z[r + T], wr, wi); }
+                if (s == 3) hook(r, r + T);
             }
         }
     }
@@ -49,7 +63,8 @@ template <bool INV> __device__ __forceinline__ void stages_uniform(cplx (&z)[16]
 
 // one in-lane stage of layout B or C: register distance TAU, G = 8/TAU twiddle groups,
 // twiddle of group g = per-lane base * U_G[g] (g even), rotated by i for odd g
-template <bool INV, int TAU> __device__ __forceinline__ void stage_lane(cplx (&z)[16], double br, double bi) {
+template <bool INV, int TAU, class Hook = no_hook>
+__device__ __forceinline__ void stage_lane(cplx (&z)[16], double br, double bi, const Hook &hook = Hook()) {
     constexpr int G = 8 / TAU;
 #pragma unroll
     for (int g = 0; g < G; g += 2) {
@@ -64,11 +79,13 @@ template <bool INV, int TAU> __device__ __forceinline__ void stage_lane(cplx (&z
 #pragma unroll
         for (int c = 2 * g * TAU; c < 2 * g * TAU + TAU; c++) {
             if (INV) bf_inv<false>(z[c], z[c + TAU], wr, wi); else bf_fwd<false>(z[c], z[c + TAU], wr, wi);
+            hook(c, c + TAU);
         }
         if (G > 1) {
 #pragma unroll
             for (int c = 2 * (g + 1) * TAU; c < 2 * (g + 1) * TAU + TAU; c++) {
                 if (INV) bf_inv<true>(z[c], z[c + TAU], wr, wi); else bf_fwd<true>(z[c], z[c + TAU], wr, wi);
+                hook(c, c + TAU);
             }
         }
     }
@@ -93,12 +110,7 @@ __device__ __forceinline__ void load_lane_tw(LaneTw &t, const double *__restrict
 
 // forward: z[r] = point (lane + 64 r)  ->  z[c] = value at array index 16*lane + c
 __device__ __forceinline__ void fft_forward(cplx (&z)[16], double *lds, int lane, const LaneTw &tw) {
-    stages_uniform<false>(z);
-    {
-        cplx *w = slotA(lds, lane);
-#pragma unroll
-        for (int r = 0; r < 16; r++) w[68 * r] = z[r];
-    }
+    stages_uniform<false>(z, store_hook{slotA(lds, lane), z, 68, 0});             // slot A of register r: 68 r
     __builtin_amdgcn_wave_barrier();
     {
         const cplx *rd = slotB(lds, lane);
@@ -109,12 +121,7 @@ __device__ __forceinline__ void fft_forward(cplx (&z)[16], double *lds, int lane
     stage_lane<false, 8>(z, tw.re[0], tw.im[0]);
     stage_lane<false, 4>(z, tw.re[1], tw.im[1]);
     stage_lane<false, 2>(z, tw.re[2], tw.im[2]);
-    stage_lane<false, 1>(z, tw.re[3], tw.im[3]);
-    {
-        cplx *w = slotB(lds, lane);
-#pragma unroll
-        for (int p = 0; p < 16; p++) w[4 * p + (p >> 2)] = z[p];
-    }
+    stage_lane<false, 1>(z, tw.re[3], tw.im[3], store_hook{slotB(lds, lane), z, 4, 1});   // slot B: 4 p + (p >> 2)
     __builtin_amdgcn_wave_barrier();
     {
         const cplx *rd = slotC(lds, lane);
@@ -123,18 +130,16 @@ __device__ __forceinline__ void fft_forward(cplx (&z)[16], double *lds, int lane
     }
     __builtin_amdgcn_wave_barrier();
     stage_lane<false, 2>(z, tw.re[4], tw.im[4]);
-    stage_lane<false, 1>(z, tw.re[5], tw.im[5]);
+}
+// last forward stage, with the transform published for the partner wavefront ([c][lane] order) as it completes
+__device__ __forceinline__ void fft_forward_last(cplx (&z)[16], double *lds, int lane, const LaneTw &tw) {
+    stage_lane<false, 1>(z, tw.re[5], tw.im[5], store_hook{reinterpret_cast<cplx *>(lds) + lane, z, 64, 0});
 }
 
 // inverse (unscaled): z[c] at array index 16*lane + c  ->  z[r] = point (lane + 64 r)
 __device__ __forceinline__ void fft_inverse(cplx (&z)[16], double *lds, int lane, const LaneTw &tw) {
     stage_lane<true, 1>(z, tw.re[5], tw.im[5]);
-    stage_lane<true, 2>(z, tw.re[4], tw.im[4]);
-    {
-        cplx *w = slotC(lds, lane);
-#pragma unroll
-        for (int c = 0; c < 16; c++) w[c] = z[c];
-    }
+    stage_lane<true, 2>(z, tw.re[4], tw.im[4], store_hook{slotC(lds, lane), z, 1, 0});            // slot C: c
     __builtin_amdgcn_wave_barrier();
     {
         const cplx *rd = slotB(lds, lane);
@@ -145,12 +150,7 @@ __device__ __forceinline__ void fft_inverse(cplx (&z)[16], double *lds, int lane
     stage_lane<true, 1>(z, tw.re[3], tw.im[3]);
     stage_lane<true, 2>(z, tw.re[2], tw.im[2]);
     stage_lane<true, 4>(z, tw.re[1], tw.im[1]);
-    stage_lane<true, 8>(z, tw.re[0], tw.im[0]);
-    {
-        cplx *w = slotB(lds, lane);
-#pragma unroll
-        for (int p = 0; p < 16; p++) w[4 * p + (p >> 2)] = z[p];
-    }
+    stage_lane<true, 8>(z, tw.re[0], tw.im[0], store_hook{slotB(lds, lane), z, 4, 1});
     __builtin_amdgcn_wave_barrier();
     {
         const cplx *rd = slotA(lds, lane);
@@ -158,7 +158,7 @@ __device__ __forceinline__ void fft_inverse(cplx (&z)[16], double *lds, int lane
         for (int r = 0; r < 16; r++) z[r] = rd[68 * r];
     }
     __builtin_amdgcn_wave_barrier();
-    stages_uniform<true>(z);
+    stages_uniform<true>(z, no_hook());
 }
 
 }  // namespace
@@ -248,12 +248,7 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
             LaneTw tw;
             load_lane_tw(tw, lanetab, lane);
             fft_forward(z, my, lane, tw);
-        }
-
-        {
-            cplx *pub = reinterpret_cast<cplx *>(my) + lane;
-#pragma unroll
-            for (int c = 0; c < 16; c++) pub[c * 64] = z[c];
+            fft_forward_last(z, my, lane, tw);            // publishes [c][lane] for the partner as it goes
         }
         __syncthreads();
         __builtin_amdgcn_s_setprio(2);
@@ -328,6 +323,7 @@ __global__ __launch_bounds__(64) void bsk_to_fft_kernel(const uint64_t *__restri
     LaneTw tw;
     load_lane_tw(tw, lanetab, lane);
     fft_forward(z, reinterpret_cast<double *>(smem), lane, tw);
+    stage_lane<false, 1>(z, tw.re[5], tw.im[5]);
     double *dst = out + (size_t)blockIdx.x * 2 * FM;
 #pragma unroll
     for (int c = 0; c < 16; c++) {
