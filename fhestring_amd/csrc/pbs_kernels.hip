@@ -69,7 +69,11 @@ __device__ __forceinline__ void ntt_forward(double (&x)[32], double *lds, int la
     base[0] = lanetw[lane];
 #pragma unroll
     for (int k = 0; k < 5; k++) base[1 + k] = lanetw[(1 << k) * 64 + lane];
-    // stages t = 1024..64: a 32-point CT on the register index, lane-uniform twiddles
+    // stages t = 1024..64: a 32-point CT on the register index, lane-uniform twiddles.  The last of them sends each
+    // finished pair to LDS (transpose strided -> contiguous) while the next butterflies run: a burst of 32 stores
+    // after the stage would stall the wave on the LDS store path; the scheduling barrier lets arithmetic cross
+    // but pins the stores.  pad_slot(lane + 64 r) == (lane + 2*(lane>>5)) + 68 r: one address register.
+    double *wr = lds + (lane + 2 * (lane >> 5));
 #pragma unroll
     for (int T = 16; T >= 1; T >>= 1) {
         const int m = 16 / T;
@@ -81,14 +85,13 @@ __device__ __forceinline__ void ntt_forward(double (&x)[32], double *lds, int la
                 double v = mulmod(x[r + T], w, p, pinv);
                 x[r + T] = x[r] - v;
                 x[r] = x[r] + v;
+                if (T == 1) {
+                    wr[68 * r] = x[r];
+                    wr[68 * (r + 1)] = x[r + 1];
+                    __builtin_amdgcn_sched_barrier(0x7);
+                }
             }
         }
-    }
-    // transpose strided -> contiguous through LDS
-    {   // pad_slot(lane + 64 r) == (lane + 2*(lane>>5)) + 68 r: one address register, immediate offsets
-        double *wr = lds + (lane + 2 * (lane >> 5));
-#pragma unroll
-        for (int r = 0; r < 32; r++) wr[68 * r] = x[r];
     }
     __builtin_amdgcn_wave_barrier();
     // stage t = 32 fused into the read: lanes (2k, 2k+1) share one 64-coefficient group
@@ -135,6 +138,7 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[32], double *lds, int la
     // Lazy ranges: magnitudes are tracked statically per register (in units of p: pointwise output
     // 1.3, a sum adds its operands, a mulmod/reduce output is 0.5 + input/60) and only the 13
     // registers that would push a mulmod input past 24 p are reset -- see DESIGN.md section 2.
+    double *wr = lds + 34 * lane;
     int lg = 4;
 #pragma unroll
     for (int t = 1; t <= 16; t <<= 1, lg--) {
@@ -148,16 +152,14 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[32], double *lds, int la
                 double u = x[c], v = x[c + t];
                 x[c] = u + v;
                 x[c + t] = mulmod(u - v, w, p, pinv);
+                if (t == 16) {   // last in-lane stage: transpose contiguous -> strided as the pairs complete
+                    if (c < 4) x[c] = reduce_once(x[c], p, pinv);   // the only registers above 3 p
+                    wr[c] = x[c];
+                    wr[c + 16] = x[c + 16];
+                    __builtin_amdgcn_sched_barrier(0x7);
+                }
             }
         }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; c++) x[c] = reduce_once(x[c], p, pinv);   // the only registers above 3 p
-    // transpose contiguous -> strided, stage t = 32 fused into the read
-    {
-        double *wr = lds + 34 * lane;
-#pragma unroll
-        for (int c = 0; c < 32; c++) wr[c] = x[c];
     }
     __builtin_amdgcn_wave_barrier();
     {
