@@ -91,6 +91,8 @@ int Context::init(int device_id) {
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return fail(-2, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+    wg_slots = 4 * prop.multiProcessorCount;
+    HIP_TRY(hipMalloc(&d_work_counter, 64), "hipMalloc counter");
     return 0;
 }
 
@@ -108,6 +110,8 @@ void Context::shutdown() {
     dig_buf.release();
     if (d_bsk_ntt) (void)hipFree(d_bsk_ntt);
     if (d_tables) (void)hipFree(d_tables);
+    if (d_work_counter) (void)hipFree(d_work_counter);
+    d_work_counter = nullptr;
     if (d_bsk_fft) (void)hipFree(d_bsk_fft);
     if (d_fft_tables) (void)hipFree(d_fft_tables);
     d_bsk_fft = nullptr;
@@ -229,6 +233,8 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
         p.bsk_fft = d_bsk_fft;
         p.lanetab = d_fft_tables;
         p.weff = d_fft_tables + 12 * 64;
+        p.work_counter = d_work_counter;
+        p.slots = wg_slots;
         p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
         e = four ? launch_blind_rotate_fft4(p, s) : launch_blind_rotate_fft(p, s);
     } else {

@@ -59,6 +59,8 @@ class Context {
     int arith = 0;
     double *d_bsk_fft = nullptr;
     double *d_fft_tables = nullptr;   // lanetab[12][64] | weff[1024][2]
+    uint32_t *d_work_counter = nullptr;   // persistent-workgroup ciphertext counter of the 2-wavefront FFT kernel
+    int wg_slots = 1024;                  // 4 workgroups per CU
     int fft4_max_batch = 512;         // batches up to this size use the 4-wavefront kernel (lower latency)
     int set_arithmetic(int mode);
     // keyswitch of a dense batch into ks_buf (timed as kernel kind 1); ks_buf must hold B rows

@@ -53,6 +53,8 @@ struct BlindRotateFftParams {
     const double *bsk_fft;    // [742][row 2][col 2][16][64 lanes][2 re,im], pre-scaled by 2^-74 (1/1024 and 2^-64)
     const double *lanetab;    // [12][64] per-lane twiddle bases (fft_tables.cpp), 2-wavefront kernel
     const double *weff;       // [1024][2] effective twiddles (fft_tables.cpp), 4-wavefront kernel
+    uint32_t *work_counter;   // 2-wavefront kernel: next ciphertext to take (zeroed by the launcher)
+    int slots;                // 2-wavefront kernel: resident workgroup slots of the device (4 per CU)
     uint64_t *out;
     uint64_t *const *out_ptrs;
     int B;
