@@ -80,8 +80,9 @@ int fhs_pbs_batch(fhs_ctx *ctx, const uint64_t *in, const uint32_t *lut_idx, con
                   size_t n_luts, uint64_t *out, size_t B);
 /* keyswitch + modulus switch only: ms_out[B][743] values in [0,4096) */
 int fhs_keyswitch_modswitch_batch(fhs_ctx *ctx, const uint64_t *in, uint32_t *ms_out, size_t B);
-/* Device-resident variant used by bench.py: all pointers are device pointers
- * (e.g. torch tensors' data_ptr); work is enqueued on `hip_stream` (0 = default). */
+/* Device-resident variant: all pointers are device pointers (e.g. torch tensors' data_ptr); work is enqueued
+ * on `hip_stream` (0 = default).  A context owns one set of scratch buffers and one work counter: calls on it
+ * must be ordered (one stream at a time); use several contexts for concurrent streams. */
 int fhs_pbs_batch_device(fhs_ctx *ctx, const uint64_t *d_in, const uint32_t *d_lut_idx,
                          const uint64_t *d_luts, uint64_t *d_out, size_t B, void *hip_stream);
 /* Average duration (ms) of the blind-rotation / keyswitch kernel launches since the last
