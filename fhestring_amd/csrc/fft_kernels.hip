@@ -9,8 +9,8 @@
 // It is deterministic, and mode 3 of the CPU oracle mirrors it lane for lane with the same
 // IEEE-754 operation order, so the GPU output is still checked bit for bit.
 //
-// Mapping: one workgroup of 2 wavefronts per ciphertext, wavefront j owns GLWE polynomial j:
-// 16 complex points per lane in registers.  The 10 radix-2 stages run in three register layouts, each
+// Mapping: a workgroup of 2 wavefronts works on one ciphertext at a time (persistent: it takes the next one from
+// a counter until the batch is done), wavefront j owns GLWE polynomial j: 16 complex points per lane in registers.  The 10 radix-2 stages run in three register layouts, each
 // with 4 (or 2) of the index bits in the register number so that every butterfly is in-lane:
 //   A  lane = n mod 64,                    reg = n bits 6-9   stages t = 512..64 (lane-uniform twiddles)
 //   B  lane = 4*(n div 64) + (n mod 4),    reg = n bits 2-5   stages t = 32..4
