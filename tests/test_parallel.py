@@ -58,6 +58,10 @@ for s, p in cases:
     shard = job.upload_shard(ClearKey(), s, len(s) // world, len(p))
     got = job.run(shard, p).v
     ok &= (got == int(p in s))
+# the batched entry bench.py uses (falls back to the per-string exchange without RCCL)
+strings = ["abcdefghij" * 3, "zzzzzzzzzzjabzzzzzzzzzzzzzzzzz", "q" * 30]
+shards = [job.upload_shard(ClearKey(), s, len(s) // world, 3) for s in strings]
+ok &= ([o.v for o in job.run_batch(shards, "jab")] == [int("jab" in s) for s in strings])
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 3)
