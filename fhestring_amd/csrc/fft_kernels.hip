@@ -28,6 +28,24 @@ namespace fhs {
 namespace {
 using namespace fftdev;
 
+// high word of (flip ? -v : v) - a (64-bit wrapping), flip given as a lane mask: the carry chains run through VCC
+// back to back (the compiler's own sequence carries through SGPR pairs and pays a wait state after each borrow)
+__device__ __forceinline__ uint32_t rot_sub_hi(uint64_t v, uint64_t a, uint64_t flipmask) {
+    const uint32_t vl = (uint32_t)v, vh = (uint32_t)(v >> 32), al = (uint32_t)a, ah = (uint32_t)(a >> 32);
+    uint32_t tl, th;
+    asm("v_sub_co_u32 %0, vcc, 0, %2\n\t"
+        "v_subb_co_u32 %1, vcc, 0, %3, vcc\n\t"
+        "v_cndmask_b32 %0, %2, %0, %6\n\t"
+        "v_cndmask_b32 %1, %3, %1, %6\n\t"
+        "v_sub_co_u32 %0, vcc, %0, %4\n\t"
+        "v_subb_co_u32 %1, vcc, %1, %5, vcc"
+        : "=&v"(tl), "=&v"(th)
+        : "v"(vl), "v"(vh), "v"(al), "v"(ah), "s"(flipmask)
+        : "vcc");
+    (void)tl;
+    return th;
+}
+
 // Hook called by a stage right after the butterfly on registers (a, b): the transposes use it to send finished
 // points to LDS while the next butterflies run (the store path needs ~13 cycles per 16-byte wave store, 16 of them in
 // one burst would stall the wave); the scheduling barrier lets arithmetic move across it but pins the stores.
@@ -232,14 +250,16 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
         // lower, which for row 0 is the copy of row 31 kept in front of it.  The sign flips where the index wrapped.
         const uint32_t sl = s & 63, sh = s >> 6;
         const bool borrow = (uint32_t)lane < sl;
+        const uint64_t borrowmask = __builtin_amdgcn_ballot_w64(borrow), negmask = neg ? ~0ull : 0ull;
         const uint64_t *vbase = my_u + (((uint32_t)lane - sl) & 63) + (borrow ? 0 : 64);
 #pragma unroll
         for (int r = 0; r < 32; r++) {
-            uint64_t v = vbase[64 * ((r - sh) & 31)];
-            const bool wrapped = ((uint32_t)r < sh) || ((uint32_t)r == sh && borrow);
-            if (wrapped != neg) v = (uint64_t)0 - v;
-            const uint64_t d = v - acc[r];
-            const int32_t dig = (int32_t)((uint32_t)(d >> 32) + 0x100u) >> 9;
+            const uint64_t v = vbase[64 * ((r - sh) & 31)];
+            // lane mask of the sign flips, built from scalars: all lanes if the row index wrapped, the borrowing lanes
+            // in the row where it wraps, none above; inverted when the monomial carries a minus sign
+            const uint64_t wrapmask = (uint32_t)r < sh ? ~0ull : ((uint32_t)r == sh ? borrowmask : 0ull);
+            const uint32_t dhi = rot_sub_hi(v, acc[r], wrapmask ^ negmask);
+            const int32_t dig = (int32_t)(dhi + 0x100u) >> 9;
             if (r < 16) z[r].r = (double)dig; else z[r - 16].i = (double)dig;
         }
         __builtin_amdgcn_wave_barrier();
