@@ -36,8 +36,8 @@ SEED = 0xF5E57121
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chars", type=int, default=64, help="plaintext characters per rank")
     ap.add_argument("--pattern-len", type=int, default=4)
     ap.add_argument("--strings", type=int, default=8,
@@ -260,7 +260,7 @@ def main():
         sync()
         all_stats(reset=True)
         all_timing(reset=True)
-        n2 = max(1, min(args.steps, 2))
+        n2 = max(1, min(args.steps, 2 * P))
         t2 = time.perf_counter()
         for _ in range(n2):
             outs2 = step()
