@@ -154,6 +154,8 @@ def main():
     from fhestring_amd.api import MyClientKey, MyServerKey, BIG_CT
     from fhestring_amd.parallel import ShardedContains
 
+    if args.op == "find" and world > 1 and args.dist_mode == "windows":
+        args.dist_mode = "levels"     # find has no window-sharded form yet: every rank splits every level instead
     m = args.pattern_len
     rnd = random.Random(SEED)
     strings, pattern = synth_strings(args.strings, args.chars * world, m, rnd)
