@@ -2,8 +2,9 @@
 //
 // Same arithmetic as fft_kernels.hip (same butterflies on the same values in the same order: the CPU mirror,
 // mode 3 of the CPU oracle, checks both bit for bit) but each GLWE polynomial is spread over a PAIR of wavefronts, 8 complex
-// points and 16 accumulator words per lane.  Half the work per wavefront halves the latency of one PBS, which is
-// what a narrow dependency level pays, and at 128 registers per lane four wavefronts share a SIMD.
+// points and 16 accumulator words per lane.  Half the work per wavefront shortens the latency of one PBS (4.3 ms
+// instead of 5.2 ms), which is what a narrow dependency level pays; Context::blind_rotate uses this kernel for batches
+// of at most fft4_max_batch (512) ciphertexts, where at most 2 workgroups share a CU.
 //
 //   wave w = 2*j + h: polynomial j, half h = bit 9 of the point index n.  The first (last, for the inverse) radix-2
 //   stage t = 512 pairs the two halves and is done through one exchange in LDS; the other 9 stages are a 512-point
