@@ -29,7 +29,50 @@ def plan_windows(n_chars, m, world):
     return out
 
 
-class ShardedContains:
+class _FlagExchange:
+    """Gathers one partial FheAsciiChar flag per item from every rank: parts[item][rank]."""
+
+    def _stream_ordered(self):
+        import os
+        t = self.torch
+        return (t.cuda.is_available() and self.sk.device_resident and self.dist.get_backend() == "nccl"
+                and not os.environ.get("FHS_SYNC_EXCHANGE"))
+
+    def _gather(self, local):
+        sk, torch, n = self.sk, self.torch, len(local)
+        if self._stream_ordered():
+            # one all-gather of n chars per rank on the context's own HIP stream: no host synchronisation anywhere,
+            # so consecutive batches on different contexts keep overlapping
+            if getattr(self, "_ext", None) is None:
+                self._ext = torch.cuda.ExternalStream(sk.stream_handle())
+            with torch.cuda.stream(self._ext):
+                mine = torch.empty(n * CHAR_WORDS, dtype=torch.int64, device="cuda")
+                allp = torch.empty(self.world * n * CHAR_WORDS, dtype=torch.int64, device="cuda")
+                for k, l in enumerate(local):
+                    sk.export_device_async(l, mine.data_ptr() + 8 * CHAR_WORDS * k)   # first call flushes the DAG
+                self.dist.all_gather_into_tensor(allp, mine)    # RCCL over xGMI: world x n x 65 568 B
+            self._keep = (mine, allp)       # device buffers stay referenced until the next exchange replaces them
+        else:
+            # host-synchronised path: CPU stand-in, several ranks sharing one GPU through gloo (tests), fallback
+            dev = "cuda" if torch.cuda.is_available() and sk.device_resident else "cpu"
+            mine = torch.empty(n * CHAR_WORDS, dtype=torch.int64, device=dev)
+            for k, l in enumerate(local):
+                sk.export_device(l, mine.data_ptr() + 8 * CHAR_WORDS * k)             # flushes this rank's DAG
+            allp = torch.empty(self.world * n * CHAR_WORDS, dtype=torch.int64, device=dev)
+            if dev == "cuda" and self.dist.get_backend() != "nccl":
+                parts_cpu = [torch.empty(n * CHAR_WORDS, dtype=torch.int64) for _ in range(self.world)]
+                self.dist.all_gather(parts_cpu, mine.cpu())
+                allp.copy_(torch.cat(parts_cpu))
+            else:
+                self.dist.all_gather_into_tensor(allp, mine)
+            if dev == "cuda":
+                torch.cuda.synchronize()
+            self._keep = (mine, allp)
+        return [[sk.import_device(allp.data_ptr() + 8 * CHAR_WORDS * (r * n + k)) for r in range(self.world)]
+                for k in range(n)]
+
+
+class ShardedContains(_FlagExchange):
     def __init__(self, sk, rank, world, dist, torch):
         self.sk, self.rank, self.world, self.dist, self.torch = sk, rank, world, dist, torch
 
@@ -41,66 +84,63 @@ class ShardedContains:
         pad_here = max(0, c1 - max(c0, len(full_string)))
         return ck.encrypt(text, pad_here, None, self.sk)
 
-    def run(self, shard, clear_pattern, op="contains"):
-        sk = self.sk
-        if op == "find":
-            if self.world != 1:
-                raise NotImplementedError("find is single-GPU in this round")
-            return sk.find_clear(shard, clear_pattern)
+    def _local(self, shard, clear_pattern):
         if len(shard) >= len(clear_pattern):
-            local = sk.contains_clear(shard, clear_pattern)
-        else:
-            local = sk.trivial(0)      # this rank owns no window
-        if self.world == 1:
-            return local
-        torch = self.torch
-        dev = "cuda" if torch.cuda.is_available() and sk.device_resident else "cpu"
-        mine = torch.empty(CHAR_WORDS, dtype=torch.int64, device=dev)
-        sk.export_device(local, mine.data_ptr())          # flushes this rank's DAG
-        allp = torch.empty(self.world * CHAR_WORDS, dtype=torch.int64, device=dev)
-        if dev == "cuda" and self.dist.get_backend() != "nccl":
-            # CPU-side process group (tests: several ranks sharing one GPU): stage through the host
-            parts_cpu = [torch.empty(CHAR_WORDS, dtype=torch.int64) for _ in range(self.world)]
-            self.dist.all_gather(parts_cpu, mine.cpu())
-            allp.copy_(torch.cat(parts_cpu))
-        else:
-            self.dist.all_gather_into_tensor(allp, mine)   # RCCL over xGMI: world x 65 568 B
-        if dev == "cuda":
-            torch.cuda.synchronize()
-        parts = [sk.import_device(allp.data_ptr() + 8 * CHAR_WORDS * r) for r in range(self.world)]
-        return sk.flags_or(parts)
+            return self.sk.contains_clear(shard, clear_pattern)
+        return self.sk.trivial(0)          # this rank owns no window
 
+    def run(self, shard, clear_pattern, op="contains"):
+        return self.run_batch([shard], clear_pattern, op=op)[0]
 
     def run_batch(self, shards, clear_pattern, op="contains", force_exchange=False):
         """contains() on several independent strings with ONE exchange: the local flags of all strings are
-        evaluated in one DAG flush, exported stream-ordered, gathered with one all-gather of len(shards) chars per
-        rank issued on the context's own HIP stream (no host synchronisation anywhere, so consecutive batches on
-        different contexts overlap), and OR-ed in one level."""
+        evaluated in one DAG flush, gathered with one all-gather of len(shards) chars per rank and OR-ed in one
+        level (every rank evaluates it, so every rank ends with the result, like the reference's return value)."""
         sk = self.sk
-        if (self.world == 1 and not force_exchange) or op != "contains":   # force_exchange: 1-rank RCCL test
-            return [self.run(sh, clear_pattern, op=op) for sh in shards]
-        torch = self.torch
-        import os
-        if not (torch.cuda.is_available() and sk.device_resident and self.dist.get_backend() == "nccl") \
-                or os.environ.get("FHS_SYNC_EXCHANGE"):
-            return [self.run(sh, clear_pattern, op=op) for sh in shards]   # host-synchronised path (tests, fallback)
-        n = len(shards)
-        local = [sk.contains_clear(sh, clear_pattern) if len(sh) >= len(clear_pattern) else sk.trivial(0)
-                 for sh in shards]
-        if getattr(self, "_ext", None) is None:
-            self._ext = torch.cuda.ExternalStream(sk.stream_handle())
-        with torch.cuda.stream(self._ext):
-            mine = torch.empty(n * CHAR_WORDS, dtype=torch.int64, device="cuda")
-            allp = torch.empty(self.world * n * CHAR_WORDS, dtype=torch.int64, device="cuda")
-            for k, l in enumerate(local):
-                sk.export_device_async(l, mine.data_ptr() + 8 * CHAR_WORDS * k)    # first call flushes the DAG
-            self.dist.all_gather_into_tensor(allp, mine)   # RCCL over xGMI: world x n x 65 568 B, stream-ordered
-        outs = []
-        for k in range(n):
-            parts = [sk.import_device(allp.data_ptr() + 8 * CHAR_WORDS * (r * n + k)) for r in range(self.world)]
-            outs.append(sk.flags_or(parts))
-        self._keep = (mine, allp)      # device buffers stay referenced until the next batch replaces them
-        return outs
+        if op == "find":
+            if self.world != 1:
+                raise NotImplementedError("find has no window-sharded form: use LevelParallel")
+            return [sk.find_clear(sh, clear_pattern) for sh in shards]
+        local = [self._local(sh, clear_pattern) for sh in shards]
+        if self.world == 1 and not force_exchange:          # force_exchange: 1-rank RCCL test
+            return local
+        return [sk.flags_or(parts) for parts in self._gather(local)]
+
+
+class ShardedEq(_FlagExchange):
+    """eq / eq_ignore_case of two padded strings of the SAME buffer length (BASELINE config 5): the character
+    positions are split into `world` contiguous ranges and a rank holds only its slice of both strings.  On
+    well-formed padded strings (NULs only at the end) the reference's semantics (src/server_key/mod.rs:1122-1149:
+    every position equal or both NUL, and equal lengths) is the conjunction of the same predicate over the slices,
+    so each rank evaluates the op on its slices and the partial flags are AND-ed after one all-gather of one
+    FheAsciiChar per rank."""
+
+    def __init__(self, sk, rank, world, dist, torch):
+        self.sk, self.rank, self.world, self.dist, self.torch = sk, rank, world, dist, torch
+
+    @staticmethod
+    def plan(n_chars, world):
+        base, extra = divmod(n_chars, world)
+        out, c = [], 0
+        for r in range(world):
+            cnt = base + (1 if r < extra else 0)
+            out.append((c, c + cnt))
+            c += cnt
+        return out
+
+    def upload_shard(self, ck, full_string, n_chars):
+        """This rank's slice of `full_string` padded with NULs to n_chars positions."""
+        c0, c1 = self.plan(n_chars, self.world)[self.rank]
+        text = full_string[c0:min(c1, len(full_string))]
+        return ck.encrypt(text, (c1 - c0) - len(text), None, self.sk)
+
+    def run(self, a_shard, b_shard, op="eq", force_exchange=False):
+        sk = self.sk
+        fn = {"eq": sk.eq, "eq_ignore_case": sk.eq_ignore_case}[op]
+        local = fn(a_shard, b_shard) if len(a_shard) else sk.trivial(1)
+        if self.world == 1 and not force_exchange:
+            return local
+        return sk.flags_and(self._gather([local])[0])
 
 
 class LevelParallel:

@@ -14,7 +14,7 @@ import os, sys
 import torch, torch.distributed as dist
 sys.path.insert(0, os.environ["FHS_ROOT"])
 from fhestring_amd.api import MyClientKey, MyServerKey
-from fhestring_amd.parallel import ShardedContains
+from fhestring_amd.parallel import ShardedContains, ShardedEq
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -28,6 +28,12 @@ for s, p in [("the quick brown fox jumps over", "n fo"), ("the quick brown fox j
     shard = job.upload_shard(ck, s, len(s) // world, len(p))
     got = ck.decrypt_char(job.run(shard, p))
     ok &= (got == int(p in s))
+ej = ShardedEq(sk, rank, world, dist, torch)
+for a, b, op in [("Sharded Equality", "Sharded Equality", "eq"), ("Sharded Equality", "Sharded Equalitx", "eq"),
+                 ("Sharded Equality", "sHARDED eQUALITY", "eq_ignore_case"), ("short", "shorter", "eq")]:
+    n = max(len(a), len(b)) + 1
+    got = ck.decrypt_char(ej.run(ej.upload_shard(ck, a, n), ej.upload_shard(ck, b, n), op))
+    ok &= (got == (int(a == b) if op == "eq" else int(a.lower() == b.lower())))
 dist.barrier()
 dist.destroy_process_group()
 sk.close()

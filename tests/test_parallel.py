@@ -28,7 +28,7 @@ import ctypes, os, sys
 import numpy as np
 import torch, torch.distributed as dist
 sys.path.insert(0, os.environ["FHS_ROOT"])
-from fhestring_amd.parallel import ShardedContains, CHAR_WORDS
+from fhestring_amd.parallel import ShardedContains, ShardedEq, CHAR_WORDS
 
 class ClearChar:
     def __init__(self, v): self.v = v
@@ -48,6 +48,10 @@ class ClearServerKey:                 # stands in for MyServerKey (same method n
         ctypes.memmove(buf.ctypes.data, ptr, buf.nbytes)
         return ClearChar(int(buf[2048]))
     def flags_or(self, parts): return ClearChar(int(any(p.v for p in parts)))
+    def flags_and(self, parts): return ClearChar(int(all(p.v for p in parts)))
+    def _text(self, chars): return bytes(c.v for c in chars).split(b"\0")[0]
+    def eq(self, a, b): return ClearChar(int(self._text(a) == self._text(b)))
+    def eq_ignore_case(self, a, b): return ClearChar(int(self._text(a).lower() == self._text(b).lower()))
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -62,6 +66,14 @@ for s, p in cases:
 strings = ["abcdefghij" * 3, "zzzzzzzzzzjabzzzzzzzzzzzzzzzzz", "q" * 30]
 shards = [job.upload_shard(ClearKey(), s, len(s) // world, 3) for s in strings]
 ok &= ([o.v for o in job.run_batch(shards, "jab")] == [int("jab" in s) for s in strings])
+# eq / eq_ignore_case with the character positions split over the ranks (config 5 shape)
+ej = ShardedEq(ClearServerKey(), rank, world, dist, torch)
+for a, b, op in [("hello world!", "hello world!", "eq"), ("hello world!", "hello worle!", "eq"), ("abc", "abcd", "eq"),
+                 ("Hello World", "hELLO wORLD", "eq_ignore_case"), ("Hello World", "hELLO wORLx", "eq_ignore_case")]:
+    n = max(len(a), len(b)) + 1
+    got = ej.run(ej.upload_shard(ClearKey(), a, n), ej.upload_shard(ClearKey(), b, n), op).v
+    want = int(a == b) if op == "eq" else int(a.lower() == b.lower())
+    ok &= (got == want)
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 3)
