@@ -111,6 +111,8 @@ def _declare(L):
         f.restype = i
     L.fhs_str_compare.argtypes = [vp, hp, sz, hp, sz, i, hp]
     L.fhs_str_compare.restype = i
+    L.fhs_str_compare_partial.argtypes = [vp, hp, sz, hp, sz, i, hp, hp]
+    L.fhs_str_compare_partial.restype = i
     for name in ("fhs_str_to_upper", "fhs_str_to_lower", "fhs_str_trim_end", "fhs_str_trim_start",
                  "fhs_str_trim", "fhs_bubble_zeroes_right"):
         f = getattr(L, name)
@@ -136,6 +138,8 @@ def _declare(L):
         f = getattr(L, name)
         f.argtypes = [vp, hp, sz, hp]
         f.restype = i
+    L.fhs_flags_first_decides.argtypes = [vp, hp, hp, sz, i, hp]
+    L.fhs_flags_first_decides.restype = i
     L.fhs_str_split_dim.argtypes = [i, sz]
     L.fhs_str_split_dim.restype = sz
     L.fhs_str_split.argtypes = [vp, i, hp, sz, hp, sz, h, hp, sz, C.POINTER(sz), hp]

@@ -413,6 +413,13 @@ class MyServerKey:
     def flags_or(self, flags): return self._flags("fhs_flags_or", flags)
     def flags_and(self, flags): return self._flags("fhs_flags_and", flags)
 
+    def flags_first_decides(self, any_diff, verdict, tie):
+        """Combine compare_partial() results of consecutive ranges: the first range that differs decides."""
+        out = C.c_uint64()
+        self.ctx._check(self.ctx._L.fhs_flags_first_decides(self.ctx._h, _harr(any_diff), _harr(verdict),
+                                                            len(any_diff), int(tie), C.byref(out)))
+        return FheAsciiChar(self, out.value)
+
     def stats(self, reset=False):
         from ._lib import Stats
         st = Stats()
@@ -505,6 +512,15 @@ class MyServerKey:
         self.ctx._check(self.ctx._L.fhs_str_compare(self.ctx._h, _harr(a), len(a), _harr(b), len(b), cmp,
                                                     C.byref(out)))
         return FheAsciiChar(self, out.value)
+
+    def compare_partial(self, a, b, cmp):
+        """(any position differs, verdict at the first differing position) of two equally long slices:
+        the per-GPU partial of a position-sharded lt/le/gt/ge (cmp = 0/1/2/3)."""
+        a, b = self._chars(a), self._chars(b)
+        d, v = C.c_uint64(), C.c_uint64()
+        self.ctx._check(self.ctx._L.fhs_str_compare_partial(self.ctx._h, _harr(a), len(a), _harr(b), len(b), cmp,
+                                                            C.byref(d), C.byref(v)))
+        return FheAsciiChar(self, d.value), FheAsciiChar(self, v.value)
 
     def lt(self, a, b, public_parameters=None): return self._compare(a, b, 0)   # mod.rs:1577
     def le(self, a, b, public_parameters=None): return self._compare(a, b, 1)   # mod.rs:1613

@@ -221,6 +221,26 @@ int fhs_str_compare(fhs_ctx *c, const fhs_char_t *a, size_t na, const fhs_char_t
     return FHS_OK;
 }
 
+int fhs_str_compare_partial(fhs_ctx *c, const fhs_char_t *a, size_t na, const fhs_char_t *b, size_t nb, int cmp,
+                            fhs_char_t *any_diff, fhs_char_t *verdict) {
+    if (!ok_all(c, a, na) || !ok_all(c, b, nb) || !any_diff || !verdict || cmp < 0 || cmp > 3 || na != nb) return bad(c);
+    Strings S(&c->eng);
+    FChar d, v;
+    S.f_cmp_partial(load_str(c->eng, a, na), load_str(c->eng, b, nb), cmp, &d, &v);
+    *any_diff = store(c->eng, d);
+    *verdict = store(c->eng, v);
+    return FHS_OK;
+}
+
+int fhs_flags_first_decides(fhs_ctx *c, const fhs_char_t *any_diff, const fhs_char_t *verdict, size_t n, int tie,
+                            fhs_char_t *out) {
+    if (!ok_all(c, any_diff, n) || !ok_all(c, verdict, n) || !out) return bad(c);
+    Strings S(&c->eng);
+    FChar r = S.flags_first_decides(load_str(c->eng, any_diff, n), load_str(c->eng, verdict, n), tie);
+    *out = store(c->eng, r);
+    return FHS_OK;
+}
+
 #define STR_MAP_OP(NAME, METHOD)                                                  \
     int NAME(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out) {        \
         if (!ok_all(c, s, n) || (n && !out)) return bad(c);                       \

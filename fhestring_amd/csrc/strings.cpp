@@ -719,6 +719,48 @@ FChar Strings::f_comparison(const FStr &a_in, const FStr &b_in, int cmp) {
     return ch_flag(e_, lin(e_, {{1, &sel}, {1, &ret}}));
 }
 
+// The positional half of f_comparison on two equally long slices: (any position differs, verdict at the FIRST
+// differing position; 0 when none differs).  Multi-GPU position sharding combines these per-range partials: the
+// first range that differs decides (fhestring_amd/parallel.py ShardedCmp).
+void Strings::f_cmp_partial(const FStr &a, const FStr &b, int cmp, FChar *any_diff_out, FChar *verdict_out) {
+    const size_t n = std::min(a.size(), b.size());
+    if (n == 0) {
+        *any_diff_out = t(0);
+        *verdict_out = t(0);
+        return;
+    }
+    Ref one = trivial_block(e_, 1);
+    std::vector<Ref> differs(n), x(n);
+    const int xl = (cmp == 0 || cmp == 1) ? LUT_CMP_LT : LUT_CMP_GT;
+    for (size_t i = 0; i < n; i++) {
+        Ref eq = and_tree(block_eq_flags(a[i], b[i]));
+        differs[i] = lin(e_, {{1, &one}, {-1, &eq}});
+        x[i] = blk_cmp_flag(a[i], b[i], xl);
+    }
+    std::vector<Ref> before = prefix_or(differs);
+    std::vector<Ref> pick(n);
+    for (size_t i = 0; i < n; i++) pick[i] = pbs(lin(e_, {{2, &x[i]}, {1, &before[i]}}), LUT_IS2);
+    *verdict_out = ch_flag(e_, or_tree(pick));               // at most one pick is set
+    *any_diff_out = ch_flag(e_, or_tree(differs));
+}
+
+// Combines per-range partials of f_cmp_partial (ranges in string order): the first range that differs decides;
+// if none differs the result is `tie` (1 for le / ge, 0 for lt / gt: equal buffers are equal strings).
+FChar Strings::flags_first_decides(const FStr &any_diff, const FStr &verdict, int tie) {
+    const size_t n = std::min(any_diff.size(), verdict.size());
+    if (n == 0) return t(tie ? 1 : 0);
+    std::vector<Ref> d(n), pick(n);
+    for (size_t r = 0; r < n; r++) d[r] = any_diff[r].b[0];
+    std::vector<Ref> before = prefix_or(d);                  // exclusive: some earlier range differs
+    for (size_t r = 0; r < n; r++) pick[r] = pbs(lin(e_, {{2, &verdict[r].b[0]}, {1, &before[r]}}), LUT_IS2);
+    Ref ret = or_tree(pick);                                 // at most one pick is set
+    if (tie) {                                               // ret = 1 implies a difference: the sum stays in {0, 1}
+        Ref one = trivial_block(e_, 1), any = or_tree(d);
+        ret = lin(e_, {{1, &ret}, {1, &one}, {-1, &any}});
+    }
+    return ch_flag(e_, ret);
+}
+
 std::vector<Ref> Strings::suffix_or(const std::vector<Ref> &f) {
     std::vector<Ref> rev(f.rbegin(), f.rend());
     std::vector<Ref> p = prefix_or(rev);

@@ -31,6 +31,10 @@ class Strings {
     FChar ne(const FStr &a, const FStr &b);
     FChar eq_ignore_case(const FStr &a, const FStr &b);
     FChar comparison(const FStr &a, const FStr &b, int cmp);   // 0 lt, 1 le, 2 gt, 3 ge
+    // positional half on two equally long slices: (any position differs, verdict at the first differing position)
+    void f_cmp_partial(const FStr &a, const FStr &b, int cmp, FChar *any_diff_out, FChar *verdict_out);
+    // combine such partials over consecutive ranges: the first range that differs decides, `tie` if none does
+    FChar flags_first_decides(const FStr &any_diff, const FStr &verdict, int tie);
     FStr to_upper(const FStr &s);
     FStr to_lower(const FStr &s);
     FStr replace(const FStr &s, const FStr &from, const FStr &to);

@@ -143,6 +143,28 @@ class ShardedEq(_FlagExchange):
         return sk.flags_and(self._gather([local])[0])
 
 
+class ShardedCmp(ShardedEq):
+    """lt / le / gt / ge of two padded strings of the SAME buffer length with the character positions split over
+    the ranks (BASELINE config 5, `<=`).  Each rank reduces its slices to (some position differs, verdict at the
+    first differing position) -- the positional half of src/server_key/mod.rs:1497-1518 -- the two flags of every
+    rank are gathered with one all-gather, and the first range that differs decides; when nothing differs the
+    buffers, hence the strings, are equal (le / ge -> 1, lt / gt -> 0).  NUL padding compares below every
+    character, which is exactly the reference's length tie-break."""
+
+    def run(self, a_shard, b_shard, op="le", force_exchange=False):
+        sk = self.sk
+        cmp = {"lt": 0, "le": 1, "gt": 2, "ge": 3}[op]
+        if len(a_shard):
+            d, v = sk.compare_partial(a_shard, b_shard, cmp)
+        else:
+            d, v = sk.trivial(0), sk.trivial(0)
+        if self.world == 1 and not force_exchange:
+            ds, vs = [d], [v]
+        else:
+            ds, vs = self._gather([d, v])
+        return sk.flags_first_decides(ds, vs, 1 if op in ("le", "ge") else 0)
+
+
 class LevelParallel:
     """Generic multi-GPU execution of ANY op: the ranks hold the same ciphertexts, record the same DAG
     and split every PBS level; one all-gather of the level's outputs (width x 16 392 B) per level.

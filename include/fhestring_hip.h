@@ -152,6 +152,11 @@ int fhs_str_ne(fhs_ctx *c, const fhs_char_t *a, size_t na, const fhs_char_t *b, 
 int fhs_str_eq_ignore_case(fhs_ctx *c, const fhs_char_t *a, size_t na, const fhs_char_t *b, size_t nb, fhs_char_t *out);/* mod.rs:1221 */
 /* cmp: 0 lt, 1 le, 2 gt, 3 ge (enum Comparison, fhestring.rs:11-16) */
 int fhs_str_compare(fhs_ctx *c, const fhs_char_t *a, size_t na, const fhs_char_t *b, size_t nb, int cmp, fhs_char_t *out); /* mod.rs:1470 */
+/* Positional half of the comparison (mod.rs:1497-1518) on two slices of equal length n: *any_diff = some position
+ * differs, *verdict = a[i] < b[i] (cmp 0,1) resp. a[i] > b[i] (cmp 2,3) at the FIRST differing position, 0 if none.
+ * Per-GPU partial of a position-sharded comparison: the first range that differs decides. */
+int fhs_str_compare_partial(fhs_ctx *c, const fhs_char_t *a, size_t na, const fhs_char_t *b, size_t nb, int cmp,
+                            fhs_char_t *any_diff, fhs_char_t *verdict);
 int fhs_str_to_upper(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out /*[n]*/);                               /* mod.rs:65 */
 int fhs_str_to_lower(fhs_ctx *c, const fhs_char_t *s, size_t n, fhs_char_t *out /*[n]*/);                               /* mod.rs:110 */
 /* out_cap >= fhs_str_replace_len(n, m_from, m_to); *out_len receives the produced length */
@@ -181,6 +186,10 @@ int fhs_str_split(fhs_ctx *c, int kind, const fhs_char_t *s, size_t n, const fhs
  * used to combine per-GPU partial results after the gather. */
 int fhs_flags_or(fhs_ctx *c, const fhs_char_t *flags, size_t n, fhs_char_t *out);
 int fhs_flags_and(fhs_ctx *c, const fhs_char_t *flags, size_t n, fhs_char_t *out);
+/* Combines the partials of fhs_str_compare_partial over n consecutive ranges (string order): the first range that
+ * differs decides; `tie` (0 or 1) if none differs. */
+int fhs_flags_first_decides(fhs_ctx *c, const fhs_char_t *any_diff, const fhs_char_t *verdict, size_t n, int tie,
+                            fhs_char_t *out);
 
 /* ---- level-parallel multi-GPU execution (one process per GPU; SURVEY 5 "per-level" pattern) --------
  * Every rank holds the same ciphertexts and records the same DAG.  fhs_flush_plan levelises it;

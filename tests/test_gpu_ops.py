@@ -226,3 +226,21 @@ def test_server_key_from_key_file(tmp_path):
     finally:
         sk.close()
         ck.close()
+
+
+def test_compare_partial_and_first_decides_single_gpu(product):
+    """The per-range partials of a position-sharded comparison, combined on one GPU over 3 ranges, equal the whole
+    comparison and python's (NUL padding sorts below every character = the reference's length tie-break)."""
+    import operator
+    ck, sk = product
+    sk.set_mode(1)
+    for a, b in [("lexicographic", "lexicographic"), ("lexicographic", "lexicogrbphic"), ("lexicon", "lexicographic"),
+                 ("b", "abcdefghijklm")]:
+        n = max(len(a), len(b)) + 1
+        ea, eb = ck.encrypt(a, n - len(a), None, sk), ck.encrypt(b, n - len(b), None, sk)
+        cuts = [0, n // 3, 2 * n // 3, n]
+        for cmp, (name, f) in enumerate([("lt", operator.lt), ("le", operator.le), ("gt", operator.gt), ("ge", operator.ge)]):
+            ds, vs = zip(*[sk.compare_partial(ea.chars[cuts[k]:cuts[k + 1]], eb.chars[cuts[k]:cuts[k + 1]], cmp)
+                           for k in range(3)])
+            got = ck.decrypt_char(sk.flags_first_decides(list(ds), list(vs), 1 if name in ("le", "ge") else 0))
+            assert got == int(f(a, b)) == ck.decrypt_char(getattr(sk, name)(ea, eb)), (a, b, name)

@@ -14,7 +14,7 @@ import os, sys
 import torch, torch.distributed as dist
 sys.path.insert(0, os.environ["FHS_ROOT"])
 from fhestring_amd.api import MyClientKey, MyServerKey
-from fhestring_amd.parallel import ShardedContains, ShardedEq
+from fhestring_amd.parallel import ShardedContains, ShardedEq, ShardedCmp
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,6 +34,13 @@ for a, b, op in [("Sharded Equality", "Sharded Equality", "eq"), ("Sharded Equal
     n = max(len(a), len(b)) + 1
     got = ck.decrypt_char(ej.run(ej.upload_shard(ck, a, n), ej.upload_shard(ck, b, n), op))
     ok &= (got == (int(a == b) if op == "eq" else int(a.lower() == b.lower())))
+import operator
+cj = ShardedCmp(sk, rank, world, dist, torch)
+for a, b in [("apple pie", "apple pie"), ("apple pie", "apple pif"), ("bpple", "apple pie"), ("abc", "abcd")]:
+    n = max(len(a), len(b)) + 1
+    for op, f in (("lt", operator.lt), ("le", operator.le), ("gt", operator.gt), ("ge", operator.ge)):
+        got = ck.decrypt_char(cj.run(cj.upload_shard(ck, a, n), cj.upload_shard(ck, b, n), op))
+        ok &= (got == int(f(a, b)))
 dist.barrier()
 dist.destroy_process_group()
 sk.close()

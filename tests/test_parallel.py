@@ -28,7 +28,7 @@ import ctypes, os, sys
 import numpy as np
 import torch, torch.distributed as dist
 sys.path.insert(0, os.environ["FHS_ROOT"])
-from fhestring_amd.parallel import ShardedContains, ShardedEq, CHAR_WORDS
+from fhestring_amd.parallel import ShardedContains, ShardedEq, ShardedCmp, CHAR_WORDS
 
 class ClearChar:
     def __init__(self, v): self.v = v
@@ -50,6 +50,16 @@ class ClearServerKey:                 # stands in for MyServerKey (same method n
     def flags_or(self, parts): return ClearChar(int(any(p.v for p in parts)))
     def flags_and(self, parts): return ClearChar(int(all(p.v for p in parts)))
     def _text(self, chars): return bytes(c.v for c in chars).split(b"\0")[0]
+    def compare_partial(self, a, b, cmp):
+        x, y = bytes(c.v for c in a), bytes(c.v for c in b)
+        diff = [i for i in range(len(x)) if x[i] != y[i]]
+        if not diff: return ClearChar(0), ClearChar(0)
+        i = diff[0]
+        return ClearChar(1), ClearChar(int(x[i] < y[i]) if cmp in (0, 1) else int(x[i] > y[i]))
+    def flags_first_decides(self, ds, vs, tie):
+        for d, v in zip(ds, vs):
+            if d.v: return ClearChar(v.v)
+        return ClearChar(tie)
     def eq(self, a, b): return ClearChar(int(self._text(a) == self._text(b)))
     def eq_ignore_case(self, a, b): return ClearChar(int(self._text(a).lower() == self._text(b).lower()))
 
@@ -74,6 +84,14 @@ for a, b, op in [("hello world!", "hello world!", "eq"), ("hello world!", "hello
     got = ej.run(ej.upload_shard(ClearKey(), a, n), ej.upload_shard(ClearKey(), b, n), op).v
     want = int(a == b) if op == "eq" else int(a.lower() == b.lower())
     ok &= (got == want)
+cj = ShardedCmp(ClearServerKey(), rank, world, dist, torch)
+import operator
+OPS = {"lt": operator.lt, "le": operator.le, "gt": operator.gt, "ge": operator.ge}
+for a, b in [("apple pie", "apple pie"), ("apple pie", "apple pif"), ("bpple pie", "apple pie"), ("abc", "abcd"), ("abcd", "abc"), ("", "")]:
+    n = max(len(a), len(b)) + 1
+    for op, f in OPS.items():
+        got = cj.run(cj.upload_shard(ClearKey(), a, n), cj.upload_shard(ClearKey(), b, n), op).v
+        ok &= (got == int(f(a, b)))
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 3)
