@@ -154,6 +154,9 @@ def main():
     from fhestring_amd.api import MyClientKey, MyServerKey, BIG_CT
     from fhestring_amd.parallel import ShardedContains
 
+    if args.op == "find" and args.chars * world + 1 >= 255 + args.pattern_len:
+        raise SystemExit("find returns an encrypted u8 index: the reference panics for strings of 255 + m characters or more "
+                         "(src/server_key/mod.rs:1025-1027); lower --chars or the number of GPUs")
     if args.op == "find" and world > 1 and args.dist_mode == "windows":
         args.dist_mode = "levels"     # find has no window-sharded form yet: every rank splits every level instead
     m = args.pattern_len
