@@ -158,8 +158,12 @@ def _declare(L):
     L.fhs_get_stats.restype = i
     L.fhs_reset_stats.argtypes = [vp]
     L.fhs_reset_stats.restype = i
-    L.fhs_client_create.argtypes = [u64, C.POINTER(vp)]
+    L.fhs_client_create.argtypes = [C.POINTER(vp)]
     L.fhs_client_create.restype = i
+    L.fhs_client_create_insecure_seeded.argtypes = [u64, C.POINTER(vp)]
+    L.fhs_client_create_insecure_seeded.restype = i
+    L.fhs_chacha20_block.argtypes = [vp, C.c_uint32, vp, vp]
+    L.fhs_chacha20_block.restype = None
     L.fhs_client_destroy.argtypes = [vp]
     L.fhs_client_destroy.restype = None
     L.fhs_client_bsk.argtypes = [vp]

@@ -121,15 +121,22 @@ MODE_FUSED = 1
 
 
 class MyClientKey:
-    """Host-CPU client key (keygen / encrypt / decrypt), like the reference's."""
+    """Host-CPU client key (keygen / encrypt / decrypt), like the reference's.
 
-    def __init__(self, seed=0xF5E57121, _handle=None):
+    MyClientKey() draws everything from a ChaCha20 generator keyed with OS entropy (fhs_client_create), like the
+    reference's OS-seeded tfhe-rs CSPRNG.  MyClientKey(seed) is the TEST / BENCHMARK constructor
+    (fhs_client_create_insecure_seeded): reproducible keys, identical on every rank, never for real data."""
+
+    def __init__(self, seed=None, _handle=None):
         self._L = lib()
         if _handle is not None:
             self._h = _handle
             return
         h = C.c_void_p()
-        rc = self._L.fhs_client_create(int(seed), C.byref(h))
+        if seed is None:
+            rc = self._L.fhs_client_create(C.byref(h))
+        else:
+            rc = self._L.fhs_client_create_insecure_seeded(int(seed), C.byref(h))
         if rc != 0:
             raise FhsError("fhs_client_create failed (%d)" % rc)
         self._h = h
@@ -147,7 +154,7 @@ class MyClientKey:
         return cls(_handle=h)
 
     @classmethod
-    def from_params(cls, params=None, num_blocks=4, seed=0xF5E57121):   # client_key.rs:30-35
+    def from_params(cls, params=None, num_blocks=4, seed=None):   # client_key.rs:30-35 (seed: tests only)
         assert num_blocks == 4
         return cls(seed)
 

@@ -200,7 +200,8 @@ def main(argv=None):
     ap.add_argument("--arith", choices=["exact", "fft"], default="exact",
                     help="arithmetic of blind rotation: exact two-prime NTT or f64 FFT (fhs_set_arithmetic)")
     ap.add_argument("--methods", default="", help="comma-separated subset (default: all non-split methods)")
-    ap.add_argument("--seed", type=int, default=0xF5E57121)
+    ap.add_argument("--seed", type=int, default=None,
+                    help="reproducible (insecure) keys for tests; default: OS entropy, like the reference")
     a = ap.parse_args(argv)
     assert a.n <= MAX_REPETITIONS, "n must be <= MAX_REPETITIONS"  # src/main.rs:37-40
     ck = MyClientKey.from_params(seed=a.seed)                     # src/main.rs:43

@@ -90,6 +90,7 @@ int Context::init(int device_id) {
     HIP_TRY(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return fail(-2, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    HIP_TRY(prepare_device_for_kernels(), "hipFuncSetAttribute (dynamic LDS)");
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
     wg_slots = 4 * prop.multiProcessorCount;
     HIP_TRY(hipMalloc(&d_work_counter, 64), "hipMalloc counter");

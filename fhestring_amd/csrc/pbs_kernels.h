@@ -72,6 +72,8 @@ struct LinTerm {
 };
 
 size_t blind_rotate_lds_bytes();
+// per-device function attributes (dynamic LDS above 64 KB); call with the device current
+hipError_t prepare_device_for_kernels();
 hipError_t read_device_ntt_consts(double *fwd_uni /*[64]*/, double *inv_uni /*[128]*/, double *crt);
 hipError_t launch_blind_rotate(const BlindRotateParams &p, hipStream_t s);
 hipError_t launch_blind_rotate_fft(const BlindRotateFftParams &p, hipStream_t s);    // 2 wavefronts per ciphertext

@@ -403,16 +403,15 @@ hipError_t read_device_ntt_consts(double *fwd_uni /*[64]*/, double *inv_uni /*[1
 
 size_t blind_rotate_lds_bytes() { return (size_t)4 * LDS_WAVE_SLOTS * sizeof(double); }
 
+// The exact-NTT kernel asks for more than 64 KB of dynamic LDS: the opt-in is a per-DEVICE function attribute, so it
+// is set for the current device by Context::init (every context, any thread) and not cached per process.
+hipError_t prepare_device_for_kernels() {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(blind_rotate_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)blind_rotate_lds_bytes());
+}
+
 hipError_t launch_blind_rotate(const BlindRotateParams &p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(blind_rotate_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)blind_rotate_lds_bytes());
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     hipLaunchKernelGGL(blind_rotate_kernel, dim3(p.B), dim3(256), blind_rotate_lds_bytes(), s, p);
     return hipGetLastError();
 }

@@ -215,7 +215,14 @@ int fhs_get_stats(fhs_ctx *ctx, fhs_stats *out);
 int fhs_reset_stats(fhs_ctx *ctx);
 
 /* ---- client side (MyClientKey, src/client_key.rs) -- host CPU, like the reference -- */
-int fhs_client_create(uint64_t seed, fhs_client **out);                  /* from_params :30-35 */
+/* Keys, masks and noise come from ChaCha20 keyed with 256 bits of getrandom(2) entropy (the reference: tfhe-rs's
+ * OS-seeded concrete-csprng); separate streams for secret keys, public masks and noise. */
+int fhs_client_create(fhs_client **out);                                 /* from_params :30-35 */
+/* TEST / BENCHMARK ONLY: the same generator keyed from a 64-bit seed -> reproducible keys and ciphertexts (identical
+ * keys on every rank of a multi-GPU run, fixed test vectors).  At most 64 bits of entropy: never for real data. */
+int fhs_client_create_insecure_seeded(uint64_t seed, fhs_client **out);
+/* Diagnostic: one block of the generator's ChaCha20 (RFC 8439 2.3.2 known-answer test in tests/test_cabi.py). */
+void fhs_chacha20_block(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3], uint32_t out[16]);
 void fhs_client_destroy(fhs_client *ck);
 const uint64_t *fhs_client_bsk(const fhs_client *ck);                    /* get_server_key :37-39 */
 const uint64_t *fhs_client_ksk(const fhs_client *ck);
