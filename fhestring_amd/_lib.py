@@ -154,6 +154,45 @@ def _declare(L):
     L.fhs_flush_level_commit.restype = i
     L.fhs_stream_sync.argtypes = [vp]
     L.fhs_stream_sync.restype = i
+    szp = C.POINTER(C.c_size_t)
+    L.fhs_dist_unique_id.argtypes = [vp]
+    L.fhs_dist_unique_id.restype = i
+    L.fhs_dist_init.argtypes = [vp, i, i, C.c_char_p]
+    L.fhs_dist_init.restype = i
+    L.fhs_dist_init_host_transport.argtypes = [vp, i, i, vp, vp]
+    L.fhs_dist_init_host_transport.restype = i
+    L.fhs_dist_shutdown.argtypes = [vp]
+    L.fhs_dist_shutdown.restype = i
+    L.fhs_dist_rank.argtypes = [vp]
+    L.fhs_dist_rank.restype = i
+    L.fhs_dist_world.argtypes = [vp]
+    L.fhs_dist_world.restype = i
+    L.fhs_dist_level_parallel.argtypes = [vp, i]
+    L.fhs_dist_level_parallel.restype = i
+    L.fhs_dist_plan_windows.argtypes = [sz, sz, i, i, szp, szp, szp, szp]
+    L.fhs_dist_plan_windows.restype = None
+    L.fhs_dist_plan_positions.argtypes = [sz, i, i, szp, szp]
+    L.fhs_dist_plan_positions.restype = None
+    L.fhs_dist_allgather_chars.argtypes = [vp, hp, sz, hp]
+    L.fhs_dist_allgather_chars.restype = i
+    L.fhs_dist_allgather_flags.argtypes = [vp, hp, sz, hp]
+    L.fhs_dist_allgather_flags.restype = i
+    L.fhs_dist_str_contains.argtypes = [vp, hp, sz, hp, sz, hp]
+    L.fhs_dist_str_contains.restype = i
+    L.fhs_dist_str_contains_clear.argtypes = [vp, hp, sz, C.c_char_p, sz, hp]
+    L.fhs_dist_str_contains_clear.restype = i
+    L.fhs_dist_str_find.argtypes = [vp, hp, sz, hp, sz, sz, sz, hp]
+    L.fhs_dist_str_find.restype = i
+    L.fhs_dist_str_find_clear.argtypes = [vp, hp, sz, C.c_char_p, sz, sz, sz, hp]
+    L.fhs_dist_str_find_clear.restype = i
+    L.fhs_dist_str_eq.argtypes = [vp, hp, sz, hp, sz, i, hp]
+    L.fhs_dist_str_eq.restype = i
+    L.fhs_dist_str_compare.argtypes = [vp, hp, sz, hp, sz, i, hp]
+    L.fhs_dist_str_compare.restype = i
+    L.fhs_debug_capture_pbs_inputs.argtypes = [vp, C.c_size_t]
+    L.fhs_debug_capture_pbs_inputs.restype = i
+    L.fhs_debug_capture_read.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.fhs_debug_capture_read.restype = i
     L.fhs_get_stats.argtypes = [vp, vp]
     L.fhs_get_stats.restype = i
     L.fhs_reset_stats.argtypes = [vp]
@@ -188,9 +227,14 @@ def _declare(L):
     L.fhs_client_secret_keys.restype = i
 
 
+class CaptureRec(C.Structure):
+    _fields_ = [("level", C.c_uint32), ("index", C.c_uint32), ("lut", C.c_uint32), ("n_terms", C.c_uint32),
+                ("sum_c2", C.c_int64), ("konst", C.c_int32), ("width", C.c_uint32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("pbs_executed", C.c_uint64), ("pbs_folded", C.c_uint64), ("levels", C.c_uint64),
-                ("max_level_width", C.c_uint64), ("blocks_live", C.c_uint64)]
+                ("max_level_width", C.c_uint64), ("blocks_live", C.c_uint64), ("max_input_sum_c2", C.c_uint64)]
 
 
 def fft_tables():

@@ -394,8 +394,6 @@ class MyServerKey:
 
     def flush(self, wait=True):
         """Run every pending PBS level.  wait=False only enqueues the launches (fhs_flush_async)."""
-        if getattr(self, "_dist", None) is not None:
-            return self._dist.flush()
         if wait:
             self.ctx._check(self.ctx._L.fhs_flush(self.ctx._h))
         else:
@@ -405,11 +403,12 @@ class MyServerKey:
         self.ctx._check(self.ctx._L.fhs_stream_sync(self.ctx._h))
 
     def enable_level_parallel(self, rank, world, dist, torch):
-        """Level-parallel multi-GPU mode (fhestring_amd.parallel.LevelParallel): every rank records the
-        same DAG on the same ciphertexts and runs 1/world of every PBS level."""
-        from .parallel import LevelParallel
-        self.ctx._check(self.ctx._L.fhs_dist_config(self.ctx._h, int(rank), int(world)))
-        self._dist = LevelParallel(self, rank, world, dist, torch) if world > 1 else None
+        """Level-parallel multi-GPU mode inside the library (fhs_dist_level_parallel): every rank records the same
+        DAG on the same ciphertexts and runs 1/world of every PBS level; one stream-ordered all-gather per level."""
+        from .parallel import Dist
+        if world > 1:
+            self.dist = Dist.from_torch(self, dist, torch, rank, world)
+            self.dist.level_parallel(True)
 
     def _flags(self, name, flags):
         flags = self._chars(flags)
@@ -426,6 +425,24 @@ class MyServerKey:
         self.ctx._check(self.ctx._L.fhs_flags_first_decides(self.ctx._h, _harr(any_diff), _harr(verdict),
                                                             len(any_diff), int(tie), C.byref(out)))
         return FheAsciiChar(self, out.value)
+
+    def capture_pbs_inputs(self, max_rows_per_level):
+        """fhs_debug_capture_pbs_inputs: sample the PBS inputs of every executed level (0 = off)."""
+        self.ctx._check(self.ctx._L.fhs_debug_capture_pbs_inputs(self.ctx._h, int(max_rows_per_level)))
+
+    def read_capture(self):
+        """-> (rows [n, 2049] u64, records: structured array level/index/lut/n_terms/sum_c2/konst/width)."""
+        from ._lib import CaptureRec
+        L, h = self.ctx._L, self.ctx._h
+        n = C.c_size_t()
+        self.ctx._check(L.fhs_debug_capture_read(h, None, None, 0, C.byref(n)))
+        rows = np.zeros((n.value, BIG_CT), np.uint64)
+        recs = (CaptureRec * max(1, n.value))()
+        got = C.c_size_t()
+        self.ctx._check(L.fhs_debug_capture_read(h, _ptr(rows), C.cast(recs, C.c_void_p), n.value, C.byref(got)))
+        dt = np.dtype([("level", "u4"), ("index", "u4"), ("lut", "u4"), ("n_terms", "u4"), ("sum_c2", "i8"),
+                       ("konst", "i4"), ("width", "u4")])
+        return rows[:got.value], np.frombuffer(recs, dtype=dt, count=got.value).copy()
 
     def stats(self, reset=False):
         from ._lib import Stats

@@ -88,6 +88,32 @@ int fhs_pbs_batch_device(fhs_ctx *ctx, const uint64_t *d_in, const uint32_t *d_l
                                          hip_stream ? (hipStream_t)hip_stream : ctx->eng.ctx.stream);
 }
 
+int fhs_debug_capture_pbs_inputs(fhs_ctx *ctx, size_t max_rows_per_level) {
+    if (!ctx) return FHS_ERR_ARG;
+    if (int rc = ctx->eng.flush()) return rc;
+    ctx->eng.capture_max_rows = max_rows_per_level;
+    if (!max_rows_per_level) {
+        ctx->eng.capture_rows.clear(); ctx->eng.capture_rows.shrink_to_fit();
+        ctx->eng.capture_recs.clear();
+    }
+    return FHS_OK;
+}
+int fhs_debug_capture_read(fhs_ctx *ctx, uint64_t *rows, fhs_capture_rec *recs, size_t cap, size_t *n) {
+    if (!ctx || !n) return FHS_ERR_ARG;
+    auto &e = ctx->eng;
+    static_assert(sizeof(fhs_capture_rec) == sizeof(fhs::Engine::CaptureRec), "record layout");
+    const size_t have = e.capture_recs.size();
+    if (!rows || !recs) { *n = have; return FHS_OK; }
+    const size_t k = std::min(cap, have);
+    std::copy(e.capture_rows.begin(), e.capture_rows.begin() + k * fhs::BIG_CT, rows);
+    std::copy(e.capture_recs.begin(), e.capture_recs.begin() + k,
+              reinterpret_cast<fhs::Engine::CaptureRec *>(recs));
+    *n = k;
+    e.capture_rows.clear();
+    e.capture_recs.clear();
+    return FHS_OK;
+}
+
 int fhs_kernel_timing(fhs_ctx *ctx, int reset, double *blind_rotate_ms, double *keyswitch_ms,
                       uint64_t *n_blind_rotate, uint64_t *n_keyswitch, uint64_t *pbs_in_launches) {
     if (!ctx) return FHS_ERR_ARG;

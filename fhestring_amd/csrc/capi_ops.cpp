@@ -402,6 +402,7 @@ int fhs_get_stats(fhs_ctx *c, fhs_stats *out) {
     out->levels = c->eng.stats.levels;
     out->max_level_width = c->eng.stats.max_level_width;
     out->blocks_live = c->eng.blocks_live();
+    out->max_input_sum_c2 = c->eng.stats.max_input_sum_c2;
     return FHS_OK;
 }
 int fhs_reset_stats(fhs_ctx *c) {

@@ -99,6 +99,9 @@ int Context::init(int device_id) {
 
 void Context::shutdown() {
     if (stream) (void)hipStreamSynchronize(stream);
+    dist.shutdown();
+    xchg_send.release();
+    xchg_recv.release();
     timer.destroy();
     ms_buf.release();
     ks_buf.release();

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#include "dist.h"
 #include "fft_tables.h"
 #include "ntt_tables.h"
 #include "pbs_kernels.h"
@@ -68,6 +69,10 @@ class Context {
     // blind rotation in the selected arithmetic (timed as kernel kind 0)
     int blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const uint64_t *d_luts, uint64_t *d_out,
                      uint64_t *const *d_out_ptrs, size_t B, hipStream_t s);
+
+    // multi-GPU exchange (fhs_dist_init): RCCL communicator of this context, or a host transport
+    Dist dist;
+    DevBuf xchg_send, xchg_recv;     // char exchange of the sharded string ops / level slices of the level-parallel flush
 
     // scratch
     DevBuf dig_buf;                  // keyswitch digits of the current batch

@@ -189,6 +189,7 @@ Bid Engine::pbs(Bid x, int lut) {
 // flush: plan every level on the host, upload the plan once, enqueue all launches
 // ------------------------------------------------------------------------------------------
 int Engine::flush() {
+    if (level_parallel && ctx.dist.active()) return flush_level_parallel();   // world 1 too: same stream-ordered path
     if (dist_world > 1 && !pending_.empty())
         return ctx.fail(-3, "distributed context: pending PBS must be run with fhs_flush_plan/level_exec/level_commit");
     int rc = plan_flush();
@@ -199,9 +200,68 @@ int Engine::flush() {
     return 0;
 }
 
+// All levels and all exchanges are enqueued back to back: with RCCL nothing waits on the host.
+int Engine::flush_level_parallel() {
+    int rc = plan_flush();
+    if (rc) return rc;
+    if (plan_.levels.empty()) return 0;
+    if (!ctx.dist.active()) return ctx.fail(-3, "level-parallel flush without a transport (fhs_dist_init)");
+    const size_t world = (size_t)ctx.dist.world, rank = (size_t)ctx.dist.rank;
+    const size_t cap_max = (plan_.max_width + world - 1) / world;
+    if (ctx.xchg_send.cap < cap_max * BIG_CT * 8 || ctx.xchg_recv.cap < world * cap_max * BIG_CT * 8) {
+        hipError_t e = hipStreamSynchronize(ctx.stream);          // queued work may still read the old buffers
+        if (e == hipSuccess) e = ctx.xchg_send.reserve(cap_max * BIG_CT * 8);
+        if (e == hipSuccess) e = ctx.xchg_recv.reserve(world * cap_max * BIG_CT * 8);
+        if (e != hipSuccess) return ctx.hip_fail(e, "level exchange buffers");
+    }
+    const size_t n_levels = plan_.levels.size();
+    for (size_t k = 0; k < n_levels; k++) {
+        const size_t w = plan_.levels[k].count, cap = (w + world - 1) / world;
+        const size_t lo = std::min(w, rank * cap), hi = std::min(w, lo + cap);
+        if ((rc = exec_level(k, lo, hi, ctx.xchg_send.as<uint64_t>()))) return rc;
+        if (hi == lo) { stats.levels += 1; }                      // a rank without a slice still takes part
+        if ((rc = ctx.dist.all_gather(ctx.xchg_send.ptr, ctx.xchg_recv.ptr, cap * BIG_CT * 8, ctx.stream, ctx.err)))
+            return rc;
+        if ((rc = commit_level(k, ctx.xchg_recv.as<uint64_t>()))) return rc;
+    }
+    plan_.levels.clear();
+    return 0;
+}
+
+int Engine::gather_blocks(const Bid *local, size_t n, std::vector<Bid> &out) {
+    out.clear();
+    if (!ctx.dist.active()) return ctx.fail(-3, "no distributed transport (fhs_dist_init)");
+    if (n == 0) return 0;
+    const size_t world = (size_t)ctx.dist.world, row = (size_t)BIG_CT * 8;
+    int rc = flush();                                             // the local DAG (or the level-parallel one)
+    if (rc) return rc;
+    if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
+    if (ctx.xchg_send.cap < n * row || ctx.xchg_recv.cap < world * n * row) {
+        hipError_t e = hipStreamSynchronize(ctx.stream);
+        if (e == hipSuccess) e = ctx.xchg_send.reserve(n * row);
+        if (e == hipSuccess) e = ctx.xchg_recv.reserve(world * n * row);
+        if (e != hipSuccess) return ctx.hip_fail(e, "exchange buffers");
+    }
+    for (size_t k = 0; k < n; k++)
+        if ((rc = copy_block_to_device(local[k], ctx.xchg_send.as<uint64_t>() + k * BIG_CT, false))) return rc;
+    if ((rc = ctx.dist.all_gather(ctx.xchg_send.ptr, ctx.xchg_recv.ptr, n * row, ctx.stream, ctx.err))) return rc;
+    out.reserve(world * n);
+    for (size_t i = 0; i < world * n; i++) {
+        Bid b = from_device(ctx.xchg_recv.as<uint64_t>() + i * BIG_CT);
+        if (!b) {
+            for (Bid x : out) release(x);
+            out.clear();
+            return ctx.fail(-2, "import of a gathered block failed");
+        }
+        out.push_back(b);
+    }
+    return 0;
+}
+
 // Builds the plan for every pending level and uploads it; nodes get their output blocks here.
 int Engine::plan_flush() {
     plan_.levels.clear();
+    plan_.recs.clear();
     if (pending_.empty()) return 0;
     if (!ctx.key_loaded) return ctx.fail(-3, "server key not loaded");
     if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
@@ -245,6 +305,17 @@ int Engine::plan_flush() {
             }
             descs.push_back(d);
             lut_idx.push_back(n.lut);
+            {   // noise bookkeeping: sum of squared coefficients of the (flattened) linear combination entering this
+                // bootstrap, i.e. its noise variance in units of one bootstrap output's (uploads counted like outputs)
+                int64_t c2 = 0;
+                if (s.kind == BlockNode::LIN) for (const Term &t : s.terms) c2 += t.coef * t.coef;
+                else c2 = 1;
+                stats.max_input_sum_c2 = std::max<uint64_t>(stats.max_input_sum_c2, (uint64_t)c2);
+                if (capture_max_rows)
+                    plan_.recs.push_back(CaptureRec{(uint32_t)levels.size(), (uint32_t)(descs.size() - 1 - first), n.lut,
+                                                    d.n_terms, c2, s.kind == BlockNode::LIN ? s.konst : 0,
+                                                    (uint32_t)lv.size()});
+            }
             uint64_t *o = alloc_block();
             if (!o) return ctx.fail(-2, "device block pool exhausted (hipMalloc failed)");
             out_ptrs.push_back(o);
@@ -316,6 +387,19 @@ int Engine::exec_level(size_t k, size_t lo, size_t hi, uint64_t *dense_out) {
     uint64_t *const *d_out = reinterpret_cast<uint64_t *const *>(dp + plan_.off_out) + lp.first + lo;
     hipError_t e = launch_lincomb(d_desc, d_terms, batch_in_.as<uint64_t>(), (int)cnt, ctx.stream);
     if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
+    if (capture_max_rows && plan_.recs.size() >= lp.first + hi) {
+        // debug only: a strided sample of this level's PBS inputs goes to the host (synchronous copies)
+        const size_t stride = (cnt + capture_max_rows - 1) / capture_max_rows;
+        for (size_t i = 0; i < cnt; i += stride) {
+            const size_t at = capture_rows.size();
+            capture_rows.resize(at + BIG_CT);
+            e = hipMemcpyAsync(capture_rows.data() + at, batch_in_.as<uint64_t>() + i * BIG_CT, BIG_CT * 8,
+                               hipMemcpyDeviceToHost, ctx.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx.stream);
+            if (e != hipSuccess) return ctx.hip_fail(e, "capture download");
+            capture_recs.push_back(plan_.recs[lp.first + lo + i]);
+        }
+    }
     if (int rc = ctx.keyswitch(batch_in_.as<uint64_t>(), cnt, ctx.stream)) return rc;
     if (int rc = ctx.blind_rotate(ctx.ks_buf.as<uint64_t>(), d_lut, d_luts_, dense_out, dense_out ? nullptr : d_out, cnt,
                                   ctx.stream))

@@ -37,6 +37,7 @@ struct BlockNode {
 
 struct EngineStats {
     uint64_t pbs_executed = 0, pbs_folded = 0, levels = 0, max_level_width = 0;
+    uint64_t max_input_sum_c2 = 0;   // largest sum of squared coefficients of any executed bootstrap's input
 };
 
 class Engine {
@@ -61,6 +62,13 @@ class Engine {
     int triv_val(Bid b) const { return nodes_[b].triv; }
 
     int flush();
+    // Level-parallel execution INSIDE the library (fhs_dist_level_parallel): every rank holds the same ciphertexts and
+    // records the same DAG; flush() then runs slice [rank*cap, (rank+1)*cap) of every level, all-gathers the slices on
+    // the context's stream (ctx.dist: RCCL, no host wait between levels) and installs the gathered level.
+    bool level_parallel = false;
+    // Gathers `n` blocks per rank: local[k] of every rank -> out[r * n + k] (fresh MAT blocks owned by the caller).
+    // Flushes the local DAG first; everything is enqueued on the context's stream.
+    int gather_blocks(const Bid *local, size_t n, std::vector<Bid> &out);
     // distributed execution (one process per GPU, identical DAGs on every rank): plan once, then per
     // level every rank runs its slice into a dense buffer, the caller all-gathers, commit scatters
     int dist_rank = 0, dist_world = 1;
@@ -74,6 +82,14 @@ class Engine {
     int read_block(Bid b, uint64_t *host_out);        // flushes if needed
     int copy_block_to_device(Bid b, uint64_t *d_out, bool wait = true);  // flushes if needed; wait=false: enqueue only
     uint64_t blocks_live() const { return live_dev_blocks_; }
+
+    // ---- debug: capture of PBS inputs (the linear-combination results entering keyswitch) ----
+    // Noise-margin tests download a sample of every level's inputs and measure their phase error with the client
+    // key; nothing here sees a secret.  capture_max_rows == 0: off.
+    struct CaptureRec { uint32_t level, index, lut, n_terms; int64_t sum_c2; int32_t konst; uint32_t width; };
+    size_t capture_max_rows = 0;
+    std::vector<uint64_t> capture_rows;      // [n][2049]
+    std::vector<CaptureRec> capture_recs;
 
     // ---- char handles (fhs_char_t) ----
     struct CharRec { Bid b[4]; bool used; };
@@ -102,11 +118,13 @@ class Engine {
 
     struct FlushPlan {
         std::vector<LevelPlan> levels;
+        std::vector<CaptureRec> recs;        // per planned PBS (only filled while capturing)
         size_t off_desc = 0, off_terms = 0, off_lut = 0, off_out = 0, max_width = 0;
     } plan_;
 
     Bid new_node();
     int materialize_lin(Bid b);
+    int flush_level_parallel();
 };
 
 // RAII reference to a block

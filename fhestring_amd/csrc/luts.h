@@ -22,9 +22,12 @@ enum LutId : uint16_t {
     LUT_BIT0_UNLESS,   // v = digit + 4*mask -> mask ? 0 : digit & 1
     LUT_BIT1_UNLESS,   // v = digit + 4*mask -> mask ? 0 : (digit >> 1) & 1
     LUT_LO_WS0,        // low nibble of NUL or of an ASCII whitespace 0x09..0x0D: v in {0, 9..13}
-    // greedy non-overlapping match selection, v = blocked_countdown + 8 * match_flag (countdown < 8)
+    // greedy non-overlapping match selection, v = 2 * blocked_countdown + match_flag (countdown < 8): the weights
+    // (2, 1) instead of (1, 8) keep the sum of squared coefficients at 5 (noise budget, fhestring_hip.h)
     LUT_GREEDY_SEL,    // 1 iff countdown == 0 and match
-    LUT_GREEDY_DEC,    // countdown > 0 ? countdown - 1 : 0
+    LUT_GREEDY_NEXT0,  // next countdown for a pattern of length k + 1: selected ? k : max(countdown - 1, 0)
+    LUT_GREEDY_NEXT1, LUT_GREEDY_NEXT2, LUT_GREEDY_NEXT3, LUT_GREEDY_NEXT4, LUT_GREEDY_NEXT5, LUT_GREEDY_NEXT6,
+    LUT_GREEDY_NEXT7,
     LUT_COUNT
 };
 
@@ -59,10 +62,11 @@ inline int lut_function(int id, int v) {
         case LUT_BIT0_UNLESS: return (v >> 2) ? 0 : (v & 1);
         case LUT_BIT1_UNLESS: return (v >> 2) ? 0 : ((v >> 1) & 1);
         case LUT_LO_WS0: return v == 0 || (v >= 9 && v <= 13);
-        case LUT_GREEDY_SEL: return v == 8;
-        case LUT_GREEDY_DEC: return (v & 7) ? (v & 7) - 1 : 0;
+        case LUT_GREEDY_SEL: return v == 1;
         default: break;
     }
+    if (id >= LUT_GREEDY_NEXT0 && id <= LUT_GREEDY_NEXT7)
+        return v == 1 ? id - LUT_GREEDY_NEXT0 : ((v >> 1) ? (v >> 1) - 1 : 0);
     if (id >= LUT_EQ_C0 && id <= LUT_EQ_C3) return v == id - LUT_EQ_C0;
     if (id >= LUT_NE_C0 && id <= LUT_NE_C3) return v != id - LUT_NE_C0;
     if (id >= LUT_IS1 && id <= LUT_IS3) return v == 1 + (id - LUT_IS1);

@@ -680,6 +680,50 @@ FChar Strings::f_find(const FStr &s, const FStr &pat) {
     return position_of(first, 0, &nf, 255);                  // 255 = 3,3,3,3 when absent (:1023)
 }
 
+// Window-sharded find: the same DAG as f_find on one rank's slice, with the global window index baked into the
+// position digits (free: they are plaintext weights) and the found flag kept apart instead of the 255 sentinel.
+void Strings::f_find_partial(const FStr &s, const FStr &pat, size_t first_window, Ref *found, FChar *pos) {
+    if (s.size() < pat.size() || s.empty()) {
+        *found = trivial_block(e_, 0);
+        *pos = t(0);
+        return;
+    }
+    const size_t W = s.size() - pat.size() + 1;
+    std::vector<Ref> f(W);
+    for (size_t i = 0; i < W; i++) f[i] = pat.empty() ? trivial_block(e_, 1) : window_match(s, i, pat);
+    std::vector<Ref> p = prefix_or(f);
+    std::vector<Ref> first(W);
+    for (size_t i = 0; i < W; i++) first[i] = pbs(lin(e_, {{2, &f[i]}, {1, &p[i]}}), LUT_IS2);
+    *found = or_tree(f);
+    *pos = position_of(first, first_window, nullptr, 0);
+}
+
+// The first slice (string order) that found a match decides (mod.rs:1010-1053: the FIRST match index, 255 if none).
+FChar Strings::find_first_decides(const std::vector<Ref> &found, const std::vector<FChar> &pos) {
+    const size_t n = std::min(found.size(), pos.size());
+    Ref three = trivial_block(e_, 3);
+    FChar r;
+    if (n == 0) return t(255);
+    std::vector<Ref> before = prefix_or(found);              // exclusive: an earlier slice found one
+    std::vector<Ref> sel(n);
+    for (size_t k = 0; k < n; k++) sel[k] = pbs(lin(e_, {{2, &found[k]}, {1, &before[k]}}), LUT_IS2);
+    Ref any = or_tree(found);
+    for (int blk = 0; blk < 4; blk++) {
+        std::vector<Ref> picked(n);
+        for (size_t k = 0; k < n; k++) picked[k] = pbs(lin(e_, {{4, &sel[k]}, {1, &pos[k].b[blk]}}), LUT_SEL_T);
+        Ref sum = n <= 15 ? sum_refs(e_, picked.data(), n) : Ref();
+        if (n > 15) {                                        // more than 15 slices: refreshed partial sums (one-hot)
+            std::vector<Ref> part;
+            for (size_t g = 0; g < n; g += 15)
+                part.push_back(pbs(sum_refs(e_, &picked[g], std::min<size_t>(15, n - g)), LUT_MSG));
+            sum = sum_refs(e_, part.data(), part.size());
+        }
+        // + 3 * (1 - any): every digit of 255 when no slice found the pattern
+        r.b[blk] = pbs(lin(e_, {{1, &sum}, {1, &three}, {-3, &any}}), LUT_MSG);
+    }
+    return r;
+}
+
 // comparison (mod.rs:1470-1541) re-associated.  The reference's 4-op state machine per character
 // (:1504-1513) selects the comparison result at the FIRST differing position; there `le` equals `lt`
 // and `ge` equals `gt`, so: pick_i = X_i & !prefix_or(differs)_i with X = lt (lt, le) or gt (gt, ge),
@@ -785,36 +829,53 @@ Ref Strings::char_significant(const FChar &c) {
 }
 
 // u8 position encoded by one-hot flags: sum_i pick_i * (i + offset) digit-wise (at most one pick is set);
-// when `absent_flag` is set the result is `absent_value` (255 for find/rfind, mod.rs:1023)
+// when `absent_flag` is set the result is `absent_value` (255 for find/rfind, mod.rs:1023).
+// Noise: a sum of k bootstrap outputs with weights c carries sum c^2 output variances into the next bootstrap, so
+// the weighted picks are grouped by WEIGHT (sum of digit^2 <= FHS_NOISE_BUDGET_SUM_C2, not by count), every group is
+// refreshed with LUT_MSG before groups are added up, and the digits handed back to the caller are refreshed too:
+// like every op of the reference (fheasciichar.rs:35-104) the result is a fresh, clean-carry ciphertext.
 FChar Strings::position_of(const std::vector<Ref> &pick, size_t off, const Ref *absent_flag, int absent_value) {
     const size_t W = pick.size();
     FChar r;
     for (int blk = 0; blk < 4; blk++) {
         std::vector<Ref> cur;
-        for (size_t g = 0; g < W; g += 15) {
-            Term tt[16];
+        {
+            Term tt[64];
             size_t m = 0;
-            for (size_t i = g; i < std::min(W, g + 15); i++) {
+            int64_t c2 = 0;
+            // a lone group also takes the `absent` term (weight <= 3) before its refresh
+            const int64_t limit = FHS_NOISE_BUDGET_SUM_C2 - (absent_flag ? 9 : 0);
+            auto close = [&] {
+                if (m) cur.push_back(Ref(e_, e_->lin(tt, m, 0)));
+                m = 0;
+                c2 = 0;
+            };
+            for (size_t i = 0; i < W; i++) {
                 const int dig = (int)(((i + off) >> (2 * blk)) & 3);
-                if (dig) tt[m++] = {dig, pick[i].id()};
+                if (!dig || e_->is_triv(pick[i].id())) {
+                    if (dig && e_->triv_val(pick[i].id())) { tt[m++] = {dig, pick[i].id()}; }   // folds into the constant
+                    if (m == 64) close();
+                    continue;
+                }
+                if (c2 + dig * dig > limit || m == 64) close();
+                tt[m++] = {dig, pick[i].id()};
+                c2 += dig * dig;
             }
-            cur.push_back(Ref(e_, e_->lin(tt, m, 0)));
+            close();
         }
-        while (cur.size() > 15) {
+        // tree of refreshed partial sums: <= 15 fresh digits (one-hot: the value stays <= 3) per node
+        while (cur.size() > 1) {
             std::vector<Ref> nxt;
             for (size_t g = 0; g < cur.size(); g += 15) {
                 std::vector<Ref> fresh;
                 for (size_t i = g; i < std::min(cur.size(), g + 15); i++) fresh.push_back(pbs(cur[i], LUT_MSG));
-                nxt.push_back(sum_refs(e_, fresh.data(), fresh.size()));
+                nxt.push_back(fresh.size() == 1 ? fresh[0] : sum_refs(e_, fresh.data(), fresh.size()));
             }
             cur.swap(nxt);
         }
-        std::vector<Ref> fresh;
-        for (Ref &c : cur) fresh.push_back(cur.size() > 1 ? pbs(c, LUT_MSG) : c);
-        Ref digit = fresh.empty() ? trivial_block(e_, 0)
-                                  : (fresh.size() == 1 ? fresh[0] : sum_refs(e_, fresh.data(), fresh.size()));
-        if (absent_flag) r.b[blk] = lin(e_, {{1, &digit}, {(absent_value >> (2 * blk)) & 3, absent_flag}});
-        else r.b[blk] = digit;
+        Ref digit = cur.empty() ? trivial_block(e_, 0) : cur[0];
+        if (absent_flag) digit = lin(e_, {{1, &digit}, {(absent_value >> (2 * blk)) & 3, absent_flag}});
+        r.b[blk] = pbs(digit, LUT_MSG);                      // folds when everything was trivial
     }
     return r;
 }
@@ -880,10 +941,9 @@ FStr Strings::f_replace_expand(const FStr &s_in, const FStr &from, const FStr &t
     Ref state = trivial_block(e_, 0);                        // positions still blocked by the last match
     for (size_t i = 0; i < n; i++) {
         Ref f = i + m <= n ? window_match(s, i, from) : trivial_block(e_, 0);
-        Ref v = lin(e_, {{1, &state}, {8, &f}});
+        Ref v = lin(e_, {{2, &state}, {1, &f}});
         sel[i] = pbs(v, LUT_GREEDY_SEL);
-        Ref dec = pbs(v, LUT_GREEDY_DEC);
-        state = m > 1 ? lin(e_, {{1, &dec}, {(int64_t)(m - 1), &sel[i]}}) : dec;   // sel => countdown was 0
+        state = pbs(v, LUT_GREEDY_NEXT0 + (int)(m - 1));     // selected ? m - 1 : max(countdown - 1, 0)
     }
     for (size_t i = 0; i < n; i++) {
         Term tt[8];

@@ -35,6 +35,11 @@ class Strings {
     void f_cmp_partial(const FStr &a, const FStr &b, int cmp, FChar *any_diff_out, FChar *verdict_out);
     // combine such partials over consecutive ranges: the first range that differs decides, `tie` if none does
     FChar flags_first_decides(const FStr &any_diff, const FStr &verdict, int tie);
+    // window-sharded find (multi-GPU): local partial on a slice whose first window has global index `first_window`:
+    // *found = some local window matches, *pos = global index of the first local match (0 when none)
+    void f_find_partial(const FStr &s, const FStr &pat, size_t first_window, Ref *found, FChar *pos);
+    // combine such partials over consecutive slices (string order): position of the first slice that found one, 255 if none
+    FChar find_first_decides(const std::vector<Ref> &found, const std::vector<FChar> &pos);
     FStr to_upper(const FStr &s);
     FStr to_lower(const FStr &s);
     FStr replace(const FStr &s, const FStr &from, const FStr &to);

@@ -1,209 +1,210 @@
-"""Multi-GPU sharding of one string operation (one process per GPU, RCCL via torch.distributed).
+"""Multi-GPU string operations: thin Python glue over the library's own distributed layer (include/fhestring_hip.h
+"multi-GPU inside the library": fhs_dist_*).  One process per GPU; the RCCL communicator, the all-gathers (enqueued on
+the context's HIP stream) and the partial / combine DAGs all live in C++ (csrc/dist.cpp, capi_dist.cpp, strings.cpp);
+this module only hands the 128-byte communicator id around (torch.distributed, any backend) and mirrors the entry points.
 
-contains(): the match windows of a string are independent (src/server_key/mod.rs:170-177), so
-they are split into `world` contiguous ranges; a rank only ever holds the characters its windows
-touch (its slice plus an (m-1)-character halo).  The only exchange is one all-gather of one
-FheAsciiChar (the partial flag, 65 568 B) per rank, followed by one OR level that every rank
-evaluates redundantly (so every rank ends with the result, like the reference's return value).
+* window sharding: contains / find (src/server_key/mod.rs:170-177, :1010-1053) -- a rank holds its slice plus an
+  (m-1)-character halo;
+* position sharding: eq / eq_ignore_case / lt / le / gt / ge of two equally long padded buffers (:1122-1149, :1470-1541);
+* level-parallel mode for everything else (replace with its compaction, ...): identical DAGs, every PBS level split.
 """
+import ctypes as C
+
 import numpy as np
 
+from ._lib import lib
+
 CHAR_WORDS = 4 * 2049
+ID_BYTES = 128
 
 
 def plan_windows(n_chars, m, world):
-    """Split windows 0..n_chars-m over `world` ranks.
-
-    Returns a list of (w0, w1, c0, c1): rank r evaluates windows [w0, w1) and needs characters
-    [c0, c1).  Ranks beyond the number of windows get an empty range.  n_chars includes padding.
-    """
-    n_win = max(0, n_chars - m + 1) if m <= n_chars else 0
-    base, extra = divmod(n_win, world)
-    out, w = [], 0
+    """[(w0, w1, c0, c1)] per rank (fhs_dist_plan_windows): rank r evaluates windows [w0, w1) and holds chars [c0, c1)."""
+    L = lib()
+    out = []
     for r in range(world):
-        cnt = base + (1 if r < extra else 0)
-        w0, w1 = w, w + cnt
-        c0, c1 = (w0, w1 + m - 1) if cnt else (0, 0)
-        out.append((w0, w1, c0, min(c1, n_chars)))
-        w = w1
+        v = [C.c_size_t() for _ in range(4)]
+        L.fhs_dist_plan_windows(n_chars, m, world, r, *[C.byref(x) for x in v])
+        out.append(tuple(int(x.value) for x in v))
     return out
 
 
-class _FlagExchange:
-    """Gathers one partial FheAsciiChar flag per item from every rank: parts[item][rank]."""
+def plan_positions(n_chars, world):
+    """[(c0, c1)] per rank (fhs_dist_plan_positions)."""
+    L = lib()
+    out = []
+    for r in range(world):
+        a, b = C.c_size_t(), C.c_size_t()
+        L.fhs_dist_plan_positions(n_chars, world, r, C.byref(a), C.byref(b))
+        out.append((int(a.value), int(b.value)))
+    return out
 
-    def _stream_ordered(self):
-        import os
-        t = self.torch
-        return (t.cuda.is_available() and self.sk.device_resident and self.dist.get_backend() == "nccl"
-                and not os.environ.get("FHS_SYNC_EXCHANGE"))
 
-    def _gather(self, local):
-        sk, torch, n = self.sk, self.torch, len(local)
-        if self._stream_ordered():
-            # one all-gather of n chars per rank on the context's own HIP stream: no host synchronisation anywhere,
-            # so consecutive batches on different contexts keep overlapping
-            if getattr(self, "_ext", None) is None:
-                self._ext = torch.cuda.ExternalStream(sk.stream_handle())
-            with torch.cuda.stream(self._ext):
-                mine = torch.empty(n * CHAR_WORDS, dtype=torch.int64, device="cuda")
-                allp = torch.empty(self.world * n * CHAR_WORDS, dtype=torch.int64, device="cuda")
-                for k, l in enumerate(local):
-                    sk.export_device_async(l, mine.data_ptr() + 8 * CHAR_WORDS * k)   # first call flushes the DAG
-                self.dist.all_gather_into_tensor(allp, mine)    # RCCL over xGMI: world x n x 65 568 B
-            self._keep = (mine, allp)       # device buffers stay referenced until the next exchange replaces them
+def unique_id():
+    buf = C.create_string_buffer(ID_BYTES)
+    rc = lib().fhs_dist_unique_id(buf)
+    if rc != 0:
+        raise RuntimeError("fhs_dist_unique_id failed (%d): is librccl.so.1 loadable?" % rc)
+    return buf.raw
+
+
+class Dist:
+    """The distributed side of one MyServerKey (one context = one communicator = one HIP stream)."""
+
+    def __init__(self, sk, rank, world):
+        self.sk, self.rank, self.world = sk, rank, world
+        self._cb = None
+
+    # ---- set-up ---------------------------------------------------------------------------------------
+    @classmethod
+    def from_torch(cls, sk, dist, torch, rank=None, world=None):
+        """Communicator id from rank 0 through torch.distributed (any backend).  backend nccl -> the library's own RCCL
+        communicator (one rank per GPU, xGMI); any other backend -> host transport through that backend (ranks sharing
+        one GPU in tests: RCCL refuses two ranks on one device)."""
+        rank = dist.get_rank() if rank is None else rank
+        world = dist.get_world_size() if world is None else world
+        self = cls(sk, rank, world)
+        if world == 1 and dist is None:
+            return self
+        if dist.get_backend() == "nccl":
+            box = [unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            sk.ctx._check(sk.ctx._L.fhs_dist_init(sk.ctx._h, rank, world, box[0]))
         else:
-            # host-synchronised path: CPU stand-in, several ranks sharing one GPU through gloo (tests), fallback
-            dev = "cuda" if torch.cuda.is_available() and sk.device_resident else "cpu"
-            mine = torch.empty(n * CHAR_WORDS, dtype=torch.int64, device=dev)
-            for k, l in enumerate(local):
-                sk.export_device(l, mine.data_ptr() + 8 * CHAR_WORDS * k)             # flushes this rank's DAG
-            allp = torch.empty(self.world * n * CHAR_WORDS, dtype=torch.int64, device=dev)
-            if dev == "cuda" and self.dist.get_backend() != "nccl":
-                parts_cpu = [torch.empty(n * CHAR_WORDS, dtype=torch.int64) for _ in range(self.world)]
-                self.dist.all_gather(parts_cpu, mine.cpu())
-                allp.copy_(torch.cat(parts_cpu))
-            else:
-                self.dist.all_gather_into_tensor(allp, mine)
-            if dev == "cuda":
-                torch.cuda.synchronize()
-            self._keep = (mine, allp)
-        return [[sk.import_device(allp.data_ptr() + 8 * CHAR_WORDS * (r * n + k)) for r in range(self.world)]
-                for k in range(n)]
+            self.init_host_transport(lambda send: _gloo_all_gather(dist, torch, send, world))
+        return self
 
+    def init_single(self):
+        """world = 1 with a real RCCL communicator (exercises the stream-ordered path on one GPU)."""
+        self.sk.ctx._check(self.sk.ctx._L.fhs_dist_init(self.sk.ctx._h, 0, 1, unique_id()))
+        return self
 
-class ShardedContains(_FlagExchange):
-    def __init__(self, sk, rank, world, dist, torch):
-        self.sk, self.rank, self.world, self.dist, self.torch = sk, rank, world, dist, torch
+    def init_host_transport(self, all_gather_bytes):
+        """all_gather_bytes(send: bytes-like of k bytes) -> bytes-like of world * k bytes, rank-major."""
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
-    def upload_shard(self, ck, full_string, chars_per_rank, m, padding=1):
-        """Encrypt and upload only this rank's slice (+halo) of `full_string` + padding NULs."""
+        def cb(_user, send, recv, nbytes):
+            try:
+                data = all_gather_bytes(C.string_at(send, nbytes))
+                C.memmove(recv, bytes(data), nbytes * self.world)
+                return 0
+            except Exception:                   # never unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = CB(cb)                       # keep the trampoline alive as long as the context uses it
+        self.sk.ctx._check(self.sk.ctx._L.fhs_dist_init_host_transport(self.sk.ctx._h, self.rank, self.world,
+                                                                       self._cb, None))
+        return self
+
+    def shutdown(self):
+        self.sk.ctx._check(self.sk.ctx._L.fhs_dist_shutdown(self.sk.ctx._h))
+
+    def level_parallel(self, on=True):
+        self.sk.ctx._check(self.sk.ctx._L.fhs_dist_level_parallel(self.sk.ctx._h, int(bool(on))))
+
+    # ---- slices ---------------------------------------------------------------------------------------
+    def window_shard(self, ck, full_string, m, padding=1):
+        """Encrypt and upload only this rank's slice (+ halo) of `full_string` + padding NULs.
+        -> (FheString shard, global index of its first window, total chars incl. padding)"""
         n_chars = len(full_string) + padding
         w0, w1, c0, c1 = plan_windows(n_chars, m, self.world)[self.rank]
         text = full_string[c0:min(c1, len(full_string))]
         pad_here = max(0, c1 - max(c0, len(full_string)))
-        return ck.encrypt(text, pad_here, None, self.sk)
+        return ck.encrypt(text, pad_here, None, self.sk), w0, n_chars
 
-    def _local(self, shard, clear_pattern):
-        if len(shard) >= len(clear_pattern):
-            return self.sk.contains_clear(shard, clear_pattern)
-        return self.sk.trivial(0)          # this rank owns no window
-
-    def run(self, shard, clear_pattern, op="contains"):
-        return self.run_batch([shard], clear_pattern, op=op)[0]
-
-    def run_batch(self, shards, clear_pattern, op="contains", force_exchange=False):
-        """contains() on several independent strings with ONE exchange: the local flags of all strings are
-        evaluated in one DAG flush, gathered with one all-gather of len(shards) chars per rank and OR-ed in one
-        level (every rank evaluates it, so every rank ends with the result, like the reference's return value)."""
-        sk = self.sk
-        if op == "find":
-            if self.world != 1:
-                raise NotImplementedError("find has no window-sharded form: use LevelParallel")
-            return [sk.find_clear(sh, clear_pattern) for sh in shards]
-        local = [self._local(sh, clear_pattern) for sh in shards]
-        if self.world == 1 and not force_exchange:          # force_exchange: 1-rank RCCL test
-            return local
-        return [sk.flags_or(parts) for parts in self._gather(local)]
-
-
-class ShardedEq(_FlagExchange):
-    """eq / eq_ignore_case of two padded strings of the SAME buffer length (BASELINE config 5): the character
-    positions are split into `world` contiguous ranges and a rank holds only its slice of both strings.  On
-    well-formed padded strings (NULs only at the end) the reference's semantics (src/server_key/mod.rs:1122-1149:
-    every position equal or both NUL, and equal lengths) is the conjunction of the same predicate over the slices,
-    so each rank evaluates the op on its slices and the partial flags are AND-ed after one all-gather of one
-    FheAsciiChar per rank."""
-
-    def __init__(self, sk, rank, world, dist, torch):
-        self.sk, self.rank, self.world, self.dist, self.torch = sk, rank, world, dist, torch
-
-    @staticmethod
-    def plan(n_chars, world):
-        base, extra = divmod(n_chars, world)
-        out, c = [], 0
-        for r in range(world):
-            cnt = base + (1 if r < extra else 0)
-            out.append((c, c + cnt))
-            c += cnt
-        return out
-
-    def upload_shard(self, ck, full_string, n_chars):
+    def position_shard(self, ck, full_string, n_chars):
         """This rank's slice of `full_string` padded with NULs to n_chars positions."""
-        c0, c1 = self.plan(n_chars, self.world)[self.rank]
+        c0, c1 = plan_positions(n_chars, self.world)[self.rank]
         text = full_string[c0:min(c1, len(full_string))]
         return ck.encrypt(text, (c1 - c0) - len(text), None, self.sk)
 
-    def run(self, a_shard, b_shard, op="eq", force_exchange=False):
-        sk = self.sk
-        fn = {"eq": sk.eq, "eq_ignore_case": sk.eq_ignore_case}[op]
-        local = fn(a_shard, b_shard) if len(a_shard) else sk.trivial(1)
-        if self.world == 1 and not force_exchange:
-            return local
-        return sk.flags_and(self._gather([local])[0])
+    # ---- sharded entry points (C) -------------------------------------------------------------------------
+    def _h(self, chars):
+        from .api import _harr
+        chars = self.sk._chars(chars)
+        return _harr(chars), len(chars), chars
 
+    def _char(self, h):
+        from .api import FheAsciiChar
+        return FheAsciiChar(self.sk, h)
 
-class ShardedCmp(ShardedEq):
-    """lt / le / gt / ge of two padded strings of the SAME buffer length with the character positions split over
-    the ranks (BASELINE config 5, `<=`).  Each rank reduces its slices to (some position differs, verdict at the
-    first differing position) -- the positional half of src/server_key/mod.rs:1497-1518 -- the two flags of every
-    rank are gathered with one all-gather, and the first range that differs decides; when nothing differs the
-    buffers, hence the strings, are equal (le / ge -> 1, lt / gt -> 0).  NUL padding compares below every
-    character, which is exactly the reference's length tie-break."""
+    def allgather_flags(self, flags):
+        """n flag chars per rank -> [[rank 0's n], [rank 1's n], ...] on every rank; ONE all-gather."""
+        arr, n, keep = self._h(flags)
+        out = (C.c_uint64 * (self.world * max(1, n)))()
+        self.sk.ctx._check(self.sk.ctx._L.fhs_dist_allgather_flags(self.sk.ctx._h, arr, n, out))
+        return [[self._char(out[r * n + i]) for i in range(n)] for r in range(self.world)]
 
-    def run(self, a_shard, b_shard, op="le", force_exchange=False):
-        sk = self.sk
+    def allgather_chars(self, chars):
+        arr, n, keep = self._h(chars)
+        out = (C.c_uint64 * (self.world * max(1, n)))()
+        self.sk.ctx._check(self.sk.ctx._L.fhs_dist_allgather_chars(self.sk.ctx._h, arr, n, out))
+        return [[self._char(out[r * n + i]) for i in range(n)] for r in range(self.world)]
+
+    def contains(self, shard, pattern):
+        out = C.c_uint64()
+        sa, sn, k1 = self._h(shard)
+        L, h = self.sk.ctx._L, self.sk.ctx._h
+        if isinstance(pattern, str):
+            p = pattern.encode()
+            self.sk.ctx._check(L.fhs_dist_str_contains_clear(h, sa, sn, p, len(p), C.byref(out)))
+        else:
+            pa, pn, k2 = self._h(pattern)
+            self.sk.ctx._check(L.fhs_dist_str_contains(h, sa, sn, pa, pn, C.byref(out)))
+        return self._char(out.value)
+
+    def find(self, shard, pattern, first_window, total_chars):
+        out = C.c_uint64()
+        sa, sn, k1 = self._h(shard)
+        L, h = self.sk.ctx._L, self.sk.ctx._h
+        if isinstance(pattern, str):
+            p = pattern.encode()
+            rc = L.fhs_dist_str_find_clear(h, sa, sn, p, len(p), first_window, total_chars, C.byref(out))
+        else:
+            pa, pn, k2 = self._h(pattern)
+            rc = L.fhs_dist_str_find(h, sa, sn, pa, pn, first_window, total_chars, C.byref(out))
+        if rc == -4:
+            raise OverflowError(L.fhs_last_error(h).decode())
+        self.sk.ctx._check(rc)
+        return self._char(out.value)
+
+    def eq(self, a_shard, b_shard, ignore_case=False):
+        out = C.c_uint64()
+        aa, an, k1 = self._h(a_shard)
+        ba, bn, k2 = self._h(b_shard)
+        self.sk.ctx._check(self.sk.ctx._L.fhs_dist_str_eq(self.sk.ctx._h, aa, an, ba, bn, int(ignore_case), C.byref(out)))
+        return self._char(out.value)
+
+    def eq_ignore_case(self, a_shard, b_shard):
+        return self.eq(a_shard, b_shard, True)
+
+    def compare(self, a_shard, b_shard, op):
+        out = C.c_uint64()
+        aa, an, k1 = self._h(a_shard)
+        ba, bn, k2 = self._h(b_shard)
         cmp = {"lt": 0, "le": 1, "gt": 2, "ge": 3}[op]
-        if len(a_shard):
-            d, v = sk.compare_partial(a_shard, b_shard, cmp)
-        else:
-            d, v = sk.trivial(0), sk.trivial(0)
-        if self.world == 1 and not force_exchange:
-            ds, vs = [d], [v]
-        else:
-            ds, vs = self._gather([d, v])
-        return sk.flags_first_decides(ds, vs, 1 if op in ("le", "ge") else 0)
+        self.sk.ctx._check(self.sk.ctx._L.fhs_dist_str_compare(self.sk.ctx._h, aa, an, ba, bn, cmp, C.byref(out)))
+        return self._char(out.value)
+
+    def contains_batch(self, shards, clear_pattern):
+        """contains_clear on several independent strings with ONE exchange: the local flags of all strings are
+        evaluated in one DAG flush, gathered with one all-gather of len(shards) blocks per rank and OR-ed in one
+        level that every rank evaluates."""
+        sk = self.sk
+        local = [sk.contains_clear(sh, clear_pattern) if len(sh) >= len(clear_pattern) else sk.trivial(0)
+                 for sh in shards]
+        if self.world == 1 and not self._force:
+            return local
+        parts = self.allgather_flags(local)
+        return [sk.flags_or([parts[r][i] for r in range(self.world)]) for i in range(len(local))]
+
+    _force = False
 
 
-class LevelParallel:
-    """Generic multi-GPU execution of ANY op: the ranks hold the same ciphertexts, record the same DAG
-    and split every PBS level; one all-gather of the level's outputs (width x 16 392 B) per level.
-    Works for replace / compare / find / ... without op-specific partial results (the window sharding
-    above moves less data and is what bench.py uses for contains)."""
-
-    def __init__(self, sk, rank, world, dist, torch):
-        self.sk, self.rank, self.world, self.dist, self.torch = sk, rank, world, dist, torch
-        self._send = self._recv = None
-
-    def _buffers(self, cap):
-        torch = self.torch
-        words = cap * 2049
-        if self._send is None or self._send.numel() < words:
-            self._send = torch.empty(words, dtype=torch.int64, device="cuda")
-            self._recv = torch.empty(self.world * words, dtype=torch.int64, device="cuda")
-        return self._send[:words], self._recv[:self.world * words]
-
-    def flush(self):
-        import ctypes as C
-        L, h, torch = self.sk.ctx._L, self.sk.ctx._h, self.torch
-        n_levels, max_w = C.c_uint64(), C.c_uint64()
-        self.sk.ctx._check(L.fhs_flush_plan(h, C.byref(n_levels), C.byref(max_w)))
-        if n_levels.value == 0:
-            return
-        cap_max = (max_w.value + self.world - 1) // self.world
-        self._buffers(cap_max)
-        for k in range(n_levels.value):
-            width, cap = C.c_uint64(), C.c_uint64()
-            self.sk.ctx._check(L.fhs_flush_level_exec(h, k, C.c_void_p(self._send.data_ptr()), C.byref(width),
-                                                      C.byref(cap)))
-            self.sk.ctx._check(L.fhs_stream_sync(h))
-            send, recv = self._buffers(cap.value)
-            if self.dist.get_backend() != "nccl":             # tests: ranks sharing one GPU, CPU group
-                parts = [torch.empty(send.numel(), dtype=torch.int64) for _ in range(self.world)]
-                self.dist.all_gather(parts, send.cpu())
-                recv.copy_(torch.cat(parts))
-            else:
-                self.dist.all_gather_into_tensor(recv, send)   # RCCL over xGMI
-            torch.cuda.synchronize()
-            self.sk.ctx._check(L.fhs_flush_level_commit(h, k, C.c_void_p(recv.data_ptr())))
-        self.sk.ctx._check(L.fhs_stream_sync(h))
+def _gloo_all_gather(dist, torch, send, world):
+    t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return b"".join(p.numpy().tobytes() for p in parts)

@@ -191,7 +191,50 @@ int fhs_flags_and(fhs_ctx *c, const fhs_char_t *flags, size_t n, fhs_char_t *out
 int fhs_flags_first_decides(fhs_ctx *c, const fhs_char_t *any_diff, const fhs_char_t *verdict, size_t n, int tie,
                             fhs_char_t *out);
 
-/* ---- level-parallel multi-GPU execution (one process per GPU; SURVEY 5 "per-level" pattern) --------
+/* ---- multi-GPU inside the library (one process per GPU, RCCL over xGMI) ---------------------------------
+ * north_star: "characters of an FheString are independent PBS batches, so long strings shard across the GPUs of one
+ * node with an RCCL gather".  fhs_dist_init creates this context's communicator (librccl.so.1 is loaded at run time;
+ * rank 0 obtains the 128-byte id with fhs_dist_unique_id and hands it to the other ranks by any means).  All
+ * collectives are ncclAllGather calls enqueued on the context's own HIP stream: nothing waits on the host. */
+#define FHS_DIST_ID_BYTES 128
+int fhs_dist_unique_id(void *id /*[128]*/);
+int fhs_dist_init(fhs_ctx *ctx, int rank, int world, const void *nccl_unique_id /*[128]*/);
+/* Transport for ranks that SHARE one GPU (RCCL refuses two ranks on one device; tests on a one-GPU box): the library
+ * stages through pinned host memory and calls `fn(user, send, recv, bytes_per_rank)` (0 = ok), e.g. a gloo all-gather. */
+typedef int (*fhs_allgather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
+int fhs_dist_init_host_transport(fhs_ctx *ctx, int rank, int world, fhs_allgather_fn fn, void *user);
+int fhs_dist_shutdown(fhs_ctx *ctx);
+int fhs_dist_rank(const fhs_ctx *ctx);
+int fhs_dist_world(const fhs_ctx *ctx);
+/* Partition helpers (pure host logic).  Windows 0..n_chars-m of contains/find split into `world` contiguous ranges:
+ * rank evaluates windows [*w0, *w1) and holds characters [*c0, *c1) (its slice plus an (m-1)-character halo).
+ * Positions 0..n_chars split into `world` contiguous ranges [*c0, *c1) (eq / eq_ignore_case / comparisons). */
+void fhs_dist_plan_windows(size_t n_chars, size_t m, int world, int rank, size_t *w0, size_t *w1, size_t *c0, size_t *c1);
+void fhs_dist_plan_positions(size_t n_chars, int world, int rank, size_t *c0, size_t *c1);
+/* Generic exchange: n chars (resp. n single-block flags) of every rank -> out[r * n + i] on every rank. */
+int fhs_dist_allgather_chars(fhs_ctx *ctx, const fhs_char_t *local, size_t n, fhs_char_t *out /*[world * n]*/);
+int fhs_dist_allgather_flags(fhs_ctx *ctx, const fhs_char_t *local, size_t n, fhs_char_t *out /*[world * n]*/);
+/* Sharded string methods: `shard` is THIS rank's slice (fhs_dist_plan_*), patterns are replicated; every rank returns
+ * the full result.  contains: mod.rs:151-182 (1 block exchanged per rank).  find: mod.rs:1010-1053, partial =
+ * (found, position) with the global index of the slice's first window baked in, first slice that finds decides
+ * (5 blocks per rank); FHS_ERR_LIMIT when total_chars >= 255 + m like the reference's panic.  eq / eq_ignore_case:
+ * mod.rs:1122-1149, :1221-1231 on equally long padded buffers (1 block).  compare: mod.rs:1470-1541, cmp 0 lt, 1 le,
+ * 2 gt, 3 ge (2 blocks). */
+int fhs_dist_str_contains(fhs_ctx *c, const fhs_char_t *shard, size_t n, const fhs_char_t *pat, size_t m, fhs_char_t *out);
+int fhs_dist_str_contains_clear(fhs_ctx *c, const fhs_char_t *shard, size_t n, const char *pat, size_t m, fhs_char_t *out);
+int fhs_dist_str_find(fhs_ctx *c, const fhs_char_t *shard, size_t n, const fhs_char_t *pat, size_t m, size_t first_window,
+                      size_t total_chars, fhs_char_t *out);
+int fhs_dist_str_find_clear(fhs_ctx *c, const fhs_char_t *shard, size_t n, const char *pat, size_t m, size_t first_window,
+                            size_t total_chars, fhs_char_t *out);
+int fhs_dist_str_eq(fhs_ctx *c, const fhs_char_t *a, size_t na, const fhs_char_t *b, size_t nb, int ignore_case,
+                    fhs_char_t *out);
+int fhs_dist_str_compare(fhs_ctx *c, const fhs_char_t *a, size_t na, const fhs_char_t *b, size_t nb, int cmp, fhs_char_t *out);
+/* Level-parallel mode for ANY op (replace with its compaction, ...): every rank holds the same ciphertexts and records
+ * the same DAG; while on, fhs_flush / fhs_flush_async run slice [rank*cap, (rank+1)*cap) of every dependency level,
+ * all-gather the level (cap x 16 392 B per rank) on the stream and install it -- all levels enqueued back to back. */
+int fhs_dist_level_parallel(fhs_ctx *ctx, int on);
+
+/* ---- level-parallel execution with a caller-provided collective (low-level protocol; SURVEY 5 "per-level") ----
  * Every rank holds the same ciphertexts and records the same DAG.  fhs_flush_plan levelises it;
  * for each level k every rank runs its slice [rank*cap, (rank+1)*cap) of the level's PBS
  * (cap = ceil(width / world)) into rows of `d_slice` (device, cap x 2049 u64), the caller all-gathers
@@ -203,6 +246,23 @@ int fhs_flush_level_exec(fhs_ctx *ctx, uint64_t level, uint64_t *d_slice, uint64
 int fhs_flush_level_commit(fhs_ctx *ctx, uint64_t level, const uint64_t *d_all);
 int fhs_stream_sync(fhs_ctx *ctx);
 
+/* ---- debug: capture of PBS inputs (noise-margin measurement; tests/test_gpu_noise.py) -------------
+ * While enabled, every executed level copies a strided sample (at most max_rows_per_level rows) of its PBS inputs --
+ * the linear-combination results that enter keyswitch -- to host memory, with the record below.  The caller
+ * decrypts their phase with the client key; the library never sees a secret.  0 disables and clears. */
+typedef struct {
+    uint32_t level, index;     /* dependency level within its flush, position within the level */
+    uint32_t lut;              /* LUT catalogue id of the PBS (csrc/luts.h) */
+    uint32_t n_terms;          /* ciphertext terms of the linear combination */
+    int64_t sum_c2;            /* sum of squared coefficients (noise amplification of the construct) */
+    int32_t konst;             /* trivial constant added (mod 32) */
+    uint32_t width;            /* PBS in this level */
+} fhs_capture_rec;
+int fhs_debug_capture_pbs_inputs(fhs_ctx *ctx, size_t max_rows_per_level);
+/* Copies up to `cap` captured rows ([2049] u64 each) and records, returns the number in *n and clears the capture;
+ * rows == NULL only reports the count (nothing is cleared). */
+int fhs_debug_capture_read(fhs_ctx *ctx, uint64_t *rows, fhs_capture_rec *recs, size_t cap, size_t *n);
+
 /* ---- statistics ---------------------------------------------------------------- */
 typedef struct {
     uint64_t pbs_executed;     /* PBS actually run on the GPU (constant-folded ones excluded) */
@@ -210,7 +270,14 @@ typedef struct {
     uint64_t levels;           /* dependency levels launched */
     uint64_t max_level_width;
     uint64_t blocks_live;      /* device ciphertext blocks currently allocated */
+    uint64_t max_input_sum_c2; /* largest sum of squared coefficients of a bootstrap's input (flattened linear
+                                * combination of bootstrap outputs / uploads): its noise variance in units of one
+                                * bootstrap output's.  The string layer keeps it <= FHS_NOISE_BUDGET_SUM_C2. */
 } fhs_stats;
+/* Design rule of the fused DAGs: with a measured bootstrap-output sigma of 2^48.9 a sum with
+ * sum c^2 <= 64 adds sigma <= 2^51.9 to the 2^55.2 of keyswitch + modulus switch (+0.8 %): the reference parameter
+ * set's 2^-40 failure probability is kept (tests/test_gpu_noise.py measures it). */
+#define FHS_NOISE_BUDGET_SUM_C2 64
 int fhs_get_stats(fhs_ctx *ctx, fhs_stats *out);
 int fhs_reset_stats(fhs_ctx *ctx);
 

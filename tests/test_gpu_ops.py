@@ -94,7 +94,11 @@ def test_golden_vectors_on_gpu(product, v, mode):
         with pytest.raises(OverflowError, match=v["expected_panic"]):
             run_vector(v, *env)
         return
+    sk.stats(reset=True)
     check_vector(v, run_vector(v, *env))
+    # noise design rule (include/fhestring_hip.h FHS_NOISE_BUDGET_SUM_C2): no bootstrap input of any op, in either
+    # mode, is a linear combination with sum c^2 above 64 (tests/test_gpu_noise.py measures what that buys)
+    assert sk.stats()["max_input_sum_c2"] <= 64, sk.stats()
 
 
 def test_fused_and_as_written_agree_on_random_strings(product):

@@ -1,5 +1,12 @@
-"""Two ranks on one MI355X (gloo group, both contexts on GPU 0): the real sharded contains() --
-window plan, per-rank DAG, export, all-gather, import, final OR level -- against python `in`."""
+"""The library's own distributed layer (fhs_dist_*) on one MI355X.
+
+* two ranks sharing GPU 0 (RCCL refuses two ranks on one device, so the library's host transport carries the all-gather
+  through a gloo group): the sharded contains / find / eq / eq_ignore_case / comparisons of capi_dist.cpp -- window or
+  position plan, per-rank partial DAG, one exchange, combine on every rank -- against python str semantics;
+* the level-parallel flush inside the library (identical DAGs, every PBS level split, one all-gather per level);
+* a 1-rank RCCL communicator created by the library itself: the stream-ordered path (ncclAllGather enqueued on the
+  context's HIP stream, no host wait), pipelined over two contexts like bench.py.
+"""
 import os
 import subprocess
 import sys
@@ -10,50 +17,62 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
-import os, sys
+import operator, os, sys
 import torch, torch.distributed as dist
 sys.path.insert(0, os.environ["FHS_ROOT"])
 from fhestring_amd.api import MyClientKey, MyServerKey
-from fhestring_amd.parallel import ShardedContains, ShardedEq, ShardedCmp
+from fhestring_amd.parallel import Dist
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 ck = MyClientKey(0xF5E57121)                 # same seed -> same keys on every rank
-sk = MyServerKey.from_client_key(ck, 0)
+sk = MyServerKey.from_client_key(ck, 0, arith=1)
 sk.set_mode(1)
-job = ShardedContains(sk, rank, world, dist, torch)
+D = Dist.from_torch(sk, dist, torch)         # gloo backend -> host transport through the library's callback
 ok = True
 for s, p in [("the quick brown fox jumps over", "n fo"), ("the quick brown fox jumps over", "zama"),
-             ("abcabcabcabd", "cabd")]:
-    shard = job.upload_shard(ck, s, len(s) // world, len(p))
-    got = ck.decrypt_char(job.run(shard, p))
-    ok &= (got == int(p in s))
-ej = ShardedEq(sk, rank, world, dist, torch)
-for a, b, op in [("Sharded Equality", "Sharded Equality", "eq"), ("Sharded Equality", "Sharded Equalitx", "eq"),
-                 ("Sharded Equality", "sHARDED eQUALITY", "eq_ignore_case"), ("short", "shorter", "eq")]:
+             ("abcabcabcabd", "cabd"), ("ab", "abc")]:
+    shard, w0, total = D.window_shard(ck, s, len(p))
+    ok &= ck.decrypt_char(D.contains(shard, p)) == int(p in s)                                   # clear pattern
+    ok &= ck.decrypt_char(D.contains(shard, ck.encrypt_no_padding(p, sk))) == int(p in s)        # encrypted pattern
+    want = s.find(p) if p in s else 255
+    ok &= ck.decrypt_char(D.find(shard, ck.encrypt_no_padding(p, sk), w0, total)) == want
+    ok &= ck.decrypt_char(D.find(shard, p, w0, total)) == want
+try:                                          # the reference panics at 255 + m characters (mod.rs:1025-1027)
+    shard, w0, total = D.window_shard(ck, "x" * 8, 3)
+    D.find(shard, "xyz", w0, 300)
+    ok = False
+except OverflowError:
+    pass
+for a, b, fold in [("Sharded Equality", "Sharded Equality", False), ("Sharded Equality", "Sharded Equalitx", False),
+                   ("Sharded Equality", "sHARDED eQUALITY", True), ("short", "shorter", False)]:
     n = max(len(a), len(b)) + 1
-    got = ck.decrypt_char(ej.run(ej.upload_shard(ck, a, n), ej.upload_shard(ck, b, n), op))
-    ok &= (got == (int(a == b) if op == "eq" else int(a.lower() == b.lower())))
-import operator
-cj = ShardedCmp(sk, rank, world, dist, torch)
+    got = ck.decrypt_char(D.eq(D.position_shard(ck, a, n), D.position_shard(ck, b, n), fold))
+    ok &= got == (int(a.lower() == b.lower()) if fold else int(a == b))
 for a, b in [("apple pie", "apple pie"), ("apple pie", "apple pif"), ("bpple", "apple pie"), ("abc", "abcd")]:
     n = max(len(a), len(b)) + 1
     for op, f in (("lt", operator.lt), ("le", operator.le), ("gt", operator.gt), ("ge", operator.ge)):
-        got = ck.decrypt_char(cj.run(cj.upload_shard(ck, a, n), cj.upload_shard(ck, b, n), op))
-        ok &= (got == int(f(a, b)))
+        got = ck.decrypt_char(D.compare(D.position_shard(ck, a, n), D.position_shard(ck, b, n), op))
+        ok &= got == int(f(a, b))
+# batched contains (what bench.py runs): 3 strings, ONE exchange
+strings = ["the quick brown fox jumps over", "a lazy dog sleeps under the sun", "abcabcabcabdabcabcabcabdabcabc"]
+shards = [D.window_shard(ck, s, 4)[0] for s in strings]
+ok &= [ck.decrypt_char(o) for o in D.contains_batch(shards, "n fo")] == [int("n fo" in s) for s in strings]
+assert sk.stats()["max_input_sum_c2"] <= 64
 dist.barrier()
+D.shutdown()
 dist.destroy_process_group()
 sk.close()
 sys.exit(0 if ok else 3)
 '''
 
 
-def test_sharded_contains_two_ranks_one_gpu(tmp_path):
+def test_sharded_ops_two_ranks_one_gpu(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, FHS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
-    rcs = [p.wait(timeout=500) for p in procs]
+    rcs = [p.wait(timeout=600) for p in procs]
     assert rcs == [0, 0]
 
 
@@ -66,9 +85,9 @@ from fhestring_amd.api import MyClientKey, MyServerKey
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 ck = MyClientKey(0xF5E57121)                 # same seed and call order -> identical ciphertexts on every rank
-sk = MyServerKey.from_client_key(ck, 0)
+sk = MyServerKey.from_client_key(ck, 0, arith=1)
 sk.set_mode(1)
-sk.enable_level_parallel(rank, world, dist, torch)
+sk.enable_level_parallel(rank, world, dist, torch)      # fhs_dist_level_parallel: fhs_flush splits every level
 s = ck.encrypt("hello abc abc test", 1, None, sk)
 o = ck.encrypt("hello abd", 2, None, sk)
 ok = True
@@ -83,6 +102,7 @@ dist.all_gather(tot, mine)
 share = st["pbs_executed"] / sum(float(t) for t in tot)
 ok &= 0.35 < share < 0.65                    # each rank ran about half of every level
 dist.barrier()
+sk.dist.shutdown()
 dist.destroy_process_group()
 sk.close()
 sys.exit(0 if ok else 3)
@@ -102,13 +122,12 @@ def test_level_parallel_two_ranks_one_gpu(tmp_path):
 
 RCCL_WORKER = r'''
 import os, sys
-import torch, torch.distributed as dist
+import torch
 sys.path.insert(0, os.environ["FHS_ROOT"])
 from fhestring_amd.api import MyClientKey, MyServerKey
-from fhestring_amd.parallel import ShardedContains
+from fhestring_amd.parallel import Dist
 
 torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 ck = MyClientKey(0xF5E57121)
 sks = [MyServerKey.from_client_key(ck, 0, arith=1) for _ in range(2)]      # two pipelines, like bench.py
 strings = ["the quick brown fox jumps over", "a lazy dog sleeps under the sun", "abcabcabcabdabcabcabcabdabcabc"]
@@ -116,18 +135,28 @@ pat = "n fo"
 jobs, shards = [], []
 for sk in sks:
     sk.set_mode(1)
-    jobs.append(ShardedContains(sk, 0, 1, dist, torch))
-    shards.append([jobs[-1].upload_shard(ck, s, len(s), len(pat)) for s in strings])
+    D = Dist(sk, 0, 1).init_single()        # the library's own 1-rank RCCL communicator (librccl.so.1 via dlopen)
+    D._force = True                          # exchange even though world == 1
+    jobs.append(D)
+    shards.append([D.window_shard(ck, s, len(pat))[0] for s in strings])
     sk.flush()
 outs = []
 for step in range(4):                       # nothing below waits on the host until the final synchronize
     k = step % 2
-    outs.append(jobs[k].run_batch(shards[k], pat, force_exchange=True))
+    outs.append(jobs[k].contains_batch(shards[k], pat))
     sks[k].flush(wait=False)
 torch.cuda.synchronize()
 ok = all([ck.decrypt_char(o) for o in res] == [int(pat in s) for s in strings] for res in outs)
-dist.barrier()
-dist.destroy_process_group()
+# sharded find and level-parallel replace through the same communicator
+D = jobs[0]
+sh, w0, total = D.window_shard(ck, strings[0], 3)
+ok &= ck.decrypt_char(D.find(sh, ck.encrypt_no_padding("fox", sks[0]), w0, total)) == strings[0].find("fox")
+D.level_parallel(True)
+s = ck.encrypt("hello abc abc", 1, None, sks[0])
+ok &= ck.decrypt(sks[0].replace(s, ck.encrypt_no_padding("abc", sks[0]), ck.encrypt_no_padding("xy", sks[0]))) == "hello xy xy"
+D.level_parallel(False)
+for D in jobs:
+    D.shutdown()
 for sk in sks:
     sk.close()
 sys.exit(0 if ok else 3)
@@ -135,11 +164,11 @@ sys.exit(0 if ok else 3)
 
 
 def test_stream_ordered_rccl_exchange_one_rank(tmp_path):
-    """The N>1 bench path (export -> RCCL all-gather on the context's own HIP stream -> import -> OR, pipelined
-    over two contexts without any host wait) with a 1-rank nccl group: the most of it one GPU can exercise."""
+    """The N>1 bench path (local DAG -> ncclAllGather enqueued by the library on the context's own HIP stream ->
+    import -> OR, pipelined over two contexts without any host wait) with a 1-rank communicator: the most of it one GPU
+    can exercise."""
     script = tmp_path / "rccl_worker.py"
     script.write_text(RCCL_WORKER)
-    env = dict(os.environ, FHS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="1", RANK="0",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, FHS_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.Popen([sys.executable, str(script)], env=env)
     assert p.wait(timeout=500) == 0

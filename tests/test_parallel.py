@@ -1,10 +1,13 @@
-"""Sharding logic of the multi-GPU path, on CPU: window plan properties and a world_size-2 gloo
-run of fhestring_amd.parallel.ShardedContains against a clear-text stand-in for the server key."""
-import os
-import sys
+"""Sharding logic of the multi-GPU path on CPU (no GPU, gloo, world_size 2).
 
-import numpy as np
-import pytest
+The partition functions are the library's own (fhs_dist_plan_windows / fhs_dist_plan_positions, pure host code behind
+the C ABI).  The partial / combine DESIGN of the sharded entry points (fhs_dist_str_contains / find / eq / compare:
+local partial per slice, one all-gather, combine on every rank) is replayed on clear text over a real 2-rank gloo group
+and must equal python's `in` / str.find / == / comparisons on the whole string -- including ranks that own no window,
+matches that straddle the slice boundary, and the 255 "not found" sentinel."""
+import os
+import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -21,85 +24,97 @@ def test_plan_windows_partitions_all_windows():
                 for (w0, w1, c0, c1) in plan:
                     if w1 > w0:
                         assert c0 == w0 and c1 == w1 + m - 1 <= n     # slice + (m-1) halo
+                    else:
+                        assert (c0, c1) == (0, 0)
+
+
+def test_plan_positions_partitions_all_positions():
+    from fhestring_amd.parallel import plan_positions
+    for n in (0, 1, 7, 4097):
+        for world in (1, 2, 3, 8):
+            plan = plan_positions(n, world)
+            assert [c for (c0, c1) in plan for c in range(c0, c1)] == list(range(n))
+            sizes = [c1 - c0 for c0, c1 in plan]
+            assert max(sizes) - min(sizes) <= 1
 
 
 WORKER = r'''
-import ctypes, os, sys
-import numpy as np
+import operator, os, sys
 import torch, torch.distributed as dist
 sys.path.insert(0, os.environ["FHS_ROOT"])
-from fhestring_amd.parallel import ShardedContains, ShardedEq, ShardedCmp, CHAR_WORDS
-
-class ClearChar:
-    def __init__(self, v): self.v = v
-class ClearKey:                       # stands in for MyClientKey: "encrypts" to clear chars
-    def encrypt(self, text, pad, pp, sk): return [ClearChar(b) for b in text.encode()] + [ClearChar(0)] * pad
-class ClearServerKey:                 # stands in for MyServerKey (same method names)
-    device_resident = False
-    def contains_clear(self, chars, pat):
-        s = bytes(c.v for c in chars)
-        return ClearChar(int(pat.encode() in s))
-    def trivial(self, v): return ClearChar(v)
-    def export_device(self, ch, ptr):
-        buf = np.zeros(CHAR_WORDS, np.int64); buf[2048] = ch.v
-        ctypes.memmove(ptr, buf.ctypes.data, buf.nbytes)
-    def import_device(self, ptr):
-        buf = np.zeros(CHAR_WORDS, np.int64)
-        ctypes.memmove(buf.ctypes.data, ptr, buf.nbytes)
-        return ClearChar(int(buf[2048]))
-    def flags_or(self, parts): return ClearChar(int(any(p.v for p in parts)))
-    def flags_and(self, parts): return ClearChar(int(all(p.v for p in parts)))
-    def _text(self, chars): return bytes(c.v for c in chars).split(b"\0")[0]
-    def compare_partial(self, a, b, cmp):
-        x, y = bytes(c.v for c in a), bytes(c.v for c in b)
-        diff = [i for i in range(len(x)) if x[i] != y[i]]
-        if not diff: return ClearChar(0), ClearChar(0)
-        i = diff[0]
-        return ClearChar(1), ClearChar(int(x[i] < y[i]) if cmp in (0, 1) else int(x[i] > y[i]))
-    def flags_first_decides(self, ds, vs, tie):
-        for d, v in zip(ds, vs):
-            if d.v: return ClearChar(v.v)
-        return ClearChar(tie)
-    def eq(self, a, b): return ClearChar(int(self._text(a) == self._text(b)))
-    def eq_ignore_case(self, a, b): return ClearChar(int(self._text(a).lower() == self._text(b).lower()))
+from fhestring_amd.parallel import plan_windows, plan_positions
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-job = ShardedContains(ClearServerKey(), rank, world, dist, torch)
+
+def gather(vals):                       # what fhs_dist_allgather_* does: k values per rank -> [rank][k]
+    t = torch.tensor(vals, dtype=torch.int64)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return [p.tolist() for p in parts]
+
+def contains(full, pat, pad=1):         # fhs_dist_str_contains
+    buf = full.encode() + b"\0" * pad
+    w0, w1, c0, c1 = plan_windows(len(buf), len(pat), world)[rank]
+    shard = buf[c0:c1]
+    local = int(len(shard) >= len(pat) and pat.encode() in shard) if len(pat) else 1
+    return int(any(p[0] for p in gather([local])))
+
+def find(full, pat, pad=1):             # fhs_dist_str_find: partial (found, global position), first slice decides
+    buf = full.encode() + b"\0" * pad
+    w0, w1, c0, c1 = plan_windows(len(buf), len(pat), world)[rank]
+    shard = buf[c0:c1]
+    k = shard.find(pat.encode()) if len(shard) >= len(pat) else -1
+    found, pos = int(k >= 0), (w0 + k if k >= 0 else 0)
+    for f, p in gather([found, pos]):
+        if f:
+            return p
+    return 255
+
+def eq(a, b, n, fold=False):            # fhs_dist_str_eq on equally long padded buffers
+    c0, c1 = plan_positions(n, world)[rank]
+    x, y = a.encode().ljust(n, b"\0")[c0:c1], b.encode().ljust(n, b"\0")[c0:c1]
+    if fold:
+        x, y = x.lower(), y.lower()
+    return int(all(p[0] for p in gather([int(x == y)])))
+
+def compare(a, b, n, op):               # fhs_dist_str_compare: (any position differs, verdict at the first difference)
+    c0, c1 = plan_positions(n, world)[rank]
+    x, y = a.encode().ljust(n, b"\0")[c0:c1], b.encode().ljust(n, b"\0")[c0:c1]
+    diff = [i for i in range(len(x)) if x[i] != y[i]]
+    d, v = 0, 0
+    if diff:
+        i = diff[0]
+        d, v = 1, int(x[i] < y[i]) if op in ("lt", "le") else int(x[i] > y[i])
+    for dd, vv in gather([d, v]):
+        if dd:
+            return vv
+    return int(op in ("le", "ge"))
+
 ok = True
-cases = [("abcdefghij" * 3, "jab"), ("abcdefghij" * 3, "xyz"), ("aaaaab", "ab"), ("ab", "abc"), ("hello world", "o w")]
+cases = [("abcdefghij" * 3, "jab"), ("abcdefghij" * 3, "xyz"), ("aaaaab", "ab"), ("ab", "abc"), ("hello world", "o w"),
+         ("x" * 14 + "needle" + "y" * 11, "needle"), ("needle" + "y" * 30, "needle"), ("y" * 30 + "needle", "needle")]
 for s, p in cases:
-    shard = job.upload_shard(ClearKey(), s, len(s) // world, len(p))
-    got = job.run(shard, p).v
-    ok &= (got == int(p in s))
-# the batched entry bench.py uses (falls back to the per-string exchange without RCCL)
-strings = ["abcdefghij" * 3, "zzzzzzzzzzjabzzzzzzzzzzzzzzzzz", "q" * 30]
-shards = [job.upload_shard(ClearKey(), s, len(s) // world, 3) for s in strings]
-ok &= ([o.v for o in job.run_batch(shards, "jab")] == [int("jab" in s) for s in strings])
-# eq / eq_ignore_case with the character positions split over the ranks (config 5 shape)
-ej = ShardedEq(ClearServerKey(), rank, world, dist, torch)
-for a, b, op in [("hello world!", "hello world!", "eq"), ("hello world!", "hello worle!", "eq"), ("abc", "abcd", "eq"),
-                 ("Hello World", "hELLO wORLD", "eq_ignore_case"), ("Hello World", "hELLO wORLx", "eq_ignore_case")]:
+    ok &= contains(s, p) == int(p in s)
+    ok &= find(s, p) == (s.find(p) if p in s else 255)
+for a, b in [("hello world!", "hello world!"), ("hello world!", "hello worle!"), ("abc", "abcd"), ("", "")]:
     n = max(len(a), len(b)) + 1
-    got = ej.run(ej.upload_shard(ClearKey(), a, n), ej.upload_shard(ClearKey(), b, n), op).v
-    want = int(a == b) if op == "eq" else int(a.lower() == b.lower())
-    ok &= (got == want)
-cj = ShardedCmp(ClearServerKey(), rank, world, dist, torch)
-import operator
+    ok &= eq(a, b, n) == int(a == b)
+for a, b in [("Hello World", "hELLO wORLD"), ("Hello World", "hELLO wORLx")]:
+    ok &= eq(a, b, len(a) + 1, fold=True) == int(a.lower() == b.lower())
 OPS = {"lt": operator.lt, "le": operator.le, "gt": operator.gt, "ge": operator.ge}
-for a, b in [("apple pie", "apple pie"), ("apple pie", "apple pif"), ("bpple pie", "apple pie"), ("abc", "abcd"), ("abcd", "abc"), ("", "")]:
+for a, b in [("apple pie", "apple pie"), ("apple pie", "apple pif"), ("bpple pie", "apple pie"), ("abc", "abcd"),
+             ("abcd", "abc"), ("", "")]:
     n = max(len(a), len(b)) + 1
     for op, f in OPS.items():
-        got = cj.run(cj.upload_shard(ClearKey(), a, n), cj.upload_shard(ClearKey(), b, n), op).v
-        ok &= (got == int(f(a, b)))
+        ok &= compare(a, b, n, op) == int(f(a, b))
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 3)
 '''
 
 
-def test_sharded_contains_world2_gloo(tmp_path):
-    import subprocess
+def test_sharded_design_world2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, FHS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
