@@ -1,36 +1,41 @@
 #!/usr/bin/env python3
-"""bench.py -- PBS/s and ms/op for contains() on an N-char FheString (BASELINE.json metric).
+"""bench.py -- PBS/s and ms/op for FheString operations on MI355X (BASELINE.json metric).
 
-One step = one `contains_clear` over one batch of synthetic input: `--strings` independent
-FheStrings of `--chars` plaintext characters each (+1 NUL pad, src/main.rs:12), clear pattern of
-`--pattern-len` characters (hit case), i.e. BASELINE.json configs[1] at the defaults.
+Default (what the driver runs): `contains` with a clear pattern on 64-char FheStrings = BASELINE configs[1].
+One step = one pass of the hot path over one batch of synthetic input: `--strings` independent FheStrings of `--chars`
+plaintext characters (+1 NUL pad, src/main.rs:12), pattern of `--pattern-len` characters (hit case).  Inputs
+(ciphertexts, keys, LUTs) are resident in HBM before the timed region.  The timed region is K x [build the DAG on the
+host, plan it, run every PBS level on the GPU, (exchange + combine)], bracketed by barrier + device synchronize, max over
+ranks; `value` = PBS executed by all ranks / that time.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): the string is `chars * N` long
-and its match windows are sharded over the ranks (each rank holds its 64-char slice plus an
-(m-1)-char halo, no other data exchange); the per-rank partial flags are combined with one RCCL
-all-gather of one FheAsciiChar per rank followed by a single OR level.  "scaling": "weak".
-
-Inputs (ciphertexts, keys, LUTs) are resident in HBM before the timed region.  The timed region
-is: K x [build the DAG on the host, plan it, run every PBS level on the GPU, (gather + final OR)],
-bracketed by barrier + device synchronize, max over ranks.
+--op selects the other BASELINE configs, --scaling how they use N GPUs (one rank per GPU, torch.distributed.run):
+  contains        cfg 2   weak: the string grows to chars x N, match windows sharded (1 all-gather of 1 block per rank)
+                          strong: `--chars` characters in total, windows sharded
+  find_enc        cfg 3   find with an ENCRYPTED pattern on 256 chars; strong only (u8 index: < 255 + m characters)
+  replace         cfg 4   replace with encrypted from/to (5 -> 5) on 1024 chars; level-parallel (every PBS level split)
+  eq_ignore_case  cfg 5   4096-char buffers, character positions sharded
+  le              cfg 5   4096-char buffers, character positions sharded
+All exchanges are ncclAllGather calls issued by the library itself on the context's HIP stream (fhs_dist_*).
+The default run also times configs 3-5 once each at their fixed BASELINE sizes over the same N ranks ("configs").
 """
 import argparse
 import json
 import os
 import random
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_PBS = 109_559_824      # BSK + KSK + in + out + LUT, canonical u64
+ALGO_BYTES_PER_PBS = 109_559_824      # BSK + KSK + in + out + LUT, canonical u64 (NOT a bound, see hbm)
+COMPULSORY_KEY_BYTES = 109_494_272    # one key sweep serves a whole launch
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec
-# FP64 work of one PBS in blind_rotate_fft_kernel, counted in its compiled loop body (gfx950 ISA): 768 FMA + 604
-# other v_*_f64 per wave-iteration = 2140 flop per lane x 64 lanes x 2 waves x 742 iterations
-FFT_FLOP_PER_PBS = 2140 * 64 * 2 * 742
-FP64_VALU_PEAK_TFLOPS = 78.6          # half of the 157.3 TF FP32 vector peak: one FP64 FMA per 16 lanes per clock per SIMD
+FP64_VALU_PEAK_TFLOPS = 78.6          # vector FP64: 256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 flop x 2.4 GHz
 SEED = 0xF5E57121
+OPS = ("contains", "find_enc", "replace", "eq_ignore_case", "le")
+FIXED = {"find_enc": 256, "replace": 1024, "eq_ignore_case": 4096, "le": 4096}
 
 
 def parse():
@@ -38,37 +43,46 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--chars", type=int, default=64, help="plaintext characters per rank")
-    ap.add_argument("--pattern-len", type=int, default=4)
-    ap.add_argument("--strings", type=int, default=8,
-                    help="independent FheStrings per step: one 64-char contains() has ~560 PBS in 4 dependent "
-                         "levels and cannot fill 256 CUs, so a step is a batch (single-op latency is reported too)")
+    ap.add_argument("--op", choices=OPS, default="contains")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: weak for contains (chars per GPU fixed), strong for the fixed-size configs 3-5")
+    ap.add_argument("--chars", type=int, default=None, help="plaintext characters (per rank if weak, in total if strong)")
+    ap.add_argument("--pattern-len", type=int, default=None)
+    ap.add_argument("--strings", type=int, default=None,
+                    help="independent FheStrings per step (default 8 for contains: one 64-char contains() has ~560 PBS "
+                         "in 4 dependent levels and cannot fill 256 CUs; 1 for the other ops)")
     ap.add_argument("--mode", choices=["fused", "as_written"], default="fused")
-    ap.add_argument("--op", choices=["contains", "find"], default="contains")
-    ap.add_argument("--cpu-pbs", type=int, default=-1, help="PBS in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--dist-mode", choices=["windows", "levels"], default="windows",
-                    help="N>1: 'windows' shards the match windows (1 all-gather of 1 char per rank); 'levels' "
-                         "replicates the string and splits every PBS level (1 all-gather per level)")
+    ap.add_argument("--cpu-pbs", type=int, default=-1, help="PBS in the CPU-baseline throughput sample (0 = skip)")
     ap.add_argument("--arith", choices=["fft", "exact"], default="fft",
                     help="arithmetic of the negacyclic products in blind rotation: 'fft' = f64 complex FFT (the "
                          "reference engine's algorithm class, fhs_set_arithmetic(FHS_ARITH_F64_FFT)); 'exact' = "
-                         "two-prime exact NTT (library default).  The other one is timed too (secondary section)")
-    ap.add_argument("--pipelines", type=int, default=3,
-                    help="independent contexts (own HIP stream, scratch and block pool) per GPU; step k runs on "
-                         "pipeline k mod P, so the narrow tail levels of one step overlap the wide first level of the "
-                         "next (1 = strictly one step after the other)")
+                         "two-prime exact NTT (library default).  The other one is timed too (other_arithmetic)")
+    ap.add_argument("--pipelines", type=int, default=None,
+                    help="independent contexts (own HIP stream, scratch, block pool, communicator) per GPU; step k runs "
+                         "on pipeline k mod P so the narrow tail levels of one step overlap the wide first level of "
+                         "the next (default 3 for contains, 1 otherwise)")
+    ap.add_argument("--repeats", type=int, default=5, help="extra repeats for the median (0 = skip)")
     ap.add_argument("--skip-secondary", action="store_true", help="do not time the other arithmetic")
-    ap.add_argument("--skip-single-op", action="store_true",
-                    help="do not run the extra single-op latency section (profiling: every launch is then timed)")
-    return ap.parse_args()
+    ap.add_argument("--skip-single-op", action="store_true", help="skip single-op latency / end-to-end / as-written")
+    ap.add_argument("--skip-extras", action="store_true", help="skip the configs 3-5 section of the default run")
+    a = ap.parse_args()
+    if a.scaling is None:
+        a.scaling = "weak" if a.op == "contains" else "strong"
+    if a.op != "contains" and a.scaling == "weak":
+        raise SystemExit("--scaling weak is only defined for contains (configs 3-5 are fixed-size strings)")
+    if a.chars is None:
+        a.chars = FIXED.get(a.op, 64)
+    if a.pattern_len is None:
+        a.pattern_len = 5 if a.op == "replace" else 4
+    if a.strings is None:
+        a.strings = 8 if a.op == "contains" else 1
+    if a.pipelines is None:
+        a.pipelines = 3 if a.op == "contains" else 1
+    return a
 
 
-def synth_strings(n_strings, total_chars, m, rnd):
-    """printable ASCII 0x20-0x7E; the pattern is copied from a random offset (hit case)."""
-    strings = ["".join(chr(rnd.randint(0x20, 0x7E)) for _ in range(total_chars)) for _ in range(n_strings)]
-    off = rnd.randint(0, total_chars - m)
-    pattern = strings[0][off:off + m]
-    return strings, pattern
+def rand_text(rnd, n):
+    return "".join(chr(rnd.randint(0x20, 0x7E)) for _ in range(n))
 
 
 def usable_cores():
@@ -86,18 +100,138 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("FHS_CPU_THREADS", n))))
 
 
-def cpu_baseline(n_pbs):
-    """CPU side by side (kind 'port'): the oracle's PBS on the host cores, same parameter set.
-    Three variants are timed and the FASTEST one is the baseline: the exact
-    Goldilocks-NTT path (the parity oracle) and two f64-FFT external products (the algorithm class of the
-    reference's tfhe/concrete-fft; approximate, validated at decrypt level in tests/test_oracle_pbs.py)."""
+# ---------------------------------------------------------------------------------------------------------------
+# workloads: setup() makes the inputs resident, step(k) records + enqueues one step on pipeline k, check() decrypts
+# ---------------------------------------------------------------------------------------------------------------
+class Workload:
+    def __init__(self, args, ck, sks, dists, rank, world, op=None, chars=None, strings=None, scaling=None):
+        self.a, self.ck, self.sks, self.dists, self.rank, self.world = args, ck, sks, dists, rank, world
+        self.op = op or args.op
+        self.scaling = scaling or ("strong" if self.op != "contains" else args.scaling)
+        self.chars = chars if chars is not None else args.chars
+        self.n_strings = strings if strings is not None else args.strings
+        self.m = 5 if self.op == "replace" else args.pattern_len if self.op == args.op else 4
+        self.rnd = random.Random(SEED + OPS.index(self.op))
+        self.inputs = []
+        self.setup()
+
+    def total_chars(self):
+        return self.chars * self.world if (self.op == "contains" and self.scaling == "weak") else self.chars
+
+    def setup(self):
+        op, n, m, rnd, ck = self.op, self.total_chars(), self.m, self.rnd, self.ck
+        self.plain = []
+        if op in ("contains", "find_enc"):
+            strs = [rand_text(rnd, n) for _ in range(self.n_strings)]
+            off = rnd.randint(0, n - m) if op == "contains" else min(200, n - m)
+            self.pattern = strs[0][off:off + m]
+            self.plain = strs
+        elif op == "replace":
+            self.frm, self.to = "~from", "[to!]"
+            for _ in range(self.n_strings):
+                s = list(rand_text(rnd, n).replace("~", "-"))
+                for k in range(max(1, n // 128)):
+                    s[20 + 120 * k:25 + 120 * k] = self.frm
+                self.plain.append("".join(s))
+        else:
+            for _ in range(self.n_strings):
+                a = rand_text(rnd, n)
+                b = list(a.swapcase())
+                b[n - 96] = "a" if a[n - 96].lower() != "a" else "b"      # equal up to case except one position
+                self.plain.append((a, "".join(b)))
+        for sk, D in zip(self.sks, self.dists):
+            res = {}
+            if op in ("contains", "find_enc"):
+                if self.world > 1:
+                    res["shards"] = [D.window_shard(ck, s, m) for s in self.plain]
+                else:
+                    res["shards"] = [(ck.encrypt(s, 1, None, sk), 0, len(s) + 1) for s in self.plain]
+                if op == "find_enc":
+                    res["pat"] = ck.encrypt_no_padding(self.pattern, sk)
+            elif op == "replace":
+                res["strs"] = [ck.encrypt(s, 1, None, sk) for s in self.plain]       # replicated: level-parallel
+                res["from"], res["to"] = ck.encrypt_no_padding(self.frm, sk), ck.encrypt_no_padding(self.to, sk)
+            else:
+                nb = n + 1
+                if self.world > 1:
+                    res["pairs"] = [(D.position_shard(ck, a, nb), D.position_shard(ck, b, nb)) for a, b in self.plain]
+                else:
+                    res["pairs"] = [(ck.encrypt(a, 1, None, sk), ck.encrypt(b, 1, None, sk)) for a, b in self.plain]
+            sk.flush()
+            self.inputs.append(res)
+
+    def parallelism(self):
+        w = self.world
+        if self.op in ("contains", "find_enc"):
+            return "match windows sharded over %d GPU(s), 1 ncclAllGather of %d block(s) per rank per op" % (
+                w, 1 if self.op == "contains" else 5)
+        if self.op == "replace":
+            return "level-parallel: every PBS level split over %d GPU(s), 1 ncclAllGather per level" % w
+        return "character positions sharded over %d GPU(s), 1 ncclAllGather of %d block(s) per rank" % (
+            w, 1 if self.op == "eq_ignore_case" else 2)
+
+    def step(self, k=0):
+        sk, D, res, op = self.sks[k], self.dists[k], self.inputs[k], self.op
+        if op == "contains":
+            if self.world > 1:
+                return D.contains_batch([s for s, _, _ in res["shards"]], self.pattern)
+            return [sk.contains_clear(s, self.pattern) for s, _, _ in res["shards"]]
+        if op == "find_enc":
+            if self.world > 1:
+                return [D.find(s, res["pat"], w0, tot) for s, w0, tot in res["shards"]]
+            return [sk.find(s, res["pat"]) for s, _, _ in res["shards"]]
+        if op == "replace":
+            return [sk.replace(s, res["from"], res["to"]) for s in res["strs"]]
+        if self.world > 1:
+            if op == "eq_ignore_case":
+                return [D.eq_ignore_case(a, b) for a, b in res["pairs"]]
+            return [D.compare(a, b, "le") for a, b in res["pairs"]]
+        if op == "eq_ignore_case":
+            return [sk.eq_ignore_case(a, b) for a, b in res["pairs"]]
+        return [sk.le(a, b) for a, b in res["pairs"]]
+
+    def check(self, outs):
+        ck, op = self.ck, self.op
+        for i, o in enumerate(outs):
+            if op == "contains":
+                got, want = ck.decrypt_char(o), int(self.pattern in self.plain[i])
+            elif op == "find_enc":
+                got = ck.decrypt_char(o)
+                want = self.plain[i].find(self.pattern) if self.pattern in self.plain[i] else 255
+            elif op == "replace":
+                got, want = ck.decrypt(o), self.plain[i].replace(self.frm, self.to)
+            elif op == "eq_ignore_case":
+                got, want = ck.decrypt_char(o), int(self.plain[i][0].lower() == self.plain[i][1].lower())
+            else:
+                got, want = ck.decrypt_char(o), int(self.plain[i][0] <= self.plain[i][1])
+            assert got == want, ("bench result mismatch", op, i, got, want)
+
+    def describe(self):
+        names = {"contains": "contains_clear", "find_enc": "find (encrypted pattern)", "replace": "replace (encrypted from/to, 5 -> 5)",
+                 "eq_ignore_case": "eq_ignore_case", "le": "le (<=)"}
+        size = ("%d-char FheString per GPU" % self.chars) if (self.op == "contains" and self.scaling == "weak") \
+            else ("%d-char FheString%s in total" % (self.chars, "s" if self.op in ("eq_ignore_case", "le") else ""))
+        return "%s, %s (+1 NUL pad), pattern m=%d, %d string(s)/step" % (names[self.op], size, self.m, self.n_strings)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU side by side
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_baseline(n_pbs, level_widths):
+    """kind 'port': the oracle's PBS on the host cores, same parameter set.  (1) raw PBS throughput of its three
+    variants (exact Goldilocks NTT = the parity oracle; two f64-FFT external products = the algorithm class of the
+    reference's tfhe / concrete-fft), the fastest is `value`; (2) the SAME levelized batches one op of the timed
+    workload runs on the GPU, with the fastest variant; (3) BASELINE configs[0]: the reference CLI's
+    eq("hello", "hello") DAG as written (src/utils.rs:691-703), wall time on the host cores."""
     import numpy as np
     from oracle import core, radix
+    from oracle import strings as ostr
     cores = usable_cores()
     K = core.Keys(SEED)
     S = core.ServerKey(K)
     rng = np.random.default_rng(0)
     luts = np.stack([radix.lut_poly("eq_c1"), radix.lut_poly("is4")])
+    names = ["eq_c1", "is4"]
 
     def run(mode, n):
         msgs = rng.integers(0, 16, n)
@@ -107,7 +241,6 @@ def cpu_baseline(n_pbs):
         t0 = time.perf_counter()
         out = S.pbs_batch(cts, idx, luts, cores, mode=mode)
         dt = time.perf_counter() - t0
-        names = ["eq_c1", "is4"]
         ok = all(K.decrypt_block(out[i]) == radix.LUTS[names[idx[i]]](int(msgs[i])) for i in range(min(n, 16)))
         return n / dt, dt, ok
 
@@ -117,12 +250,74 @@ def cpu_baseline(n_pbs):
     mir_rate, mir_dt, mir_ok = run(3, n_fft)        # merged-twist f64 FFT (the GPU kernel's formulation)
     ex_rate, ex_dt, ex_ok = run(0, n_exact)
     assert fft_ok and mir_ok and ex_ok, "CPU baseline produced wrong plaintexts"
-    best = max(fft_rate, mir_rate, ex_rate)
-    return {"value": best, "unit": "PBS/s", "cores": cores, "kind": "port",
-            "sample": "oracle/tfhe_oracle.c on %d host threads, KS+MS+blind rotation+extract per PBS: "
-                      "merged-twist f64 FFT %d PBS in %.1f s = %.1f PBS/s; textbook f64 FFT %d PBS in %.1f s = %.1f PBS/s; "
-                      "exact NTT (parity oracle) %d PBS in %.1f s = %.1f PBS/s; fastest variant reported"
-                      % (cores, n_fft, mir_dt, mir_rate, n_fft, fft_dt, fft_rate, n_exact, ex_dt, ex_rate)}
+    best_mode, best = max(((3, mir_rate), (2, fft_rate), (0, ex_rate)), key=lambda t: t[1])
+    out = {"value": best, "unit": "PBS/s", "cores": cores, "kind": "port",
+           "ms_per_pbs_per_thread": 1e3 * cores / best,
+           "sample": "oracle/tfhe_oracle.c (a scalar C port, NOT tfhe-rs: published tfhe-rs is ~10-20 ms/PBS/core, "
+                     "i.e. this port is ~%.1fx slower per core) on %d host threads, KS+MS+blind rotation+extract per PBS: "
+                     "merged-twist f64 FFT %d PBS in %.1f s = %.1f PBS/s; textbook f64 FFT %d PBS in %.1f s = %.1f PBS/s; "
+                     "exact NTT (parity oracle) %d PBS in %.1f s = %.1f PBS/s; fastest variant reported"
+                     % ((1e3 * cores / best) / 15.0, cores, n_fft, mir_dt, mir_rate, n_fft, fft_dt, fft_rate, n_exact,
+                        ex_dt, ex_rate)}
+    # (2) the same levelized batches as ONE op of the timed workload (widths from fhs_level_widths)
+    if level_widths and sum(level_widths) <= 4096:
+        t0 = time.perf_counter()
+        for w in level_widths:
+            msgs = rng.integers(0, 16, w)
+            cts = np.stack([K.encrypt_block(int(m)) for m in msgs])
+            S.pbs_batch(cts, (np.arange(w) % 2).astype(np.uint32), luts, cores, mode=best_mode)
+        out["same_levelized_batches"] = {"levels": list(map(int, level_widths)), "pbs": int(sum(level_widths)),
+                                         "ms_per_op": (time.perf_counter() - t0) * 1e3,
+                                         "note": "one op of the timed workload, level by level, on the host threads"}
+    # (3) BASELINE configs[0]
+    eng = radix.Engine(S, nthreads=cores, mode=best_mode if best_mode else 2)
+    ops = ostr.Ops(radix.CipherChar, eng)
+    enc = lambda t: [radix.CipherChar.from_cts(K.encrypt_char(b), eng) for b in ostr.pad_plain(t, 1)]
+    a, b = enc("hello"), enc("hello")
+    t0 = time.perf_counter()
+    r = ops.eq(a, b)
+    eng.materialize(list(r.b))
+    dt = time.perf_counter() - t0
+    assert K.decrypt_char(r.cts()) == 1
+    out["config1_eq_hello_hello"] = {"ms": dt * 1e3, "pbs": int(eng.pbs_count), "levels": int(eng.levels),
+                                     "note": "reference CLI DAG as written (src/utils.rs:691-703), CPU port, %d threads" % cores}
+    return out
+
+
+def load_counters():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r02_counters.json")))
+    except Exception:
+        return {}
+
+
+def roofline_for(kernel, pbs_per_launch, launch_ms, n_launches, counters, traffic):
+    """Bounding resource: FP64 vector issue (SQ counters: the VALU is the busiest unit, HBM sits at a fraction of a
+    percent).  achieved = FP64 flop per PBS, COUNTED by SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 under rocprofv3 on this kernel
+    (profiles/r02_counters.json), x PBS per launch / HIP-event launch time measured live.  frac <= 1 by construction."""
+    c = counters.get(kernel, {})
+    flop = c.get("fp64_flop_per_pbs")
+    r = {"bound": "fp64_valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
+         "traffic": traffic, "kernel": kernel, "avg_launch_ms": launch_ms, "launches": n_launches,
+         "avg_pbs_per_launch": pbs_per_launch}
+    if flop and launch_ms > 0:
+        r["achieved"] = pbs_per_launch * flop / (launch_ms * 1e-3) / 1e12
+        r["frac"] = r["achieved"] / FP64_VALU_PEAK_TFLOPS
+    r["counters"] = {k: c.get(k) for k in ("fp64_flop_per_pbs", "valu_insts_per_pbs", "fp64_insts_per_pbs",
+                                           "valu_busy_frac_of_simd", "lds_array_busy_frac", "wave_wait_frac",
+                                           "wave_issue_stall_frac", "clock_ghz", "profile")}
+    if launch_ms > 0:
+        comp = COMPULSORY_KEY_BYTES + pbs_per_launch * 65_552
+        r["hbm"] = {"note": "NOT the bound: one key sweep out of L2 / Infinity Cache serves the whole launch",
+                    "compulsory_bytes_per_launch": comp,
+                    "compulsory_gbs": comp / (launch_ms * 1e-3) / 1e9,
+                    "compulsory_frac_of_peak": comp / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "measured_fabric_bytes_per_launch": traffic,
+                    "measured_fabric_frac_of_peak": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                    "survey_8d_algorithmic_bytes_per_pbs": ALGO_BYTES_PER_PBS,
+                    "survey_8d_figure_gbs": pbs_per_launch * ALGO_BYTES_PER_PBS / (launch_ms * 1e-3) / 1e9,
+                    "peak_gbs": HBM_PEAK_GBS}
+    return r
 
 
 def main():
@@ -135,13 +330,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # FHS_BENCH_BACKEND=gloo rehearses the multi-rank logic with several ranks on ONE GPU (exchange staged through
-        # the host, fhestring_amd/parallel.py); the real run is nccl = RCCL over xGMI, one rank per GPU
+        # FHS_BENCH_BACKEND=gloo rehearses the multi-rank logic with several ranks on ONE GPU (the library's host
+        # transport carries the all-gathers); the real run is nccl = RCCL over xGMI, one rank per GPU
         backend = os.environ.get("FHS_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             local_rank = 0
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -151,41 +345,31 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
 
-    from fhestring_amd.api import MyClientKey, MyServerKey, BIG_CT
-    from fhestring_amd.parallel import ShardedContains
+    from fhestring_amd.api import MyClientKey, MyServerKey
+    from fhestring_amd.parallel import Dist
 
-    if args.op == "find" and args.chars * world + 1 >= 255 + args.pattern_len:
-        raise SystemExit("find returns an encrypted u8 index: the reference panics for strings of 255 + m characters or more "
-                         "(src/server_key/mod.rs:1025-1027); lower --chars or the number of GPUs")
-    if args.op == "find" and world > 1 and args.dist_mode == "windows":
-        args.dist_mode = "levels"     # find has no window-sharded form yet: every rank splits every level instead
-    m = args.pattern_len
-    rnd = random.Random(SEED)
-    strings, pattern = synth_strings(args.strings, args.chars * world, m, rnd)
-    ck = MyClientKey(SEED)                      # same seed on every rank -> identical keys
+    if args.op == "find_enc" and args.chars + 1 >= 255 + args.pattern_len:
+        raise SystemExit("find returns an encrypted u8 index: the reference panics for strings of 255 + m characters "
+                         "or more (src/server_key/mod.rs:1025-1027); lower --chars")
+    ck = MyClientKey(SEED)                      # insecure seeded client: identical keys on every rank (synthetic data)
     P = max(1, args.pipelines)
     sks = [MyServerKey.from_client_key(ck, local_rank, arith=1) for _ in range(P)]   # Fourier-domain key as well
-    sk = sks[0]
-    ARITH = {"fft": sk.ctx.ARITH_F64_FFT, "exact": sk.ctx.ARITH_EXACT_NTT}
-    jobs, shard_sets = [], []
+    ARITH = {"fft": sks[0].ctx.ARITH_F64_FFT, "exact": sks[0].ctx.ARITH_EXACT_NTT}
+    dists = []
     for x in sks:
         x.ctx.set_arithmetic(ARITH[args.arith])
         x.set_mode(1 if args.mode == "fused" else 0)
-        if args.dist_mode == "levels" and world > 1:
-            x.enable_level_parallel(rank, world, dist, torch)
-            jb = ShardedContains(x, 0, 1, None, torch)                   # every rank holds the whole string
-        else:
-            jb = ShardedContains(x, rank, world, dist, torch)
-        jobs.append(jb)
-        shard_sets.append([jb.upload_shard(ck, s, args.chars, m) for s in strings])   # resident before timing
-        x.flush()
-    job, shards = jobs[0], shard_sets[0]
+        dists.append(Dist.from_torch(x, dist, torch, rank, world) if world > 1 else None)
+    wl = Workload(args, ck, sks, dists, rank, world)
+    if wl.op == "replace" and world > 1:
+        for D in dists:
+            D.level_parallel(True)
     step_no = [0]
 
     def step():
         k = step_no[0] % P
         step_no[0] += 1
-        outs = jobs[k].run_batch(shard_sets[k], pattern, op=args.op)   # N > 1: one stream-ordered all-gather
+        outs = wl.step(k)
         sks[k].flush(wait=(P == 1))          # P > 1: enqueue only; sync() below waits for every stream
         return outs
 
@@ -193,21 +377,20 @@ def main():
         tot = {}
         for x in sks:
             for key, v in x.stats(reset=reset).items():
-                tot[key] = max(tot.get(key, 0), v) if key == "max_level_width" else tot.get(key, 0) + v
+                tot[key] = max(tot.get(key, 0), v) if key.startswith("max_") else tot.get(key, 0) + v
         return tot
 
     def all_timing(reset=False):
-        ms = n = units = n4 = ms4 = u4 = 0.0
+        acc = [[0.0, 0.0, 0.0] for _ in range(3)]
         for x in sks:
-            kt = x.ctx.kernel_timing(reset=reset)
-            ms += kt["blind_rotate_ms"] * kt["n_blind_rotate"]
-            n += kt["n_blind_rotate"]
-            units += kt["pbs_in_launches"]
-            ms4 += kt["fft4_ms"] * kt["n_fft4"]
-            n4 += kt["n_fft4"]
-            u4 += kt["pbs_in_fft4"]
-        return {"blind_rotate_ms": ms / max(1, n), "n_blind_rotate": n, "pbs_in_launches": units,
-                "fft4_ms": ms4 / max(1, n4), "n_fft4": n4, "pbs_in_fft4": u4}
+            for kind in range(3):
+                ms, n, u = x.ctx.kernel_timing_kind(kind)
+                acc[kind][0] += ms * n
+                acc[kind][1] += n
+                acc[kind][2] += u
+            if reset:
+                x.ctx.kernel_timing(reset=True)
+        return [{"ms": a[0] / max(1, a[1]), "n": a[1], "pbs": a[2]} for a in acc]
 
     def set_arith(a):
         for x in sks:
@@ -219,41 +402,65 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n_steps):
+        sync()
+        all_stats(reset=True)
+        all_timing(reset=True)
+        t0 = time.perf_counter()
+        outs = None
+        for _ in range(n_steps):
+            outs = step()
+        sync()
+        return time.perf_counter() - t0, outs, all_stats(), all_timing()
+
     for _ in range(args.warmup):
         step()
-    sync()
-    all_stats(reset=True)
-    all_timing(reset=True)
-    t0 = time.perf_counter()
-    outs = None
-    for _ in range(args.steps):
-        outs = step()
-    sync()
-    dt = time.perf_counter() - t0
-    st = all_stats()
-    kt = all_timing()
+    dt, outs, st, kt = timed(args.steps)
+    wl.check(outs)
 
-    # latency of ONE op on one string (same workload, batch of 1), outside the timed region above
-    single_ms = None
-    if args.strings > 1 and not args.skip_single_op:
-        keep = job.run(shards[0], pattern, op=args.op)   # an unreferenced result is dead code: keep it
-        sk.flush()
-        sync()
+    # median of >= 5 repeats of a shorter run (SURVEY 8d timing protocol), outside the contract's timed region
+    rep_ms = []
+    n_rep_steps = max(P, min(args.steps, 2 * P))
+    for _ in range(args.repeats):
+        d, _, _, _ = timed(n_rep_steps)
+        rep_ms.append(d / n_rep_steps * 1e3)
+
+    # one op on one string: latency, level shape, end-to-end (encrypt + upload + op + download + decrypt, like the
+    # reference's own timer src/main.rs:103-114), and the as-written (reference-order) DAG of the same op
+    single = None
+    if rank == 0 and world == 1 and not args.skip_single_op:
+        sk = sks[0]
+        one = Workload(args, ck, [sk], [None], 0, 1, strings=1)
+        keep = one.step(0); sk.flush(); sync()
+        sk.stats(reset=True)
         t1 = time.perf_counter()
         for _ in range(3):
-            keep = job.run(shards[0], pattern, op=args.op)
+            keep = one.step(0)
             sk.flush()
         sync()
+        lat = (time.perf_counter() - t1) / 3 * 1e3
+        widths = sk.level_widths()
+        widths = widths[:len(widths) // 3]
+        t2 = time.perf_counter()
+        e2e = Workload(args, ck, [sk], [None], 0, 1, strings=1)     # encrypts + uploads its inputs
+        e2e.check(e2e.step(0))                                       # runs, downloads, decrypts
+        e2e_ms = (time.perf_counter() - t2) * 1e3
+        single = {"latency_ms": lat, "level_widths": widths, "pbs": int(sum(widths)), "levels": len(widths),
+                  "end_to_end_ms": e2e_ms}
+        if args.op in ("contains", "find_enc") and args.mode == "fused":
+            sk.set_mode(0)
+            sk.stats(reset=True)
+            t3 = time.perf_counter()
+            keep = one.step(0)
+            sk.flush()
+            sync()
+            aw_ms = (time.perf_counter() - t3) * 1e3
+            stw = sk.stats()
+            one.check(keep)
+            sk.set_mode(1)
+            single["as_written"] = {"levels": stw["levels"], "pbs": stw["pbs_executed"], "ms": aw_ms,
+                                    "note": "the reference's own op order (FHS_MODE_AS_WRITTEN), same kernels"}
         del keep
-        single_ms = (time.perf_counter() - t1) / 3 * 1e3
-
-    # correctness of what was timed (decrypt-level, against python str semantics)
-    def check(results):
-        for s, o in zip(strings, results):
-            got = ck.decrypt_char(o)
-            want = int(pattern in s) if args.op == "contains" else (s.find(pattern) if pattern in s else 255)
-            assert got == want, ("bench result mismatch", got, want)
-    check(outs)
 
     # the other arithmetic on the same workload (secondary figure, fewer steps)
     secondary = None
@@ -262,53 +469,77 @@ def main():
         set_arith(other)
         for _ in range(P):
             step()
-        sync()
-        all_stats(reset=True)
-        all_timing(reset=True)
         n2 = max(1, min(args.steps, 2 * P))
-        t2 = time.perf_counter()
-        for _ in range(n2):
-            outs2 = step()
-        sync()
-        dt2 = time.perf_counter() - t2
-        check(outs2)
-        st2, kt2 = all_stats(), all_timing()
-        secondary = {"arithmetic": other, "pbs_local": float(st2["pbs_executed"]), "dt": dt2, "steps": n2,
-                     "blind_rotate_ms": kt2["blind_rotate_ms"]}
+        dt2, outs2, st2, kt2 = timed(n2)
+        wl.check(outs2)
+        secondary = {"arithmetic": other, "pbs_local": float(st2["pbs_executed"]), "dt": dt2, "steps": n2, "kt": kt2}
         set_arith(args.arith)
+
+    # BASELINE configs 3-5 at their fixed sizes, once each over the same ranks (default run only)
+    extras = None
+    if args.op == "contains" and not args.skip_extras and args.mode == "fused":
+        extras = {}
+        for op in ("find_enc", "replace", "eq_ignore_case", "le"):
+            w = Workload(args, ck, sks[:1], dists[:1], rank, world, op=op, chars=FIXED[op], strings=1)
+            lp = op == "replace" and world > 1
+            if lp:
+                dists[0].level_parallel(True)
+            keep = w.step(0); sks[0].flush(); sync()
+            sks[0].stats(reset=True)
+            t0 = time.perf_counter()
+            keep = w.step(0)
+            sks[0].flush()
+            sync()
+            d = time.perf_counter() - t0
+            s2 = sks[0].stats()
+            w.check(keep)
+            if lp:
+                dists[0].level_parallel(False)
+            extras[op] = {"ms_local": d * 1e3, "pbs_local": float(s2["pbs_executed"]), "levels": s2["levels"],
+                          "workload": w.describe(), "parallelism": w.parallelism()}
+            del keep, w
 
     pbs_local = st["pbs_executed"]
     if dist is not None:
-        sec = [secondary["dt"], secondary["pbs_local"]] if secondary else [0.0, 0.0]
-        tt = torch.tensor([dt, float(pbs_local)] + sec, dtype=torch.float64,
-                          device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        tmax = tt.clone()
+        vec = [dt, float(pbs_local)] + ([secondary["dt"], secondary["pbs_local"]] if secondary else [0.0, 0.0])
+        vec += rep_ms + [0.0] * (args.repeats - len(rep_ms))
+        if extras:
+            for op in ("find_enc", "replace", "eq_ignore_case", "le"):
+                vec += [extras[op]["ms_local"], extras[op]["pbs_local"]]
+        tt = torch.tensor(vec, dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        tmax, tsum = tt.clone(), tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        dt = float(tmax[0])
-        pbs_total = float(tt[1])
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, pbs_total = float(tmax[0]), float(tsum[1])
         if secondary:
-            secondary["dt"], secondary["pbs_total"] = float(tmax[2]), float(tt[3])
+            secondary["dt"], secondary["pbs_total"] = float(tmax[2]), float(tsum[3])
+        rep_ms = [float(x) for x in tmax[4:4 + args.repeats]]
+        if extras:
+            base = 4 + args.repeats
+            for i, op in enumerate(("find_enc", "replace", "eq_ignore_case", "le")):
+                extras[op]["ms"], extras[op]["pbs"] = float(tmax[base + 2 * i]), float(tsum[base + 2 * i + 1])
     else:
         pbs_total = float(pbs_local)
         if secondary:
             secondary["pbs_total"] = secondary["pbs_local"]
+        if extras:
+            for e in extras.values():
+                e["ms"], e["pbs"] = e["ms_local"], e["pbs_local"]
 
     if rank == 0:
-        n_br = max(1, kt["n_blind_rotate"])
-        br_ms = kt["blind_rotate_ms"]                      # average launch duration (HIP events)
-        pbs_per_launch = kt["pbs_in_launches"] / n_br
-        achieved = pbs_per_launch * ALGO_BYTES_PER_PBS / (br_ms * 1e-3) / 1e9 if br_ms > 0 else 0.0
+        counters = load_counters()
+        traffic = {}
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        except Exception:
+            pass
+        wide, narrow = kt[0], kt[2]
         kernel = "blind_rotate_fft_kernel" if args.arith == "fft" else "blind_rotate_kernel"
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(kernel + "_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        if wide["n"] == 0 and narrow["n"]:          # every level ran on the narrow-level kernel
+            wide, kernel = narrow, "blind_rotate_fft4_kernel"
+        ppl = wide["pbs"] / max(1, wide["n"])
         line = {
-            "metric": "PBS/sec and ms/op for contains() on N-char FheString",
+            "metric": "PBS/sec and ms/op for %s() on N-char FheString" % ("contains" if args.op == "contains" else args.op),
             "value": pbs_total / dt,
             "unit": "PBS/s",
             "n_gpus": world,
@@ -316,62 +547,64 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": wl.scaling,
             "vs_baseline": None,
             "dtype": "f64" if args.arith == "fft" else "u64",
             "data": "synthetic",
-            "config": {"workload": "%s_clear, %d-char FheString per GPU (+1 NUL pad), clear pattern m=%d, "
-                                   "%d string(s)/step, %s DAG, %s arithmetic"
-                                   % (args.op, args.chars, m, args.strings, args.mode,
-                                      "f64-FFT" if args.arith == "fft" else "exact-NTT"),
-                       "pipelines": P,
-                       "parallelism": ("windows sharded over %d GPU(s), 1 all-gather" % world)
-                       if args.dist_mode == "windows" else
-                       ("every PBS level split over %d GPU(s), 1 all-gather per level" % world)},
-            "ms_per_op": dt / args.steps / args.strings * 1e3,
-            "single_op_latency_ms": single_ms if single_ms is not None else dt / args.steps * 1e3,
-            "pbs_per_op": pbs_total / args.steps / args.strings,
+            "config": {"workload": "%s, %s DAG, %s arithmetic" % (wl.describe(), args.mode,
+                                                                   "f64-FFT" if args.arith == "fft" else "exact-NTT"),
+                       "pipelines": P, "parallelism": wl.parallelism()},
+            "ms_per_op": dt / args.steps / wl.n_strings * 1e3,
+            "median_ms_per_step": statistics.median(rep_ms) if rep_ms else None,
+            "repeat_ms_per_step": rep_ms,
+            "repeat_steps": n_rep_steps,
+            "pbs_per_op": pbs_total / args.steps / wl.n_strings,
             "levels_per_op": st["levels"] / args.steps,
             "max_level_width": st["max_level_width"],
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "compulsory_bytes_per_launch": 109_494_272 + pbs_per_launch * 65_552,   # one key
-                         "kernel": kernel, "avg_launch_ms": br_ms,                               # sweep shared by B PBS
-                         "launches": n_br,
-                         "avg_pbs_per_launch": pbs_per_launch,
-                         "note": "algorithmic bytes 109559824 B/PBS x PBS per launch / HIP-event launch time; a batch "
-                                 "shares one key stream out of L2/Infinity Cache, so this figure can exceed the HBM peak "
-                                 "(traffic = measured fabric-side bytes per launch); the kernel is FP64-VALU-bound "
-                                 "(fp64_valu, DESIGN.md section 4)"},
-            "parity": "GPU bit-exact vs own CPU oracle in both arithmetics (exact NTT vs oracle mode 0, f64 FFT vs its "
-                      "lane-for-lane mirror, oracle mode 3); decrypt-exact vs reference test vectors; "
-                      "ciphertext-level parity with tfhe-rs unpinned",
+            "max_input_sum_c2": st.get("max_input_sum_c2"),
+            "roofline": roofline_for(kernel, ppl, wide["ms"], wide["n"], counters,
+                                     traffic.get(kernel + "_hbm_bytes_per_launch")),
+            "parity": "GPU bit-exact vs own CPU oracle in both arithmetics at the widths run here (exact NTT vs oracle "
+                      "mode 0; f64 FFT vs its lane-for-lane C mirror, oracle mode 3, which shows determinism and "
+                      "agreement with its twin, the independent anchors being decrypt-level and phase within 2^52 of the "
+                      "exact path); decrypt-exact vs the reference's test vectors; ciphertext-level parity with tfhe-rs unpinned",
         }
-        if kt["n_fft4"]:
+        if single:
+            line["single_op_latency_ms"] = single["latency_ms"]
+            line["single_op"] = single
+            line["end_to_end_ms"] = single["end_to_end_ms"]
+        else:
+            line["single_op_latency_ms"] = dt / args.steps * 1e3
+        if narrow["n"] and kernel != "blind_rotate_fft4_kernel":
             line["roofline"]["narrow_levels"] = {
-                "kernel": "blind_rotate_fft4_kernel", "launches": kt["n_fft4"], "avg_launch_ms": kt["fft4_ms"],
-                "avg_pbs_per_launch": kt["pbs_in_fft4"] / kt["n_fft4"],
+                "kernel": "blind_rotate_fft4_kernel", "launches": narrow["n"], "avg_launch_ms": narrow["ms"],
+                "avg_pbs_per_launch": narrow["pbs"] / narrow["n"],
                 "note": "dependency levels of <= 512 ciphertexts run on the 4-wavefront kernel (latency, not "
                         "throughput); not part of the figures above"}
-        if args.arith == "fft" and br_ms > 0:
-            tf = pbs_per_launch * FFT_FLOP_PER_PBS / (br_ms * 1e-3) / 1e12
-            line["roofline"]["fp64_valu"] = {
-                "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
-                "note": "the resource that actually binds: %d FP64 flop per PBS (static count of the kernel's loop; "
-                        "56 %% of its FP64 instructions are FMAs, so back-to-back FP64 issue would read 0.78 here and the "
-                        "460 integer/conversion instructions per iteration lower that further; with several pipelines "
-                        "the launch durations include time shared with other launches)" % FFT_FLOP_PER_PBS}
         if secondary:
+            k2 = secondary["kt"]
+            okern = "blind_rotate_kernel" if secondary["arithmetic"] == "exact" else "blind_rotate_fft_kernel"
             line["other_arithmetic"] = {
                 "arithmetic": "exact-NTT (u64, library default)" if secondary["arithmetic"] == "exact" else "f64-FFT",
                 "value": secondary["pbs_total"] / secondary["dt"], "unit": "PBS/s", "steps": secondary["steps"],
                 "ms_per_step": secondary["dt"] / secondary["steps"] * 1e3,
-                "avg_blind_rotate_launch_ms": secondary["blind_rotate_ms"]}
+                "roofline": roofline_for(okern, k2[0]["pbs"] / max(1, k2[0]["n"]), k2[0]["ms"], k2[0]["n"], counters,
+                                         traffic.get(okern + "_hbm_bytes_per_launch"))}
+        if extras:
+            line["configs"] = {}
+            names = {"find_enc": "cfg3_find_encrypted_256", "replace": "cfg4_replace_1024",
+                     "eq_ignore_case": "cfg5_eq_ignore_case_4096", "le": "cfg5_le_4096"}
+            for op, e in extras.items():
+                line["configs"][names[op]] = {"ms_per_op": e["ms"], "pbs": e["pbs"], "levels": e["levels"],
+                                              "pbs_per_s": e["pbs"] / (e["ms"] * 1e-3), "scaling": "strong",
+                                              "workload": e["workload"], "parallelism": e["parallelism"]}
         if args.cpu_pbs != 0:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_pbs)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_pbs, single["level_widths"] if single else None)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
+        for D in dists:
+            D.shutdown()
         dist.destroy_process_group()
     for x in sks:
         x.close()

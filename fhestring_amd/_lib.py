@@ -37,6 +37,8 @@ def _declare(L):
     vp, sz, i, u64, u8 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.c_uint8
     L.fhs_ctx_create.argtypes = [i, C.POINTER(vp)]
     L.fhs_ctx_create.restype = i
+    L.fhs_ctx_create_planner.argtypes = [C.POINTER(vp)]
+    L.fhs_ctx_create_planner.restype = i
     L.fhs_ctx_destroy.argtypes = [vp]
     L.fhs_ctx_destroy.restype = None
     L.fhs_last_error.argtypes = [vp]
@@ -193,6 +195,8 @@ def _declare(L):
     L.fhs_debug_capture_pbs_inputs.restype = i
     L.fhs_debug_capture_read.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.fhs_debug_capture_read.restype = i
+    L.fhs_level_widths.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.fhs_level_widths.restype = i
     L.fhs_get_stats.argtypes = [vp, vp]
     L.fhs_get_stats.restype = i
     L.fhs_reset_stats.argtypes = [vp]

@@ -18,10 +18,13 @@ class Context:
     """fhs_ctx: one per GPU.  Replaces the tfhe::integer::ServerKey held by
     MyServerKey (src/server_key/mod.rs:13-16)."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, planner=False):
         self._L = lib()
         h = C.c_void_p()
-        rc = self._L.fhs_ctx_create(int(device_id), C.byref(h))
+        if planner:        # fhs_ctx_create_planner: records and levelises DAGs (statistics only), computes nothing
+            rc = self._L.fhs_ctx_create_planner(C.byref(h))
+        else:
+            rc = self._L.fhs_ctx_create(int(device_id), C.byref(h))
         self._h = h
         if rc != 0:
             msg = self._L.fhs_last_error(h).decode() if h else "allocation failed"
@@ -347,6 +350,16 @@ class MyServerKey:
         return cls(ctx)
 
     @classmethod
+    def planner(cls):
+        """Planner context (no GPU): DAG statistics of any op -- PBS count, levels, level widths, noise bookkeeping."""
+        return cls(Context(planner=True))
+
+    def dummy_string(self, n):
+        """n placeholder chars for a planner context (contents are never read)."""
+        z = np.zeros((4, BIG_CT), np.uint64)
+        return FheString([self.upload_char(z) for _ in range(n)])
+
+    @classmethod
     def from_key_file(cls, path, device_id=0, arith=0):
         ctx = Context(device_id)
         ctx.set_arithmetic(arith)
@@ -443,6 +456,14 @@ class MyServerKey:
         dt = np.dtype([("level", "u4"), ("index", "u4"), ("lut", "u4"), ("n_terms", "u4"), ("sum_c2", "i8"),
                        ("konst", "i4"), ("width", "u4")])
         return rows[:got.value], np.frombuffer(recs, dtype=dt, count=got.value).copy()
+
+    def level_widths(self):
+        """Widths of the dependency levels executed since the last stats reset (fhs_level_widths)."""
+        n = C.c_size_t()
+        self.ctx._check(self.ctx._L.fhs_level_widths(self.ctx._h, None, 0, C.byref(n)))
+        out = np.zeros(max(1, n.value), np.uint32)
+        self.ctx._check(self.ctx._L.fhs_level_widths(self.ctx._h, _ptr(out), n.value, C.byref(n)))
+        return out[:n.value].tolist()
 
     def stats(self, reset=False):
         from ._lib import Stats

@@ -21,6 +21,15 @@ int fhs_ctx_create(int device_id, fhs_ctx **out) {
     return FHS_OK;
 }
 
+int fhs_ctx_create_planner(fhs_ctx **out) {
+    if (!out) return FHS_ERR_ARG;
+    fhs_ctx *c = new (std::nothrow) fhs_ctx();
+    if (!c) return FHS_ERR_STATE;
+    c->eng.planner = true;
+    *out = c;
+    return FHS_OK;
+}
+
 void fhs_ctx_destroy(fhs_ctx *ctx) {
     if (!ctx) return;
     ctx->eng.shutdown();

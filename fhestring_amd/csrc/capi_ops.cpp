@@ -65,7 +65,7 @@ fhs_char_t fhs_trivial(fhs_ctx *c, uint8_t v) {
 }
 fhs_char_t fhs_upload(fhs_ctx *c, const uint64_t *blocks) {
     if (!c || !blocks) { bad(c); return 0; }
-    if (hipSetDevice(c->eng.ctx.device) != hipSuccess) { c->eng.ctx.fail(FHS_ERR_HIP, "hipSetDevice failed"); return 0; }
+    if (!c->eng.planner && hipSetDevice(c->eng.ctx.device) != hipSuccess) { c->eng.ctx.fail(FHS_ERR_HIP, "hipSetDevice failed"); return 0; }
     Bid b[4] = {0, 0, 0, 0};
     for (int i = 0; i < 4; i++) {
         b[i] = c->eng.from_host(blocks + (size_t)i * FHS_BIG_CT);
@@ -123,6 +123,7 @@ int fhs_flush(fhs_ctx *c) {
     if (!c) return FHS_ERR_ARG;
     int rc = c->eng.flush();
     if (rc) return rc;
+    if (c->eng.planner) return FHS_OK;
     if (hipStreamSynchronize(c->eng.ctx.stream) != hipSuccess) return c->eng.ctx.fail(FHS_ERR_HIP, "stream sync failed");
     return FHS_OK;
 }
@@ -391,6 +392,7 @@ int fhs_flush_level_commit(fhs_ctx *c, uint64_t level, const uint64_t *d_all) {
 }
 int fhs_stream_sync(fhs_ctx *c) {
     if (!c) return FHS_ERR_ARG;
+    if (c->eng.planner) return FHS_OK;
     if (hipStreamSynchronize(c->eng.ctx.stream) != hipSuccess) return c->eng.ctx.fail(FHS_ERR_HIP, "stream sync failed");
     return FHS_OK;
 }
@@ -403,6 +405,13 @@ int fhs_get_stats(fhs_ctx *c, fhs_stats *out) {
     out->max_level_width = c->eng.stats.max_level_width;
     out->blocks_live = c->eng.blocks_live();
     out->max_input_sum_c2 = c->eng.stats.max_input_sum_c2;
+    return FHS_OK;
+}
+int fhs_level_widths(fhs_ctx *c, uint32_t *out, size_t cap, size_t *n) {
+    if (!c || !n) return bad(c);
+    const auto &w = c->eng.stats.level_widths;
+    *n = w.size();
+    if (out) std::copy(w.begin(), w.begin() + std::min(cap, w.size()), out);
     return FHS_OK;
 }
 int fhs_reset_stats(fhs_ctx *c) {

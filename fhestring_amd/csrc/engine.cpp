@@ -24,6 +24,7 @@ int Engine::on_key_loaded() {
 }
 
 void Engine::shutdown() {
+    if (planner) return;
     if (ctx.stream) (void)hipStreamSynchronize(ctx.stream);
     for (void *c : chunks_) (void)hipFree(c);
     chunks_.clear();
@@ -36,6 +37,10 @@ void Engine::shutdown() {
 }
 
 uint64_t *Engine::alloc_block() {
+    if (planner) {                                   // distinct non-null tokens, never dereferenced
+        live_dev_blocks_++;
+        return reinterpret_cast<uint64_t *>((uintptr_t)0x1000 + 8 * (uintptr_t)(++planner_tokens_));
+    }
     if (free_blocks_.empty()) {
         void *c = nullptr;
         if (hipMalloc(&c, POOL_CHUNK_BLOCKS * POOL_STRIDE * 8) != hipSuccess) return nullptr;
@@ -49,7 +54,7 @@ uint64_t *Engine::alloc_block() {
     return p;
 }
 void Engine::free_block(uint64_t *p) {
-    free_blocks_.push_back(p);
+    if (!planner) free_blocks_.push_back(p);
     live_dev_blocks_--;
 }
 
@@ -99,10 +104,10 @@ Bid Engine::triv(int v) {
 }
 
 Bid Engine::from_host(const uint64_t *ct) {
-    (void)hipSetDevice(ctx.device);   // one process may see several GPUs (torch sets its own current device)
+    if (!planner) (void)hipSetDevice(ctx.device);   // one process may see several GPUs (torch sets its own current device)
     uint64_t *d = alloc_block();
     if (!d) return 0;
-    if (hipMemcpyAsync(d, ct, BIG_CT * 8, hipMemcpyHostToDevice, ctx.stream) != hipSuccess) {
+    if (!planner && hipMemcpyAsync(d, ct, BIG_CT * 8, hipMemcpyHostToDevice, ctx.stream) != hipSuccess) {
         free_block(d);
         return 0;
     }
@@ -113,10 +118,10 @@ Bid Engine::from_host(const uint64_t *ct) {
 }
 
 Bid Engine::from_device(const uint64_t *d_ct) {
-    (void)hipSetDevice(ctx.device);
+    if (!planner) (void)hipSetDevice(ctx.device);
     uint64_t *d = alloc_block();
     if (!d) return 0;
-    if (hipMemcpyAsync(d, d_ct, BIG_CT * 8, hipMemcpyDeviceToDevice, ctx.stream) != hipSuccess) {
+    if (!planner && hipMemcpyAsync(d, d_ct, BIG_CT * 8, hipMemcpyDeviceToDevice, ctx.stream) != hipSuccess) {
         free_block(d);
         return 0;
     }
@@ -165,6 +170,15 @@ Bid Engine::lin(const Term *terms, size_t n, int konst) {
     nn.level = lvl;
     nn.terms = std::move(flat);
     return id;
+}
+
+int64_t Engine::sum_c2(Bid b) const {
+    const BlockNode &n = nodes_[b];
+    if (n.kind == BlockNode::TRIV) return 0;
+    if (n.kind != BlockNode::LIN) return 1;
+    int64_t c2 = 0;
+    for (const Term &t : n.terms) c2 += t.coef * t.coef;
+    return c2;
 }
 
 Bid Engine::pbs(Bid x, int lut) {
@@ -263,8 +277,10 @@ int Engine::plan_flush() {
     plan_.levels.clear();
     plan_.recs.clear();
     if (pending_.empty()) return 0;
-    if (!ctx.key_loaded) return ctx.fail(-3, "server key not loaded");
-    if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
+    if (!planner) {
+        if (!ctx.key_loaded) return ctx.fail(-3, "server key not loaded");
+        if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
+    }
 
     std::map<uint32_t, std::vector<Bid>> by_level;
     for (Bid b : pending_)
@@ -334,6 +350,8 @@ int Engine::plan_flush() {
         max_width = std::max(max_width, lv.size());
     }
 
+    plan_.max_width = max_width;
+    if (planner) return 0;                           // nothing to upload: the plan only feeds the statistics
     // one upload: [descs | terms | lut_idx | out_ptrs]
     const size_t off_desc = 0;
     const size_t off_terms = off_desc + descs.size() * sizeof(LinDesc);
@@ -379,6 +397,15 @@ int Engine::exec_level(size_t k, size_t lo, size_t hi, uint64_t *dense_out) {
     if (lo > hi || hi > lp.count) return ctx.fail(-1, "slice out of range");
     const size_t cnt = hi - lo;
     if (cnt == 0) return 0;
+    if (planner) {
+        stats.pbs_executed += cnt;
+        if (lo == 0 || dense_out) {
+            stats.levels += 1;
+            if (stats.level_widths.size() < (1u << 20)) stats.level_widths.push_back((uint32_t)lp.count);
+            stats.max_level_width = std::max<uint64_t>(stats.max_level_width, lp.count);
+        }
+        return 0;
+    }
     if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
     const uint8_t *dp = plan_buf_.as<uint8_t>();
     const LinDesc *d_desc = reinterpret_cast<const LinDesc *>(dp + plan_.off_desc) + lp.first + lo;
@@ -407,6 +434,7 @@ int Engine::exec_level(size_t k, size_t lo, size_t hi, uint64_t *dense_out) {
     stats.pbs_executed += cnt;
     if (lo == 0 || dense_out) {
         stats.levels += 1;
+        if (stats.level_widths.size() < (1u << 20)) stats.level_widths.push_back((uint32_t)lp.count);
         stats.max_level_width = std::max<uint64_t>(stats.max_level_width, lp.count);
     }
     return 0;
@@ -416,6 +444,10 @@ int Engine::exec_level(size_t k, size_t lo, size_t hi, uint64_t *dense_out) {
 int Engine::commit_level(size_t k, const uint64_t *d_all) {
     if (k >= plan_.levels.size()) return ctx.fail(-1, "level index out of range");
     const LevelPlan &lp = plan_.levels[k];
+    if (planner) {
+        if (k + 1 == plan_.levels.size()) plan_.levels.clear();
+        return 0;
+    }
     if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
     uint64_t *const *d_out =
         reinterpret_cast<uint64_t *const *>(plan_buf_.as<uint8_t>() + plan_.off_out) + lp.first;
@@ -428,6 +460,7 @@ int Engine::commit_level(size_t k, const uint64_t *d_all) {
 int Engine::materialize_lin(Bid b) {
     BlockNode &n = nodes_[b];
     if (n.kind != BlockNode::LIN) return 0;
+    if (planner) return ctx.fail(-3, "planner context: nothing is computed");
     std::vector<LinTerm> terms;
     for (const Term &t : n.terms) {
         const BlockNode &tb = nodes_[t.blk];
@@ -459,6 +492,7 @@ int Engine::materialize_lin(Bid b) {
 }
 
 int Engine::read_block(Bid b, uint64_t *host_out) {
+    if (planner) return ctx.fail(-3, "planner context: nothing is computed, there is nothing to download");
     (void)hipSetDevice(ctx.device);
     int rc = flush();
     if (rc) return rc;
@@ -476,6 +510,7 @@ int Engine::read_block(Bid b, uint64_t *host_out) {
 }
 
 int Engine::copy_block_to_device(Bid b, uint64_t *d_out, bool wait) {
+    if (planner) return ctx.fail(-3, "planner context: nothing is computed");
     (void)hipSetDevice(ctx.device);
     int rc = flush();
     if (rc) return rc;

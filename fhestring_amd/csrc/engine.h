@@ -38,6 +38,7 @@ struct BlockNode {
 struct EngineStats {
     uint64_t pbs_executed = 0, pbs_folded = 0, levels = 0, max_level_width = 0;
     uint64_t max_input_sum_c2 = 0;   // largest sum of squared coefficients of any executed bootstrap's input
+    std::vector<uint32_t> level_widths;   // width of every dependency level executed since the last reset (capped)
 };
 
 class Engine {
@@ -45,6 +46,9 @@ class Engine {
     Context ctx;
     EngineStats stats;
     int mode = 0;   // 0 as written, 1 fused (string layer)
+    // Planner context (fhs_ctx_create_planner): records DAGs, levelises them and keeps the statistics (PBS count, level
+    // widths, noise bookkeeping) but owns no device and executes nothing; downloads fail.  Host logic only.
+    bool planner = false;
 
     int on_key_loaded();
     void shutdown();
@@ -60,6 +64,9 @@ class Engine {
     const BlockNode &node(Bid b) const { return nodes_[b]; }
     bool is_triv(Bid b) const { return nodes_[b].kind == BlockNode::TRIV; }
     int triv_val(Bid b) const { return nodes_[b].triv; }
+    // sum of squared coefficients of a block as a combination of bootstrap outputs / uploads (its noise variance in
+    // units of one bootstrap output's): 0 trivial, 1 materialised or pending bootstrap, sum c^2 for a linear combination
+    int64_t sum_c2(Bid b) const;
 
     int flush();
     // Level-parallel execution INSIDE the library (fhs_dist_level_parallel): every rank holds the same ciphertexts and
@@ -109,6 +116,7 @@ class Engine {
     std::vector<void *> chunks_;
     std::vector<uint64_t *> free_blocks_;
     uint64_t live_dev_blocks_ = 0;
+    uint64_t planner_tokens_ = 0;
     uint64_t *alloc_block();
     void free_block(uint64_t *p);
 

@@ -988,8 +988,12 @@ FStr Strings::f_trim(const FStr &s, bool from_end) {
 }
 
 // cond ? t : f with cond a clean single-block 0/1 flag (no scalar_ne needed)
-FChar Strings::ite_flag(const Ref &flag, const FChar &tv, const FChar &fv) {
+FChar Strings::ite_flag(const Ref &flag_in, const FChar &tv, const FChar &fv) {
     FChar r;
+    // the flag enters with weight 4: a flag that is itself a sum of several bootstrap outputs (one-hot cover sums,
+    // 1 - x forms) is refreshed first when 16 x its sum c^2 would leave the noise budget
+    Ref flag = flag_in;
+    if (16 * e_->sum_c2(flag.id()) + 4 > FHS_NOISE_BUDGET_SUM_C2) flag = pbs(flag_in, LUT_NZ);
     for (int i = 0; i < 4; i++) {
         Ref a = pbs(lin(e_, {{4, &flag}, {1, &tv.b[i]}}), LUT_SEL_T);
         Ref b = pbs(lin(e_, {{4, &flag}, {1, &fv.b[i]}}), LUT_SEL_F);

@@ -51,6 +51,11 @@ typedef uint64_t fhs_char_t;     /* opaque handle of one lazily evaluated FheAsc
 /* ---- context / server key -------------------------------------------------
  * replaces: tfhe::integer::ServerKey held by MyServerKey (src/server_key/mod.rs:13-16) */
 int fhs_ctx_create(int device_id, fhs_ctx **out);
+/* Planner context: no device, no key.  Every fhs_* op records its DAG exactly as on a real context and fhs_flush
+ * levelises it, so the statistics (PBS count, dependency levels and their widths, noise bookkeeping) are those of the
+ * real run -- but NOTHING is computed: fhs_download / exports / raw PBS entry points fail with FHS_ERR_STATE.  Host logic
+ * only (capacity planning, the CPU test-suite's checks of DAG shape and noise budget); not a CPU fallback. */
+int fhs_ctx_create_planner(fhs_ctx **out);
 void fhs_ctx_destroy(fhs_ctx *ctx);
 const char *fhs_last_error(const fhs_ctx *ctx);
 /* Copies the key to the device; the BSK is rounded to the 58-bit torus grid and
@@ -279,6 +284,10 @@ typedef struct {
  * set's 2^-40 failure probability is kept (tests/test_gpu_noise.py measures it). */
 #define FHS_NOISE_BUDGET_SUM_C2 64
 int fhs_get_stats(fhs_ctx *ctx, fhs_stats *out);
+/* Width (PBS count) of every dependency level executed since the last fhs_reset_stats, in execution order (the shape
+ * of the levelized batches: what a CPU baseline has to run to do the same work).  *n = number of levels; out may be
+ * NULL to query it. */
+int fhs_level_widths(fhs_ctx *ctx, uint32_t *out, size_t cap, size_t *n);
 int fhs_reset_stats(fhs_ctx *ctx);
 
 /* ---- client side (MyClientKey, src/client_key.rs) -- host CPU, like the reference -- */

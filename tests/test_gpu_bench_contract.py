@@ -10,13 +10,28 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_json_line_contract():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-pbs", "32"],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
+def _run(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", *extra],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def _check_roofline(r):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm", "counters"):
+        assert k in r, k
+    # the bounding resource is the FP64 vector unit (SQ counters, profiles/r02_*): a fraction of a peak, never above 1
+    assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["counters"]["fp64_flop_per_pbs"] > 1e8          # measured flop count, not a static estimate
+    h = r["hbm"]
+    assert h["compulsory_frac_of_peak"] < 0.05 and "NOT the bound" in h["note"]
+
+
+def test_bench_json_line_contract():
+    d = _run("--cpu-pbs", "32", "--repeats", "5")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -24,12 +39,27 @@ def test_bench_json_line_contract():
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 10_000 and d["ms_per_step"] > 0
-    r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    _check_roofline(d["roofline"])
+    _check_roofline(d["other_arithmetic"]["roofline"])       # the exact-NTT arithmetic has its own roofline object
+    assert d["other_arithmetic"]["value"] > 5_000
     c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    for k in ("value", "unit", "cores", "kind", "sample", "config1_eq_hello_hello", "same_levelized_batches"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
-    assert d["other_arithmetic"]["value"] > 5_000           # the exact-NTT arithmetic timed in the same run
+    assert c["config1_eq_hello_hello"]["ms"] > 0 and c["config1_eq_hello_hello"]["pbs"] > 100
+    # SURVEY 8(d) timing protocol
+    assert len(d["repeat_ms_per_step"]) == 5 and d["median_ms_per_step"] > 0
+    assert d["end_to_end_ms"] > d["single_op_latency_ms"] > 0
+    aw = d["single_op"]["as_written"]
+    assert aw["levels"] > 4 * d["single_op"]["levels"] and aw["pbs"] > d["single_op"]["pbs"]
+    assert d["max_input_sum_c2"] <= 64
+    # BASELINE configs 3-5 at their fixed sizes in the same run
+    for k in ("cfg3_find_encrypted_256", "cfg4_replace_1024", "cfg5_eq_ignore_case_4096", "cfg5_le_4096"):
+        assert d["configs"][k]["ms_per_op"] > 0 and d["configs"][k]["pbs"] > 1000
+
+
+@pytest.mark.parametrize("op", ["find_enc", "eq_ignore_case"])
+def test_bench_other_ops(op):
+    d = _run("--op", op, "--cpu-pbs", "0", "--skip-secondary", "--repeats", "0", "--skip-single-op")
+    assert d["scaling"] == "strong" and d["value"] > 5_000
+    assert op.split("_")[0] in d["config"]["workload"]

@@ -1,0 +1,88 @@
+"""DAG shape and noise budget of every string op, on CPU, through a planner context (fhs_ctx_create_planner: the
+product's own DAG construction and levelisation, nothing computed, no GPU).
+
+* every golden vector of the reference's test-suite (tests/golden/ref_tests.json, from src/main.rs:138-1153), in both
+  modes: no bootstrap input is a linear combination with sum c^2 above FHS_NOISE_BUDGET_SUM_C2 (the design rule whose
+  effect tests/test_gpu_noise.py measures on the GPU);
+* BASELINE configs 2-5 at full size: PBS counts and dependency depth of the fused DAGs (and of the as-written ones where
+  they are small enough to record), against SURVEY.md Appendix C's model of the reference."""
+import pytest
+
+from golden_util import SPLIT_OPS, load_vectors, run_vector
+
+VECTORS = load_vectors()
+BUDGET = 64
+SLOW_AS_WRITTEN = {"replace2", "replacen", "repeat", "split_ascii_whitespace"}     # O(n^2) bubbles: millions of nodes
+
+
+@pytest.fixture()
+def sk():
+    from fhestring_amd.api import MyServerKey
+    k = MyServerKey.planner()
+    yield k
+    k.close()
+
+
+def _env(sk):
+    sk.trivial_char = sk.trivial
+    enc_s = lambda t, pad: sk.dummy_string(len(t) + pad)
+    enc_p = lambda t: sk.dummy_string(len(t))
+    enc_c = lambda v: sk.dummy_string(1)[0]
+    dec_s = lambda s: None
+    dec_c = lambda c: None
+    return sk, enc_s, enc_p, enc_c, dec_s, dec_c
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["as_written", "fused"])
+@pytest.mark.parametrize("v", VECTORS, ids=[v["name"] for v in VECTORS])
+def test_noise_budget_of_every_golden_op(sk, v, mode):
+    if "expected_panic" in v:
+        pytest.skip("the reference panics here")
+    if mode == 0 and (v["name"] in SLOW_AS_WRITTEN or v["op"] in SPLIT_OPS):
+        pytest.skip("as-written O(n^2)/O(n^3) DAG: covered on the GPU")
+    sk.set_mode(mode)
+    sk.stats(reset=True)
+    run_vector(v, *_env(sk))
+    sk.flush()
+    st = sk.stats()
+    assert st["max_input_sum_c2"] <= BUDGET, (v["name"], st)
+
+
+def test_config_dag_shapes(sk):
+    """Fused DAGs of BASELINE configs 2-5 at full size, and the as-written cfg 2 / cfg 3 DAGs, which reproduce the
+    reference's cost model (2 480 PBS / 68 levels; 12 954 PBS / 1 022 levels)."""
+    sk.set_mode(1)
+    def run(fn):
+        sk.stats(reset=True)
+        keep = fn()
+        sk.flush()
+        st = sk.stats()
+        assert st["max_input_sum_c2"] <= BUDGET, st
+        return st, sk.level_widths()
+    s65, s257, p4 = sk.dummy_string(65), sk.dummy_string(257), sk.dummy_string(4)
+    st, w = run(lambda: sk.contains_clear(s65, "abcd"))
+    assert (st["pbs_executed"], st["levels"]) == (564, 4) and w == [496, 62, 5, 1]
+    st, w = run(lambda: sk.find(s257, p4))
+    assert st["pbs_executed"] < 3200 and st["levels"] <= 12
+    s1025, f5, t5 = sk.dummy_string(1025), sk.dummy_string(5), sk.dummy_string(5)
+    st, w = run(lambda: sk.replace(s1025, f5, t5))
+    assert st["pbs_executed"] < 400_000 and st["levels"] < 60      # as written: 36.9 M PBS, 16 413 levels
+    a, b = sk.dummy_string(4097), sk.dummy_string(4097)
+    st, w = run(lambda: sk.eq_ignore_case(a, b))
+    assert st["pbs_executed"] < 90_000 and st["levels"] < 30       # as written: 418 k + 258 k PBS, 16 396 levels
+    st, w = run(lambda: sk.le(a, b))
+    assert st["pbs_executed"] < 70_000 and st["levels"] < 30       # as written: 344 k PBS, 24 591 levels
+    sk.set_mode(0)
+    st, w = run(lambda: sk.contains_clear(s65, "abcd"))
+    assert st["pbs_executed"] + st["pbs_folded"] == 2480 and st["levels"] == 68
+    st, w = run(lambda: sk.find(s257, p4))
+    # 254 sequential ite steps after the match phase; the product's if_then_else is 11 PBS / depth 3 and flag PBS on
+    # trivial blocks fold (the survey's model of tfhe's: 15 PBS / depth 4 -> 12 954 PBS, 1 022 levels)
+    assert st["levels"] > 250 and 11_000 < st["pbs_executed"] + st["pbs_folded"] < 14_000
+
+
+def test_planner_computes_nothing(sk):
+    import fhestring_amd
+    c = sk.dummy_string(1)[0]
+    with pytest.raises(fhestring_amd.FhsError, match="planner"):
+        c.eq(c).download()

@@ -1,0 +1,84 @@
+"""rocprofv3 --pmc outputs (rocpd .db or *_counter_collection.csv) -> per-kernel summary JSON for bench.py's roofline.
+
+    python tools/pmc_to_json.py OUT.json DIR [DIR ...]        (each DIR = one rocprofv3 -d output of the SAME command)
+
+Per kernel: dispatches, average duration, and counters averaged per dispatch; derived figures per PBS assume the PBS
+count of the wide launch given by --pbs (default 3968 = the bench's 8 x 64-char contains level)."""
+import csv
+import glob
+import json
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def rows(d):
+    for f in glob.glob(d + "/**/*.db", recursive=True):
+        con = sqlite3.connect(f)
+        for name, cname, val, disp, dur in con.execute(
+                "select kernel_name, counter_name, value, dispatch_id, duration from counters_collection"):
+            yield name.split("(")[0], cname, float(val), (f, disp), float(dur or 0)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            dur = float(r.get("End_Timestamp", 0) or 0) - float(r.get("Start_Timestamp", 0) or 0)
+            yield r["Kernel_Name"].split("(")[0], r["Counter_Name"], float(r["Counter_Value"]), (f, r["Dispatch_Id"]), dur
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    pbs = 3968
+    for a in sys.argv[1:]:
+        if a.startswith("--pbs="):
+            pbs = int(a.split("=")[1])
+    out_path, dirs = args[0], args[1:]
+    tot = defaultdict(float)
+    disp = defaultdict(set)
+    dur = {}
+    for d in dirs:
+        for k, c, v, did, t in rows(d):
+            if not k.startswith("fhs::"):
+                continue
+            tot[(k, c)] += v
+            disp[(k, c)].add(did)
+            dur[(k, did)] = t
+    kernels = sorted({k for k, _ in tot})
+    res = {}
+    for k in kernels:
+        short = k.replace("fhs::", "")
+        c = {cn: tot[(kk, cn)] / len(disp[(kk, cn)]) for (kk, cn) in tot if kk == k}
+        durs = [t for (kk, _), t in dur.items() if kk == k and t > 0]
+        e = {"dispatches": max(len(v) for (kk, _), v in disp.items() if kk == k),
+             "avg_duration_ms": (sum(durs) / len(durs) / 1e6) if durs else None,
+             "per_dispatch": c}
+        if "blind_rotate" in short and "fft4" not in short:
+            n = pbs
+            fma, add, mul = c.get("SQ_INSTS_VALU_FMA_F64"), c.get("SQ_INSTS_VALU_ADD_F64"), c.get("SQ_INSTS_VALU_MUL_F64")
+            if fma is not None and add is not None and mul is not None:
+                e["fp64_flop_per_pbs"] = (2 * fma + add + mul) * 64 / n          # wave instructions x 64 lanes
+                e["fp64_insts_per_pbs"] = (fma + add + mul) / n
+            if "SQ_INSTS_VALU" in c:
+                e["valu_insts_per_pbs"] = c["SQ_INSTS_VALU"] / n
+            wc = c.get("SQ_WAVE_CYCLES")
+            if wc:
+                # SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = share of a wave's life spent issuing VALU; x waves per SIMD
+                waves_per_simd = 2
+                if "SQ_ACTIVE_INST_VALU" in c:
+                    e["valu_busy_frac_of_simd"] = c["SQ_ACTIVE_INST_VALU"] / wc * waves_per_simd
+                if "SQ_WAIT_ANY" in c:
+                    e["wave_wait_frac"] = c["SQ_WAIT_ANY"] / wc
+                if "SQ_WAIT_INST_ANY" in c:
+                    e["wave_issue_stall_frac"] = c["SQ_WAIT_INST_ANY"] / wc
+            if "GRBM_GUI_ACTIVE" in c and e["avg_duration_ms"]:
+                e["clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8 / (e["avg_duration_ms"] * 1e6)
+                if "SQ_LDS_IDX_ACTIVE" in c:
+                    e["lds_array_busy_frac"] = c["SQ_LDS_IDX_ACTIVE"] / 256 / (c["GRBM_GUI_ACTIVE"] / 8)
+            e["pbs_per_dispatch_assumed"] = n
+        e["profile"] = "rocprofv3 --kernel-trace --pmc ... -- python3 bench.py --steps 3 --warmup 1 --cpu-pbs 0 " \
+                       "--skip-single-op --skip-secondary --skip-extras --pipelines 1 (separate passes; tools/pmc_to_json.py)"
+        res[short] = e
+    json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "per_dispatch"} for k, v in res.items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
