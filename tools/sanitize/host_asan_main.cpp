@@ -1,0 +1,116 @@
+// ASan/UBSan driver of the product's HOST-ONLY code (no device is touched): client keygen / encrypt / decrypt /
+// key files (client.cpp), the twiddle and key transforms (ntt_tables.cpp, fft_tables.cpp), and the whole DAG layer --
+// engine.cpp graph logic, radix.cpp, strings.cpp, capi_*.cpp -- through a planner context (fhs_ctx_create_planner),
+// which records and levelises every string op of the C ABI without executing anything.
+// Built by `make -C fhestring_amd/csrc asan`; run by tests/test_sanitizers.py.  CPU only.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fhestring_hip.h"
+#include "../../fhestring_amd/csrc/fft_tables.h"
+#include "../../fhestring_amd/csrc/ntt_tables.h"
+
+static int fails = 0;
+#define CHECK(x) do { if (!(x)) { std::printf("CHECK failed: %s (line %d)\n", #x, __LINE__); fails++; } } while (0)
+
+static std::vector<fhs_char_t> dummy(fhs_ctx *c, size_t n) {
+    std::vector<uint64_t> z((size_t)FHS_CHAR_WORDS, 0);
+    std::vector<fhs_char_t> v;
+    for (size_t i = 0; i < n; i++) v.push_back(fhs_upload(c, z.data()));
+    return v;
+}
+
+int main() {
+    // ---- client -----------------------------------------------------------------------------------------------
+    fhs_client *ck = nullptr;
+    CHECK(fhs_client_create_insecure_seeded(42, &ck) == FHS_OK);
+    std::vector<uint64_t> ct((size_t)12 * FHS_CHAR_WORDS);
+    CHECK(fhs_client_encrypt_str(ck, "sanitizers", 10, 2, ct.data()) == FHS_OK);
+    char buf[16];
+    size_t n = 0;
+    CHECK(fhs_client_decrypt_str(ck, ct.data(), 12, buf, &n) == FHS_OK && n == 10 && !std::memcmp(buf, "sanitizers", 10));
+    CHECK(fhs_client_encrypt_str(ck, "bad\0x", 5, 0, ct.data()) == FHS_ERR_ARG);
+    const std::string path = "/tmp/fhs_asan_key.bin";
+    CHECK(fhs_client_save(ck, path.c_str(), 0) == FHS_OK);
+    fhs_client *ck2 = nullptr;
+    CHECK(fhs_client_load(path.c_str(), &ck2) == FHS_OK);
+    uint8_t v = 0;
+    CHECK(fhs_client_decrypt_char(ck2, ct.data(), &v) == FHS_OK);
+    fhs_client *os = nullptr;
+    CHECK(fhs_client_create(&os) == FHS_OK);           // OS-entropy path
+    fhs_client_destroy(os);
+    std::remove(path.c_str());
+
+    // ---- host transforms of the key ---------------------------------------------------------------------------
+    {
+        fhs::HostNttTables ht;
+        fhs::build_ntt_tables(ht);
+        fhs::HostFftTables ft;
+        fhs::build_fft_tables(ft);
+        CHECK(ht.fwd_uni.size() == 64 && ft.w_re.size() == 1024);
+        std::vector<double> out((size_t)4 * 2 * 2 * 2048);       // one GGSW
+        std::vector<uint64_t> one(fhs_client_bsk(ck), fhs_client_bsk(ck) + 4 * 2048);
+        // convert_bsk_to_ntt walks all 742 GGSWs: give it the real key (reads only)
+        std::vector<double> all((size_t)742 * 4 * 2 * 2048);
+        fhs::convert_bsk_to_ntt(fhs_client_bsk(ck), all.data(), 4);
+    }
+
+    // ---- DAG layer through the planner ------------------------------------------------------------------------
+    fhs_ctx *c = nullptr;
+    CHECK(fhs_ctx_create_planner(&c) == FHS_OK);
+    for (int mode = 0; mode < 2; mode++) {
+        CHECK(fhs_set_mode(c, mode) == FHS_OK);
+        auto s = dummy(c, 14), p = dummy(c, 3), o = dummy(c, 14), to = dummy(c, 5);
+        fhs_char_t r = 0, f = 0;
+        CHECK(fhs_str_contains(c, s.data(), s.size(), p.data(), p.size(), &r) == FHS_OK);
+        CHECK(fhs_str_contains_clear(c, s.data(), s.size(), "abc", 3, &r) == FHS_OK);
+        CHECK(fhs_str_starts_with(c, s.data(), s.size(), p.data(), p.size(), &r) == FHS_OK);
+        CHECK(fhs_str_ends_with(c, s.data(), s.size(), p.data(), p.size(), &r) == FHS_OK);
+        CHECK(fhs_str_find(c, s.data(), s.size(), p.data(), p.size(), &r) == FHS_OK);
+        CHECK(fhs_str_rfind(c, s.data(), s.size(), p.data(), p.size(), &r) == FHS_OK);
+        CHECK(fhs_str_is_empty(c, s.data(), s.size(), &r) == FHS_OK);
+        CHECK(fhs_str_len(c, s.data(), s.size(), &r) == FHS_OK);
+        CHECK(fhs_str_eq(c, s.data(), s.size(), o.data(), o.size(), &r) == FHS_OK);
+        CHECK(fhs_str_ne(c, s.data(), s.size(), o.data(), o.size(), &r) == FHS_OK);
+        CHECK(fhs_str_eq_ignore_case(c, s.data(), s.size(), o.data(), o.size(), &r) == FHS_OK);
+        for (int cmp = 0; cmp < 4; cmp++) CHECK(fhs_str_compare(c, s.data(), s.size(), o.data(), o.size(), cmp, &r) == FHS_OK);
+        std::vector<fhs_char_t> out(64 * 16, 0);
+        CHECK(fhs_str_to_upper(c, s.data(), s.size(), out.data()) == FHS_OK);
+        CHECK(fhs_str_to_lower(c, s.data(), s.size(), out.data()) == FHS_OK);
+        CHECK(fhs_str_trim(c, s.data(), s.size(), out.data()) == FHS_OK);
+        CHECK(fhs_str_trim_start(c, s.data(), s.size(), out.data()) == FHS_OK);
+        CHECK(fhs_str_trim_end(c, s.data(), s.size(), out.data()) == FHS_OK);
+        CHECK(fhs_str_strip_prefix(c, s.data(), s.size(), p.data(), p.size(), out.data(), &f) == FHS_OK);
+        CHECK(fhs_str_strip_suffix(c, s.data(), s.size(), p.data(), p.size(), out.data(), &f) == FHS_OK);
+        size_t len = 0;
+        std::vector<fhs_char_t> rep(fhs_str_replace_len(s.size(), p.size(), to.size()) + 8);
+        CHECK(fhs_str_replace(c, s.data(), s.size(), p.data(), p.size(), to.data(), to.size(), rep.data(), rep.size(), &len) == FHS_OK);
+        CHECK(fhs_str_replace(c, s.data(), s.size(), to.data(), to.size(), p.data(), p.size(), rep.data(), rep.size(), &len) == FHS_OK);
+        CHECK(fhs_str_concatenate(c, s.data(), s.size(), o.data(), o.size(), out.data()) == FHS_OK);
+        if (mode == 1) {
+            for (int kind = 0; kind < 9; kind++) {
+                const size_t d = fhs_str_split_dim(kind, s.size());
+                std::vector<fhs_char_t> sp(d * d);
+                size_t dim = 0;
+                fhs_char_t cnt = (kind == 3 || kind == 6) ? fhs_trivial(c, 2) : 0;
+                CHECK(fhs_str_split(c, kind, s.data(), s.size(), p.data(), kind == 8 ? 0 : p.size(), cnt, sp.data(), sp.size(), &dim, &f) == FHS_OK);
+            }
+        }
+        CHECK(fhs_flush(c) == FHS_OK);
+        uint64_t blocks[FHS_CHAR_WORDS];
+        CHECK(fhs_download(c, r, blocks) == FHS_ERR_STATE);      // a planner computes nothing
+    }
+    fhs_stats st;
+    CHECK(fhs_get_stats(c, &st) == FHS_OK && st.pbs_executed > 1000 && st.max_input_sum_c2 <= FHS_NOISE_BUDGET_SUM_C2);
+    size_t w0, w1, c0, c1;
+    fhs_dist_plan_windows(257, 4, 8, 7, &w0, &w1, &c0, &c1);
+    CHECK(w1 == 254 && c1 == 257);
+    CHECK(fhs_str_find(c, nullptr, 3, nullptr, 0, nullptr) != FHS_OK);   // argument errors do not crash
+    fhs_ctx_destroy(c);
+    fhs_client_destroy(ck);
+    fhs_client_destroy(ck2);
+    std::printf(fails ? "FAILED\n" : "host sanitizer run ok\n");
+    return fails ? 1 : 0;
+}
