@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfhestring_hip.so")
+# FHS_LIB_PATH: load another build of the same library (kernel experiments: tools/ablate_fft.py); never a fallback
+LIB_PATH = os.environ.get("FHS_LIB_PATH") or os.path.join(_HERE, "libfhestring_hip.so")
 
 _lib = None
 

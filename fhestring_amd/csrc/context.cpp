@@ -94,7 +94,6 @@ int Context::init(int device_id) {
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
     wg_slots = 4 * prop.multiProcessorCount;
     HIP_TRY(hipMalloc(&d_work_counter, 64), "hipMalloc counter");
-    if (const char *w = std::getenv("FHS_WIDE_KERNEL")) wide_kernel = std::atoi(w);   // experiments
     return 0;
 }
 
@@ -241,7 +240,7 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
         p.work_counter = d_work_counter;
         p.slots = wg_slots;
         p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
-        e = four ? launch_blind_rotate_fft4(p, s) : (wide_kernel == 1 ? launch_blind_rotate_fft4w(p, s) : launch_blind_rotate_fft(p, s));
+        e = four ? launch_blind_rotate_fft4(p, s) : launch_blind_rotate_fft(p, s);
     } else {
         BlindRotateParams p{};
         p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;

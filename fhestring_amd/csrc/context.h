@@ -63,7 +63,6 @@ class Context {
     uint32_t *d_work_counter = nullptr;   // persistent-workgroup ciphertext counter of the 2-wavefront FFT kernel
     int wg_slots = 1024;                  // 4 workgroups per CU
     int fft4_max_batch = 512;         // batches up to this size use the 4-wavefront kernel (lower latency)
-    int wide_kernel = 0;              // batches above it: 0 = 2-wavefront kernel, 1 = 4-wavefront kernel at 3 waves per SIMD
     int set_arithmetic(int mode);
     // keyswitch of a dense batch into ks_buf (timed as kernel kind 1); ks_buf must hold B rows
     int keyswitch(const uint64_t *d_in, size_t B, hipStream_t s);

@@ -309,36 +309,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     fft4_bootstrap(P, smem, blockIdx.x);
 }
 
-// Throughput variant for wide batches: the same body compiled for 3 waves per SIMD (154 VGPRs, no scratch; 3 workgroups
-// = 12 wavefronts per CU, LDS 3 x 34 816 B), persistent workgroups taking ciphertexts from a counter like the
-// 2-wavefront kernel.  A third wave per SIMD hides the LDS round trips and barriers that leave the FP64 pipe idle a third
-// of the time at 2 waves per SIMD (profiles/r02_*).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void blind_rotate_fft4w_kernel(BlindRotateFftParams P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *next_ct = reinterpret_cast<int *>(smem + 4 * F4_WAVE_BYTES);
-    for (;;) {
-        if (threadIdx.x == 0) *next_ct = (int)atomicAdd(P.work_counter, 1u);
-        __syncthreads();
-        const int ct = __builtin_amdgcn_readfirstlane(*next_ct);
-        __syncthreads();                              // every wave holds ct before the slot can be rewritten
-        if (ct >= P.B) break;
-        fft4_bootstrap(P, smem, ct);
-    }
-}
-
 hipError_t launch_blind_rotate_fft4(const BlindRotateFftParams &p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     hipLaunchKernelGGL(blind_rotate_fft4_kernel, dim3(p.B), dim3(256), 4 * F4_WAVE_BYTES, s, p);
-    return hipGetLastError();
-}
-
-hipError_t launch_blind_rotate_fft4w(const BlindRotateFftParams &p, hipStream_t s) {
-    if (p.B <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    const int slots = p.slots / 4 * 3;                // p.slots = 4 per CU; 3 workgroups of 4 wavefronts fit a CU
-    const int grid = p.B < slots ? p.B : slots;
-    hipLaunchKernelGGL(blind_rotate_fft4w_kernel, dim3(grid), dim3(256), 4 * F4_WAVE_BYTES + 16, s, p);
     return hipGetLastError();
 }
 

@@ -78,7 +78,6 @@ hipError_t read_device_ntt_consts(double *fwd_uni /*[64]*/, double *inv_uni /*[1
 hipError_t launch_blind_rotate(const BlindRotateParams &p, hipStream_t s);
 hipError_t launch_blind_rotate_fft(const BlindRotateFftParams &p, hipStream_t s);    // 2 wavefronts per ciphertext
 hipError_t launch_blind_rotate_fft4(const BlindRotateFftParams &p, hipStream_t s);   // 4 wavefronts per ciphertext
-hipError_t launch_blind_rotate_fft4w(const BlindRotateFftParams &p, hipStream_t s);  // same, 3 waves per SIMD, persistent
 // standard-domain key [742*4][2048] u64 -> Fourier-domain key, with the device's own forward transform
 hipError_t launch_bsk_to_fft(const uint64_t *d_bsk_std, double *d_out, const double *d_lanetab, hipStream_t s);
 // the scalar twiddle literals baked into fft_kernels.hip: W[16] (index 1 and even indices used), U[3]

@@ -452,8 +452,12 @@ std::vector<FStr> Strings::xsplit(const FStr &s_in, const FStr &pat, bool inclus
     FStr s = s_in;
     s.push_back(zero);
     const size_t size = s.size();
-    FChar cur_buf = zero, stop_inc = zero, global_found = zero, allow = zero;
     std::vector<FStr> result(size, FStr(size, zero));
+    if (fused() && f_split_distribute(s, pat, n, reverse, result, found_out)) {
+        split_cleanup(result, pat, inclusive, terminator, n);
+        return result;
+    }
+    FChar cur_buf = zero, stop_inc = zero, global_found = zero, allow = zero;
     FStr mask(size, one);
     if (n) allow = ch_ne(*n, zero);
     if (!reverse && pat.empty() && n) {                      // split.rs:925-937
@@ -477,19 +481,72 @@ std::vector<FStr> Strings::xsplit(const FStr &s_in, const FStr &pat, bool inclus
             cur_buf = s_ite(ch_bitand(f, s_not(stop_inc)), ch_add(cur_buf, one), cur_buf);
         }
     }
-    // clear_pattern_from_result, split.rs:175-305
+    split_cleanup(result, pat, inclusive, terminator, n);
+    *found_out = global_found;
+    return result;
+}
+
+// Runs `op(row, a, b)` on the SUPPORT of a buffer only: leading and trailing characters that are trivially (provably)
+// NUL cannot take part in a match of a NUL-free pattern and end up behind the payload after the bubble anyway, so the
+// O(L log L) cleanup works on the L positions a buffer can actually receive instead of the whole row.
+FStr Strings::on_support(const FStr &row, FStr (Strings::*op)(const FStr &, const FStr &, const FStr &), const FStr &a,
+                         const FStr &b) {
+    auto triv0 = [&](const FChar &c) {
+        for (int k = 0; k < 4; k++)
+            if (!e_->is_triv(c.b[k].id()) || e_->triv_val(c.b[k].id()) != 0) return false;
+        return true;
+    };
+    size_t lo = 0, hi = row.size();
+    while (lo < hi && triv0(row[lo])) lo++;
+    while (hi > lo && triv0(row[hi - 1])) hi--;
+    FStr out(row.size(), t(0));
+    if (lo == hi) return out;
+    FStr sub(row.begin() + lo, row.begin() + hi);
+    FStr r = (this->*op)(sub, a, b);
+    for (size_t k = 0; k < std::min(r.size(), out.size()); k++) out[k] = r[k];
+    return out;
+}
+
+// clear_pattern_from_result, split.rs:175-305
+void Strings::split_cleanup(std::vector<FStr> &result, const FStr &pat, bool inclusive, bool terminator, const FChar *n) {
+    const FChar zero = t(0), one = t(1);
+    const size_t size = result.size();
     FStr to(pat.size(), zero);
+    // fused mode: the same operations on each buffer's support (see on_support); as written: on the whole row
+    auto do_replace = [&](const FStr &row) {
+        return fused() ? on_support(row, &Strings::replace, pat, to) : replace(row, pat, to);
+    };
+    auto bubble3 = [](Strings *S, const FStr &r) { return S->bubble_zeroes_right(r); };
+    (void)bubble3;
+    auto do_bubble = [&](const FStr &row) {
+        if (!fused()) return bubble_zeroes_right(row);
+        struct H { static FStr f(Strings *S, const FStr &r) { return S->bubble_zeroes_right(r); } };
+        // support trick without the member-pointer signature: trim by hand
+        size_t lo = 0, hi = row.size();
+        auto triv0 = [&](const FChar &c) {
+            for (int k = 0; k < 4; k++)
+                if (!e_->is_triv(c.b[k].id()) || e_->triv_val(c.b[k].id()) != 0) return false;
+            return true;
+        };
+        while (lo < hi && triv0(row[lo])) lo++;
+        while (hi > lo && triv0(row[hi - 1])) hi--;
+        FStr out(row.size(), zero);
+        if (lo == hi) return out;
+        FStr r = H::f(this, FStr(row.begin() + lo, row.begin() + hi));
+        for (size_t k = 0; k < r.size(); k++) out[k] = r[k];
+        return out;
+    };
     if (n) {
         FChar stop = zero;
         for (size_t i = 0; i < size; i++) {
             stop = ch_bitor(stop, s_eq(*n, ch_add(t((uint8_t)i), one)));
-            FStr cur = bubble_zeroes_right(result[i]);
-            FStr rep = replace(cur, pat, to);
+            FStr cur = do_bubble(result[i]);
+            FStr rep = do_replace(cur);
             for (size_t j = 0; j < size; j++) result[i][j] = s_ite(stop, cur[j], rep[j]);
         }
     } else {
         for (size_t i = 0; i < size; i++)
-            result[i] = inclusive ? bubble_zeroes_right(result[i]) : replace(result[i], pat, to);
+            result[i] = inclusive ? do_bubble(result[i]) : do_replace(result[i]);
         if (terminator) {                                    // split.rs:266-302
             FChar nonzero_found = zero;
             for (size_t i = size; i-- > 0;) {
@@ -503,8 +560,108 @@ std::vector<FStr> Strings::xsplit(const FStr &s_in, const FStr &pat, bool inclus
             }
         }
     }
-    *found_out = global_found;
-    return result;
+}
+
+// Fused distribution phase of the split family (split.rs:110-173, :307-393, :883-988 re-associated).
+//
+// The reference walks the string once; at step t it copies the current character into buffer `cur_buf` (an n x n grid
+// of if_then_else on an encrypted u8 index) and then bumps `cur_buf` if a pattern occurrence ends (starts, for the
+// reverse family) there and is not masked.  Here:
+//   1. window flags for every step at once;
+//   2. the mask as a countdown state machine: an accepted occurrence masks positions i .. i+m-1, which blocks the
+//      next 2m-2 steps of the forward scan (m-1 of the reverse scan); 2 PBS per step, like the greedy replace;
+//   3. cur_buf[t] = number of accepted occurrences before step t = an exclusive prefix count (log depth), as a
+//      multi-digit base-4 number, so buffer indices are not limited to a u8; with a limit n (splitn / rsplitn /
+//      rsplit_once) the counter stops at n - 1: cur_buf = min(count, n - 1);
+//   4. membership of character t in buffer j = AND over the digits of [digit_d(cur_buf) == digit_d(j)] (one shared
+//      LUT per digit value and step, one AND per (step, buffer)), only for the buffers step t can reach
+//      (j <= ceil(t / (block + 1))), and a 1-PBS-per-block select instead of the 11-PBS equality + if_then_else.
+// Returns false (nothing done) for the cases left to the loop above: empty pattern, or a pattern so long that the
+// countdown does not fit the LUT (m > 4 forward, m > 8 reverse).
+bool Strings::f_split_distribute(const FStr &s, const FStr &pat, const FChar *n, bool reverse, std::vector<FStr> &result,
+                                 FChar *found_out) {
+    const size_t size = s.size(), m = pat.size();
+    if (m == 0) return false;
+    const size_t block = reverse ? m - 1 : 2 * m - 2;        // steps blocked after an accepted occurrence
+    if (block > 7) return false;
+    const FChar zero = t(0), one = t(1);
+    auto pos = [&](size_t step) { return reverse ? size - 1 - step : step; };
+
+    // 1. window flags in scan order
+    std::vector<Ref> w(size);
+    for (size_t step = 0; step < size; step++) {
+        const size_t i = pos(step);
+        if (m > size) { w[step] = trivial_block(e_, 0); continue; }
+        if (reverse) w[step] = i + m < size ? window_match(s, i, pat) : trivial_block(e_, 0);          // :47-49
+        else w[step] = i + 1 >= m ? window_match(s, i + 1 - m, pat) : trivial_block(e_, 0);            // :85-87
+    }
+    // 2. accepted occurrences
+    std::vector<Ref> f(size);
+    if (block == 0) f = w;
+    else {
+        Ref state = trivial_block(e_, 0);
+        for (size_t step = 0; step < size; step++) {
+            Ref v = lin(e_, {{2, &state}, {1, &w[step]}});
+            f[step] = pbs(v, LUT_GREEDY_SEL);
+            state = pbs(v, LUT_GREEDY_NEXT0 + (int)block);
+        }
+    }
+    *found_out = ch_flag(e_, or_tree(f));
+
+    // 3. buffer index of every step
+    const size_t max_count = (size + block) / (block + 1);   // occurrences are at least block + 1 steps apart
+    size_t D = 1;
+    while (((size_t)1 << (2 * D)) <= max_count) D++;
+    if (n) D = std::max<size_t>(D, 4);
+    std::vector<Num> cur = flag_prefix_counts(f, D);
+    Ref allow;
+    if (n) {
+        allow = blk_nonzero_flag(*n);                        // n == 0: nothing is ever copied (:124-127)
+        FChar n1 = ch_sub(*n, one);                          // the counter stops at n - 1 (u8 arithmetic, :153-157)
+        for (size_t step = 0; step < size; step++) {
+            FChar low;
+            for (int d = 0; d < 4; d++) low.b[d] = cur[step][d];
+            Ref lt = blk_cmp_flag(low, n1, LUT_CMP_LT);      // count < n - 1 on the low 4 digits
+            if (D > 4) {
+                Term tt[16];
+                size_t k = 0;
+                for (size_t d = 4; d < D; d++) tt[k++] = {1, cur[step][d].id()};
+                Ref hi0 = pbs(Ref(e_, e_->lin(tt, k, 0)), LUT_IS0);
+                lt = pbs(lin(e_, {{1, &lt}, {1, &hi0}}), LUT_IS2);
+            }
+            Num clamped(D);
+            for (size_t d = 0; d < D; d++) {
+                Ref a = pbs(lin(e_, {{4, &lt}, {1, &cur[step][d]}}), LUT_SEL_T);
+                if (d < 4) {
+                    Ref b = pbs(lin(e_, {{4, &lt}, {1, &n1.b[d]}}), LUT_SEL_F);
+                    clamped[d] = lin(e_, {{1, &a}, {1, &b}});
+                } else clamped[d] = a;
+            }
+            cur[step] = clamped;
+        }
+    }
+
+    // 4. membership and copy
+    for (size_t step = 0; step < size; step++) {
+        const size_t i = pos(step);
+        size_t jmax = std::min(size - 1, (step + block) / (block + 1));
+        std::vector<Ref> q(D * 4);                           // q[4 d + v] = [digit d of cur_buf == v], made on demand
+        auto digit_flag = [&](size_t d, int v) -> Ref & {
+            Ref &r = q[4 * d + v];
+            if (!r) r = pbs(cur[step][d], lut_is_k(v));
+            return r;
+        };
+        for (size_t j = 0; j <= jmax; j++) {
+            if ((j >> (2 * D)) != 0) break;                  // not representable: unreachable by construction
+            std::vector<Ref> fl;
+            for (size_t d = 0; d < D; d++) fl.push_back(digit_flag(d, (int)((j >> (2 * d)) & 3)));
+            if (n) fl.push_back(allow);
+            Ref mem = and_tree(fl);
+            if (e_->is_triv(mem.id()) && e_->triv_val(mem.id()) == 0) continue;
+            for (int b = 0; b < 4; b++) result[j][i].b[b] = pbs(lin(e_, {{4, &mem}, {1, &s[i].b[b]}}), LUT_SEL_T);
+        }
+    }
+    return true;
 }
 
 std::vector<FStr> Strings::split_ws(const FStr &s, FChar *found_out) {   // split.rs:1377-1447
@@ -1043,6 +1200,29 @@ std::vector<Strings::Num> Strings::num_exclusive_scan(const std::vector<Num> &x,
     return out;
 }
 
+// Exclusive prefix counts of 0/1 flags as base-4 numbers: chunks of 15 flags give a (low, high) digit pair each, an
+// exclusive scan over the chunk totals (4-ary, log depth) and one add per position.
+std::vector<Strings::Num> Strings::flag_prefix_counts(const std::vector<Ref> &z, size_t D) {
+    const size_t n = z.size();
+    std::vector<Num> out(n);
+    if (n == 0) return out;
+    const size_t nch = (n + 14) / 15;
+    auto digits_of = [&](const Ref &sum) {
+        Num v(D);
+        for (size_t d = 0; d < D; d++) v[d] = d == 0 ? pbs(sum, LUT_MSG) : (d == 1 ? pbs(sum, LUT_CARRY) : trivial_block(e_, 0));
+        return v;
+    };
+    std::vector<Num> tot(nch);
+    for (size_t j = 0; j < nch; j++) tot[j] = digits_of(sum_refs(e_, &z[15 * j], std::min<size_t>(15, n - 15 * j)));
+    std::vector<Num> offs = num_exclusive_scan(tot, D);
+    for (size_t i = 0; i < n; i++) {
+        const size_t j = i / 15, k = i % 15;
+        Num loc = digits_of(k ? sum_refs(e_, &z[15 * j], k) : trivial_block(e_, 0));
+        out[i] = num_add({&offs[j], &loc}, D);
+    }
+    return out;
+}
+
 // Oblivious order-preserving compaction: non-NUL characters move left by the number of NULs before
 // them.  Shifts are prefix counts (base-4 numbers), routed LSB first through log2(n) conditional
 // moves by 2^k -- collision-free for monotone compaction.  Same result as the reference's n-pass
@@ -1056,23 +1236,11 @@ FStr Strings::f_compact(const FStr &s) {
     const FChar zero = t(0);
     std::vector<Ref> z(n);
     for (size_t i = 0; i < n; i++) z[i] = and_tree(block_eq_flags(s[i], zero));
-    // per-position shift = (NULs in earlier chunks) + (NULs earlier in this chunk)
-    const size_t nch = (n + 14) / 15;
-    std::vector<Num> tot(nch);
-    for (size_t j = 0; j < nch; j++) {
-        const size_t cnt = std::min<size_t>(15, n - 15 * j);
-        Ref sm = sum_refs(e_, &z[15 * j], cnt);
-        tot[j] = Num(D);
-        for (size_t d = 0; d < D; d++) tot[j][d] = d == 0 ? pbs(sm, LUT_MSG) : (d == 1 ? pbs(sm, LUT_CARRY) : trivial_block(e_, 0));
-    }
-    std::vector<Num> offs = num_exclusive_scan(tot, D);
+    // per-position shift = number of NULs before it
+    std::vector<Num> shifts = flag_prefix_counts(z, D);
     std::vector<std::vector<Ref>> bits(n, std::vector<Ref>(K));
     for (size_t i = 0; i < n; i++) {
-        const size_t j = i / 15, k = i % 15;
-        Num loc(D);
-        Ref e = k ? sum_refs(e_, &z[15 * j], k) : trivial_block(e_, 0);
-        for (size_t d = 0; d < D; d++) loc[d] = d == 0 ? pbs(e, LUT_MSG) : (d == 1 ? pbs(e, LUT_CARRY) : trivial_block(e_, 0));
-        Num sh = num_add({&offs[j], &loc}, D);
+        const Num &sh = shifts[i];
         for (int b = 0; b < K; b++) {
             if (((size_t)1 << b) > i) { bits[i][b] = trivial_block(e_, 0); continue; }   // shift <= i
             bits[i][b] = pbs(lin(e_, {{1, &sh[b / 2]}, {4, &z[i]}}), (b & 1) ? LUT_BIT1_UNLESS : LUT_BIT0_UNLESS);

@@ -68,6 +68,12 @@ class Strings {
     FChar split_match(bool reverse, size_t i, const FStr &s, const FStr &pat, FStr &mask);
     std::vector<FStr> xsplit(const FStr &s, const FStr &pat, bool inclusive, bool terminator, const FChar *n,
                              bool reverse, FChar *found);
+    // fused formulation of the distribution phase (buffer ids as prefix counts, multi-digit, membership selects)
+    bool f_split_distribute(const FStr &s, const FStr &pat, const FChar *n, bool reverse, std::vector<FStr> &result,
+                            FChar *found);
+    void split_cleanup(std::vector<FStr> &result, const FStr &pat, bool inclusive, bool terminator, const FChar *n);
+    FStr on_support(const FStr &row, FStr (Strings::*op)(const FStr &, const FStr &, const FStr &), const FStr &a,
+                    const FStr &b);
     std::vector<FStr> split_ws(const FStr &s, FChar *found);
     Engine *e_;
     bool fused() const { return e_->mode == 1; }
@@ -87,6 +93,7 @@ class Strings {
     FChar f_comparison(const FStr &a, const FStr &b, int cmp);
     // oblivious compaction: replaces the O(n^2) bubble of utils.rs:28-46 in fused mode
     typedef std::vector<Ref> Num;   // little-endian base-4 digits, clean (<= 3)
+    std::vector<Num> flag_prefix_counts(const std::vector<Ref> &flags, size_t digits);   // exclusive
     Num num_add(const std::vector<const Num *> &ops, size_t digits);
     std::vector<Num> num_exclusive_scan(const std::vector<Num> &x, size_t digits);
     FStr f_compact(const FStr &s);

@@ -86,3 +86,16 @@ def test_planner_computes_nothing(sk):
     c = sk.dummy_string(1)[0]
     with pytest.raises(fhestring_amd.FhsError, match="planner"):
         c.eq(c).download()
+
+
+def test_split_beyond_u8_buffer_index_plans(sk):
+    """f-4: 300 characters -> 301 buffers numbered by multi-digit prefix counts; the distribution phase is a triangle of
+    1-PBS-per-block membership selects (not n x n equality + if_then_else), the counters come from a log-depth scan."""
+    sk.set_mode(1)
+    s, p = sk.dummy_string(300), sk.dummy_string(2)
+    sk.stats(reset=True)
+    r = sk.split(s, p)
+    sk.flush()
+    st = sk.stats()
+    assert len(r.buffers) == 301 and st["max_input_sum_c2"] <= BUDGET
+    assert st["pbs_executed"] < 3_000_000 and st["levels"] < 400
