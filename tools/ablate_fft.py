@@ -29,6 +29,10 @@ VARIANTS = {
 }
 VARIANTS["hb2"] = [("constexpr int HB = 4;", "constexpr int HB = 2;")]
 VARIANTS["hb8"] = [("constexpr int HB = 4;", "constexpr int HB = 8;")]
+FLAGS = {"sched_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+         "sched_memclause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]}
+VARIANTS["sched_maxilp"] = []
+VARIANTS["sched_memclause"] = []
 VARIANTS["nolds"] = VARIANTS["notranspose"] + VARIANTS["nopartner"] + VARIANTS["norotread"]
 VARIANTS["valuonly"] = VARIANTS["nolds"] + VARIANTS["nokey"] + VARIANTS["nobarrier"]
 
@@ -46,7 +50,7 @@ def build():
         open(src, "w").write(t)
         obj = src.replace(".hip", ".o")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", SRC,
-                               "-Wno-unused-function", "-c", src, "-o", obj])
+                               "-Wno-unused-function", "-c", src, "-o", obj] + FLAGS.get(name, []))
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
                                os.path.join(OUT, "libfhs_%s.so" % name), obj] + objs + ["-lpthread", "-ldl"])
         os.remove(obj)
