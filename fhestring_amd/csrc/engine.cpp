@@ -1,6 +1,8 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -327,6 +329,11 @@ int Engine::plan_flush() {
                 if (s.kind == BlockNode::LIN) for (const Term &t : s.terms) c2 += t.coef * t.coef;
                 else c2 = 1;
                 stats.max_input_sum_c2 = std::max<uint64_t>(stats.max_input_sum_c2, (uint64_t)c2);
+                if (c2 > 64 && std::getenv("FHS_DEBUG_C2")) {
+                    std::fprintf(stderr, "c2=%lld lut=%d terms:", (long long)c2, (int)n.lut);
+                    for (const Term &t : s.terms) std::fprintf(stderr, " %lld*b%u", (long long)t.coef, t.blk);
+                    std::fprintf(stderr, "\n");
+                }
                 if (capture_max_rows)
                     plan_.recs.push_back(CaptureRec{(uint32_t)levels.size(), (uint32_t)(descs.size() - 1 - first), n.lut,
                                                     d.n_terms, c2, s.kind == BlockNode::LIN ? s.konst : 0,

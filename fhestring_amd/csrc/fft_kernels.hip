@@ -59,6 +59,31 @@ struct store_hook {
     }
 };
 
+// Hook of the LAST forward stage: as a butterfly finishes two points of the transform they are (1) published for the
+// partner wavefront ([c][lane] order), (2) multiplied by this wavefront's own key row (the first half of the pointwise
+// product: rr = fr*kx - fi*ky, ii = fr*ky + fi*kx, same operations in the same order as when the whole product ran
+// after the barrier), and (3) the key slot they used is refilled: own-row points 8..15 first, then the partner row's
+// points 0..7, which are only needed after the workgroup barrier -- their latency hides behind the rest of this stage
+// and the barrier wait.  One 8-point window (32 VGPRs) serves both rows because the two halves no longer overlap.
+typedef double __attribute__((ext_vector_type(2))) double2_t;
+struct publish_mul_hook {
+    cplx *pub; cplx *z; double2_t *kb; const double2_t *b_own, *b_par;
+    __device__ __forceinline__ void one(int p) const {
+        pub[64 * p] = z[p];
+        const double fr = z[p].r, fi = z[p].i;
+        const double2_t k = kb[p & 7];
+        double rr = fr * k.x; rr = __builtin_fma(-fi, k.y, rr);
+        double ii = fr * k.y; ii = __builtin_fma(fi, k.x, ii);
+        z[p].r = rr; z[p].i = ii;
+        kb[p & 7] = p < 8 ? b_own[(p + 8) * 64] : b_par[(p - 8) * 64];
+    }
+    __device__ __forceinline__ void operator()(int a, int b) const {
+        one(a);
+        one(b);
+        __builtin_amdgcn_sched_barrier(0x7);              // ALU may cross, memory operations may not
+    }
+};
+
 // the 4 lane-uniform stages of layout A (twiddles are scalar immediates)
 template <bool INV, class Hook> __device__ __forceinline__ void stages_uniform(cplx (&z)[16], const Hook &hook) {
 #pragma unroll
@@ -133,7 +158,10 @@ __device__ __forceinline__ void fft_forward(cplx (&z)[16], double *lds, int lane
     {
         const cplx *rd = slotB(lds, lane);
 #pragma unroll
-        for (int p = 0; p < 16; p++) z[p] = rd[4 * p + (p >> 2)];
+        for (int q = 0; q < 16; q++) {                    // in the order stage t = 32 pairs them: (p, p + 8)
+            const int p = (q >> 1) + 8 * (q & 1);
+            z[p] = rd[4 * p + (p >> 2)];
+        }
     }
     __builtin_amdgcn_wave_barrier();
     stage_lane<false, 8>(z, tw.re[0], tw.im[0]);
@@ -144,14 +172,18 @@ __device__ __forceinline__ void fft_forward(cplx (&z)[16], double *lds, int lane
     {
         const cplx *rd = slotC(lds, lane);
 #pragma unroll
-        for (int c = 0; c < 16; c++) z[c] = rd[c];
+        for (int q = 0; q < 16; q++) {                    // in the order stage t = 2 pairs them: (c, c + 2)
+            const int c = (q & ~3) + ((q & 2) >> 1) + 2 * (q & 1);
+            z[c] = rd[c];
+        }
     }
     __builtin_amdgcn_wave_barrier();
     stage_lane<false, 2>(z, tw.re[4], tw.im[4]);
 }
-// last forward stage, with the transform published for the partner wavefront ([c][lane] order) as it completes
-__device__ __forceinline__ void fft_forward_last(cplx (&z)[16], double *lds, int lane, const LaneTw &tw) {
-    stage_lane<false, 1>(z, tw.re[5], tw.im[5], store_hook{reinterpret_cast<cplx *>(lds) + lane, z, 64, 0});
+// last forward stage; every finished point goes through the hook (publication + own-row half of the pointwise product)
+template <class Hook>
+__device__ __forceinline__ void fft_forward_last(cplx (&z)[16], const LaneTw &tw, const Hook &hook) {
+    stage_lane<false, 1>(z, tw.re[5], tw.im[5], hook);
 }
 
 // inverse (unscaled): z[c] at array index 16*lane + c  ->  z[r] = point (lane + 64 r)
@@ -264,38 +296,32 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
         }
         __builtin_amdgcn_wave_barrier();
 
-        // Key rows for this iteration: own transform first (row j), then the partner's (row 1-j); column j.
-        // The first HB of the 16 per-lane points are requested before the transform; the others take over
-        // each register pair as it is consumed.
-        typedef double __attribute__((ext_vector_type(2))) double2_t;
+        // Key rows for this iteration, column j: own transform's row j, then the partner's row 1-j.  An 8-point window
+        // (32 VGPRs): the own row's first 8 points are requested before the transform; see publish_mul_hook for the rest.
         const double2_t *b_own = reinterpret_cast<const double2_t *>(P.bsk_fft) + ((((size_t)i * 2 + j) * 2 + j)) * FM + lane;
         const double2_t *b_par = reinterpret_cast<const double2_t *>(P.bsk_fft) + ((((size_t)i * 2 + (1 - j)) * 2 + j)) * FM + lane;
-        constexpr int HB = 4;
-        double2_t bo[HB], bp[HB];
+        double2_t kb[8];
 #pragma unroll
-        for (int k = 0; k < HB; k++) { bo[k] = b_own[k * 64]; bp[k] = b_par[k * 64]; }
+        for (int k = 0; k < 8; k++) kb[k] = b_own[k * 64];
 
         {
             LaneTw tw;
             load_lane_tw(tw, lanetab, lane);
             fft_forward(z, my, lane, tw);
-            fft_forward_last(z, my, lane, tw);            // publishes [c][lane] for the partner as it goes
+            fft_forward_last(z, tw, publish_mul_hook{reinterpret_cast<cplx *>(my) + lane, z, kb, b_own, b_par});
         }
         __syncthreads();
         __builtin_amdgcn_s_setprio(2);
-        {
+        {   // partner row: z[c] += g[c] * kb (the second half of the pointwise product, same operation order as before)
             const cplx *par = reinterpret_cast<const cplx *>(partner) + lane;
 #pragma unroll
             for (int c = 0; c < 16; c++) {
-                const int k = c % HB;
                 const cplx g = par[c * 64];
-                const double fr = z[c].r, fi = z[c].i;
-                double rr = fr * bo[k].x; rr = __builtin_fma(-fi, bo[k].y, rr);
-                rr = __builtin_fma(g.r, bp[k].x, rr); rr = __builtin_fma(-g.i, bp[k].y, rr);
-                double ii = fr * bo[k].y; ii = __builtin_fma(fi, bo[k].x, ii);
-                ii = __builtin_fma(g.r, bp[k].y, ii); ii = __builtin_fma(g.i, bp[k].x, ii);
+                const double2_t k = kb[c & 7];
+                double rr = __builtin_fma(g.r, k.x, z[c].r); rr = __builtin_fma(-g.i, k.y, rr);
+                double ii = __builtin_fma(g.r, k.y, z[c].i); ii = __builtin_fma(g.i, k.x, ii);
                 z[c].r = rr; z[c].i = ii;
-                if (c + HB < 16) { bo[k] = b_own[(c + HB) * 64]; bp[k] = b_par[(c + HB) * 64]; }
+                if (c < 8) kb[c] = b_par[(c + 8) * 64];
             }
         }
         __syncthreads();

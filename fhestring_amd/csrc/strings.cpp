@@ -772,9 +772,20 @@ FChar Strings::flags_and(const FStr &flags) {
 // Equality of two chars as the AND of 2 flags: nibbles (x0 + 4 x1, x2 + 4 x3) are packed linearly,
 // and (a_nib - b_nib) in [-15, 15] is tested with the `is0` LUT.  That LUT is safe under the
 // padding-bit rule: a negative difference lands on 32-k, whose PBS value is -f(16-k) = -0 = 0.
-std::vector<Ref> Strings::block_eq_flags(const FChar &a, const FChar &b) {
+std::vector<Ref> Strings::block_eq_flags(const FChar &a_in, const FChar &b_in) {
+    // Operands are char blocks (clean 2-bit digits), possibly short sums of bootstrap outputs (a select is SEL_T +
+    // SEL_F, a case shift adds 2 x flag, ...).  If the weights 1, 4, -1, -4 would carry more than the noise budget into
+    // the bootstrap, the blocks that are sums are refreshed first (LUT_MSG keeps a clean digit).
+    FChar a = a_in, b = b_in;
     std::vector<Ref> f;
     for (int h = 0; h < 2; h++) {
+        Ref *blk[4] = {&a.b[2 * h], &a.b[2 * h + 1], &b.b[2 * h], &b.b[2 * h + 1]};
+        const int64_t w2[4] = {1, 16, 1, 16};
+        int64_t tot = 0;
+        for (int k = 0; k < 4; k++) tot += w2[k] * e_->sum_c2(blk[k]->id());
+        if (tot > FHS_NOISE_BUDGET_SUM_C2)
+            for (int k = 0; k < 4; k++)
+                if (e_->sum_c2(blk[k]->id()) > 1) *blk[k] = pbs(*blk[k], LUT_MSG);
         Ref d = lin(e_, {{1, &a.b[2 * h]}, {4, &a.b[2 * h + 1]}, {-1, &b.b[2 * h]}, {-4, &b.b[2 * h + 1]}});
         f.push_back(pbs(d, LUT_IS0));
     }
@@ -1145,12 +1156,18 @@ FStr Strings::f_trim(const FStr &s, bool from_end) {
 }
 
 // cond ? t : f with cond a clean single-block 0/1 flag (no scalar_ne needed)
-FChar Strings::ite_flag(const Ref &flag_in, const FChar &tv, const FChar &fv) {
+FChar Strings::ite_flag(const Ref &flag_in, const FChar &tv_in, const FChar &fv_in) {
     FChar r;
     // the flag enters with weight 4: a flag that is itself a sum of several bootstrap outputs (one-hot cover sums,
     // 1 - x forms) is refreshed first when 16 x its sum c^2 would leave the noise budget
     Ref flag = flag_in;
     if (16 * e_->sum_c2(flag.id()) + 4 > FHS_NOISE_BUDGET_SUM_C2) flag = pbs(flag_in, LUT_NZ);
+    const int64_t room = FHS_NOISE_BUDGET_SUM_C2 - 16 * e_->sum_c2(flag.id());
+    FChar tv = tv_in, fv = fv_in;
+    for (int i = 0; i < 4; i++) {                           // the selected digits enter with weight 1
+        if (e_->sum_c2(tv.b[i].id()) > room) tv.b[i] = pbs(tv.b[i], LUT_MSG);
+        if (e_->sum_c2(fv.b[i].id()) > room) fv.b[i] = pbs(fv.b[i], LUT_MSG);
+    }
     for (int i = 0; i < 4; i++) {
         Ref a = pbs(lin(e_, {{4, &flag}, {1, &tv.b[i]}}), LUT_SEL_T);
         Ref b = pbs(lin(e_, {{4, &flag}, {1, &fv.b[i]}}), LUT_SEL_F);
@@ -1258,6 +1275,7 @@ FStr Strings::f_compact(const FStr &s) {
             const bool has_src = p + d < n && !(e_->is_triv(bits[p + d][k].id()) && e_->triv_val(bits[p + d][k].id()) == 0);
             for (int blk = 0; blk < 4; blk++) {
                 Ref st = stays ? cur[p].b[blk] : pbs(lin(e_, {{4, &bs}, {1, &cur[p].b[blk]}}), LUT_SEL_F);
+                if (stays && has_src && e_->sum_c2(st.id()) > 1) st = pbs(st, LUT_MSG);   // keep outputs at <= 2 terms
                 if (has_src) {
                     Ref in = pbs(lin(e_, {{4, &bits[p + d][k]}, {1, &cur[p + d].b[blk]}}), LUT_SEL_T);
                     nxt[p].b[blk] = lin(e_, {{1, &in}, {1, &st}});
