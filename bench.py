@@ -58,9 +58,10 @@ def parse():
                          "reference engine's algorithm class, fhs_set_arithmetic(FHS_ARITH_F64_FFT)); 'exact' = "
                          "two-prime exact NTT (library default).  The other one is timed too (other_arithmetic)")
     ap.add_argument("--pipelines", type=int, default=None,
-                    help="independent contexts (own HIP stream, scratch, block pool, communicator) per GPU; step k runs "
-                         "on pipeline k mod P so the narrow tail levels of one step overlap the wide first level of "
-                         "the next (default 3 for contains, 1 otherwise)")
+                    help="0 = ONE context with level-skewed batching (fhs_submit + fhs_pump per step: the narrow tail "
+                         "levels of step k ride in the wide launch of step k+1; default for contains on one GPU); "
+                         "P >= 1 = P independent contexts (own HIP stream, scratch, block pool, communicator), step k on "
+                         "pipeline k mod P (default 3 for contains on several GPUs, 1 for the other ops)")
     ap.add_argument("--repeats", type=int, default=5, help="extra repeats for the median (0 = skip)")
     ap.add_argument("--skip-secondary", action="store_true", help="do not time the other arithmetic")
     ap.add_argument("--skip-single-op", action="store_true", help="skip single-op latency / end-to-end / as-written")
@@ -77,7 +78,8 @@ def parse():
     if a.strings is None:
         a.strings = 8 if a.op == "contains" else 1
     if a.pipelines is None:
-        a.pipelines = 3 if a.op == "contains" else 1
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        a.pipelines = (0 if world == 1 else 3) if a.op == "contains" else 1
     return a
 
 
@@ -352,6 +354,9 @@ def main():
         raise SystemExit("find returns an encrypted u8 index: the reference panics for strings of 255 + m characters "
                          "or more (src/server_key/mod.rs:1025-1027); lower --chars")
     ck = MyClientKey(SEED)                      # insecure seeded client: identical keys on every rank (synthetic data)
+    SKEW = args.pipelines == 0
+    if SKEW and world > 1:
+        raise SystemExit("--pipelines 0 (level-skewed batching) is a single-GPU mode: the sharded ops flush at their exchange")
     P = max(1, args.pipelines)
     sks = [MyServerKey.from_client_key(ck, local_rank, arith=1) for _ in range(P)]   # Fourier-domain key as well
     ARITH = {"fft": sks[0].ctx.ARITH_F64_FFT, "exact": sks[0].ctx.ARITH_EXACT_NTT}
@@ -370,7 +375,11 @@ def main():
         k = step_no[0] % P
         step_no[0] += 1
         outs = wl.step(k)
-        sks[k].flush(wait=(P == 1))          # P > 1: enqueue only; sync() below waits for every stream
+        if SKEW:                             # plan this step as a job, enqueue ONE launch group (this step's first level
+            sks[0].submit()                  # + the later levels of the previous steps); drained by sync()
+            sks[0].pump(1)
+        else:
+            sks[k].flush(wait=(P == 1))      # P > 1: enqueue only; sync() below waits for every stream
         return outs
 
     def all_stats(reset=False):
@@ -397,6 +406,8 @@ def main():
             x.ctx.set_arithmetic(ARITH[a])
 
     def sync():
+        if SKEW:
+            sks[0].flush(wait=False)         # drain the ticks still scheduled (the last steps' narrow levels)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -420,7 +431,7 @@ def main():
 
     # median of >= 5 repeats of a shorter run (SURVEY 8d timing protocol), outside the contract's timed region
     rep_ms = []
-    n_rep_steps = max(P, min(args.steps, 2 * P))
+    n_rep_steps = 6 if SKEW else max(P, min(args.steps, 2 * P))
     for _ in range(args.repeats):
         d, _, _, _ = timed(n_rep_steps)
         rep_ms.append(d / n_rep_steps * 1e3)
@@ -553,7 +564,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s, %s DAG, %s arithmetic" % (wl.describe(), args.mode,
                                                                    "f64-FFT" if args.arith == "fft" else "exact-NTT"),
-                       "pipelines": P, "parallelism": wl.parallelism()},
+                       "pipelines": args.pipelines,
+                       "scheduling": ("level-skewed batching: one context, fhs_submit + fhs_pump per step, the narrow "
+                                      "levels of step k ride in the wide launch of step k+1" if SKEW else
+                                      "%d independent context(s), step k on context k mod %d" % (P, P)),
+                       "parallelism": wl.parallelism()},
             "ms_per_op": dt / args.steps / wl.n_strings * 1e3,
             "median_ms_per_step": statistics.median(rep_ms) if rep_ms else None,
             "repeat_ms_per_step": rep_ms,

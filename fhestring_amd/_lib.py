@@ -196,6 +196,10 @@ def _declare(L):
     L.fhs_debug_capture_pbs_inputs.restype = i
     L.fhs_debug_capture_read.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.fhs_debug_capture_read.restype = i
+    L.fhs_submit.argtypes = [vp]
+    L.fhs_submit.restype = i
+    L.fhs_pump.argtypes = [vp, sz]
+    L.fhs_pump.restype = i
     L.fhs_level_widths.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.fhs_level_widths.restype = i
     L.fhs_get_stats.argtypes = [vp, vp]

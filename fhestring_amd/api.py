@@ -412,6 +412,14 @@ class MyServerKey:
         else:
             self.ctx._check(self.ctx._L.fhs_flush_async(self.ctx._h))
 
+    def submit(self):
+        """fhs_submit: plan what was recorded since the last submit / flush as one job (nothing runs yet)."""
+        self.ctx._check(self.ctx._L.fhs_submit(self.ctx._h))
+
+    def pump(self, n_ticks=1):
+        """fhs_pump: enqueue the next n ticks (one launch group each over every job's level scheduled for it)."""
+        self.ctx._check(self.ctx._L.fhs_pump(self.ctx._h, int(n_ticks)))
+
     def stream_sync(self):
         self.ctx._check(self.ctx._L.fhs_stream_sync(self.ctx._h))
 

@@ -127,6 +127,14 @@ int fhs_flush(fhs_ctx *c) {
     if (hipStreamSynchronize(c->eng.ctx.stream) != hipSuccess) return c->eng.ctx.fail(FHS_ERR_HIP, "stream sync failed");
     return FHS_OK;
 }
+int fhs_submit(fhs_ctx *c) {
+    if (!c) return FHS_ERR_ARG;
+    return c->eng.submit();
+}
+int fhs_pump(fhs_ctx *c, size_t n_ticks) {
+    if (!c) return FHS_ERR_ARG;
+    return c->eng.pump(n_ticks);
+}
 int fhs_flush_async(fhs_ctx *c) {
     if (!c) return FHS_ERR_ARG;
     return c->eng.flush();

@@ -34,6 +34,7 @@ void Engine::shutdown() {
     if (d_luts_) (void)hipFree(d_luts_);
     d_luts_ = nullptr;
     plan_buf_.release();
+    tick_buf_.release();
     batch_in_.release();
     ctx.shutdown();
 }
@@ -56,7 +57,10 @@ uint64_t *Engine::alloc_block() {
     return p;
 }
 void Engine::free_block(uint64_t *p) {
-    if (!planner) free_blocks_.push_back(p);
+    // A scheduled job level that has not been enqueued yet may still read this block: it becomes reusable once every
+    // tick scheduled so far is in the stream (stream order then protects the readers).
+    if (!planner && last_sched_tick_ >= next_tick_) free_after_[last_sched_tick_].push_back(p);
+    else if (!planner) free_blocks_.push_back(p);
     live_dev_blocks_--;
 }
 
@@ -205,6 +209,8 @@ Bid Engine::pbs(Bid x, int lut) {
 // flush: plan every level on the host, upload the plan once, enqueue all launches
 // ------------------------------------------------------------------------------------------
 int Engine::flush() {
+    while (!sched_.empty())                                   // drain the scheduled ticks of submitted jobs first
+        if (int rc = pump(1)) return rc;
     if (level_parallel && ctx.dist.active()) return flush_level_parallel();   // world 1 too: same stream-ordered path
     if (dist_world > 1 && !pending_.empty())
         return ctx.fail(-3, "distributed context: pending PBS must be run with fhs_flush_plan/level_exec/level_commit");
@@ -214,6 +220,148 @@ int Engine::flush() {
         if ((rc = exec_level(k, 0, plan_.levels[k].count, nullptr))) return rc;
     plan_.levels.clear();
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// level-skewed batching: jobs, ticks
+// ------------------------------------------------------------------------------------------
+int Engine::submit() {
+    if (pending_.empty()) return 0;
+    if (level_parallel && ctx.dist.active()) return ctx.fail(-3, "fhs_submit is not available in level-parallel mode");
+    if (!planner && !ctx.key_loaded) return ctx.fail(-3, "server key not loaded");
+    std::map<uint32_t, std::vector<Bid>> by_level;
+    for (Bid b : pending_)
+        if (nodes_[b].kind == BlockNode::PBS) by_level[nodes_[b].level].push_back(b);
+    pending_.clear();
+    uint64_t tick = next_tick_ - 1;                           // the job's first level goes to next_tick_ at the earliest
+    for (auto &kv : by_level) {
+        std::vector<Bid> &lv = kv.second;
+        TickLevel tl;
+        uint64_t need = 0;                                    // latest tick that produces one of this level's inputs
+        for (Bid b : lv) {
+            BlockNode &n = nodes_[b];
+            const BlockNode &s = nodes_[n.src];
+            LinDesc d{};
+            d.first_term = (uint32_t)tl.terms.size();
+            int64_t c2 = 0;
+            if (s.kind == BlockNode::MAT) {
+                tl.terms.push_back({s.dev, 1});
+                d.n_terms = 1;
+                need = std::max(need, s.ready_tick);
+                c2 = 1;
+            } else if (s.kind == BlockNode::LIN) {
+                for (const Term &t : s.terms) {
+                    const BlockNode &tb = nodes_[t.blk];
+                    if (tb.kind != BlockNode::MAT || !tb.dev)
+                        return ctx.fail(-3, "internal: lincomb term not materialised at its level");
+                    tl.terms.push_back({tb.dev, t.coef});
+                    need = std::max(need, tb.ready_tick);
+                    c2 += t.coef * t.coef;
+                }
+                d.n_terms = (uint32_t)s.terms.size();
+                d.konst_body = (uint64_t)(s.konst & 31) << DELTA_LOG;
+            } else {
+                return ctx.fail(-3, "internal: PBS source is neither MAT nor LIN");
+            }
+            stats.max_input_sum_c2 = std::max<uint64_t>(stats.max_input_sum_c2, (uint64_t)c2);
+            tl.descs.push_back(d);
+            tl.lut.push_back(n.lut);
+            uint64_t *o = alloc_block();
+            if (!o) return ctx.fail(-2, "device block pool exhausted (hipMalloc failed)");
+            tl.out.push_back(o);
+        }
+        tick = std::max(tick + 1, need + 1);
+        last_sched_tick_ = std::max(last_sched_tick_, tick);  // before the releases below: their frees wait for this tick
+        for (size_t k = 0; k < lv.size(); k++) {
+            BlockNode &n = nodes_[lv[k]];
+            const Bid src = n.src;
+            n.kind = BlockNode::MAT;
+            n.dev = tl.out[k];
+            n.src = 0;
+            n.level = 0;
+            n.ready_tick = tick;
+            release(src);
+        }
+        sched_[tick].push_back(std::move(tl));
+    }
+    return 0;
+}
+
+int Engine::pump(size_t n_ticks) {
+    for (size_t it = 0; it < n_ticks && !sched_.empty(); it++) {
+        auto first = sched_.begin();
+        const uint64_t tick = first->first;
+        std::vector<TickLevel> levels = std::move(first->second);
+        sched_.erase(first);
+        if (int rc = run_tick(levels)) return rc;
+        next_tick_ = tick + 1;
+        // blocks freed while ticks <= `tick` were still pending are safe to hand out now
+        while (!free_after_.empty() && free_after_.begin()->first <= tick) {
+            for (uint64_t *p : free_after_.begin()->second) free_blocks_.push_back(p);
+            free_after_.erase(free_after_.begin());
+        }
+    }
+    if (sched_.empty() && last_sched_tick_ >= next_tick_) next_tick_ = last_sched_tick_ + 1;
+    return 0;
+}
+
+// one launch group over the union of the job levels scheduled for a tick
+int Engine::run_tick(std::vector<TickLevel> &levels) {
+    size_t width = 0, n_terms = 0;
+    for (auto &l : levels) { width += l.descs.size(); n_terms += l.terms.size(); }
+    if (width == 0) return 0;
+    for (auto &l : levels) {
+        stats.levels += 1;
+        if (stats.level_widths.size() < (1u << 20)) stats.level_widths.push_back((uint32_t)l.descs.size());
+        stats.max_level_width = std::max<uint64_t>(stats.max_level_width, l.descs.size());
+    }
+    stats.pbs_executed += width;
+    if (planner) return 0;
+    if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
+    const size_t off_desc = 0;
+    const size_t off_terms = off_desc + width * sizeof(LinDesc);
+    const size_t off_lut = off_terms + n_terms * sizeof(LinTerm);
+    const size_t off_out = (off_lut + width * 4 + 15) & ~(size_t)15;
+    const size_t total = off_out + width * sizeof(uint64_t *);
+    std::vector<uint8_t> host(total);
+    LinDesc *hd = reinterpret_cast<LinDesc *>(host.data() + off_desc);
+    LinTerm *ht = reinterpret_cast<LinTerm *>(host.data() + off_terms);
+    uint32_t *hl = reinterpret_cast<uint32_t *>(host.data() + off_lut);
+    uint64_t **ho = reinterpret_cast<uint64_t **>(host.data() + off_out);
+    size_t di = 0, ti = 0;
+    for (auto &l : levels) {
+        for (size_t k = 0; k < l.descs.size(); k++) {
+            LinDesc d = l.descs[k];
+            d.first_term += (uint32_t)ti;
+            hd[di + k] = d;
+            hl[di + k] = l.lut[k];
+            ho[di + k] = l.out[k];
+        }
+        std::memcpy(ht + ti, l.terms.data(), l.terms.size() * sizeof(LinTerm));
+        di += l.descs.size();
+        ti += l.terms.size();
+    }
+    hipError_t e = tick_buf_.cap >= total ? hipSuccess : hipStreamSynchronize(ctx.stream);
+    if (e == hipSuccess) e = tick_buf_.reserve(total);
+    if (e == hipSuccess && batch_in_.cap < width * BIG_CT * 8) {
+        e = hipStreamSynchronize(ctx.stream);
+        if (e == hipSuccess) e = batch_in_.reserve(width * BIG_CT * 8);
+    }
+    if (e == hipSuccess && ctx.ks_buf.cap < width * SMALL_CT * 8) {
+        e = hipStreamSynchronize(ctx.stream);
+        if (e == hipSuccess) e = ctx.ks_buf.reserve(width * SMALL_CT * 8);
+    }
+    if (e != hipSuccess) return ctx.hip_fail(e, "tick buffers");
+    // stream-ordered after the previous tick's kernels, which read the old contents (pageable source: consumed on return)
+    e = hipMemcpyAsync(tick_buf_.ptr, host.data(), total, hipMemcpyHostToDevice, ctx.stream);
+    if (e != hipSuccess) return ctx.hip_fail(e, "tick plan upload");
+    const uint8_t *dp = tick_buf_.as<uint8_t>();
+    e = launch_lincomb(reinterpret_cast<const LinDesc *>(dp + off_desc), reinterpret_cast<const LinTerm *>(dp + off_terms),
+                       batch_in_.as<uint64_t>(), (int)width, ctx.stream);
+    if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
+    if (int rc = ctx.keyswitch(batch_in_.as<uint64_t>(), width, ctx.stream)) return rc;
+    return ctx.blind_rotate(ctx.ks_buf.as<uint64_t>(), reinterpret_cast<const uint32_t *>(dp + off_lut), d_luts_, nullptr,
+                            reinterpret_cast<uint64_t *const *>(dp + off_out), width, ctx.stream);
 }
 
 // All levels and all exchanges are enqueued back to back: with RCCL nothing waits on the host.

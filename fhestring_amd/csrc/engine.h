@@ -7,6 +7,7 @@
 // per level on one stream with no host round trip in between.
 #pragma once
 #include <cstdint>
+#include <map>
 #include <utility>
 #include <vector>
 
@@ -30,6 +31,7 @@ struct BlockNode {
     int32_t konst = 0;       // LIN: constant (mod 32)
     uint32_t level = 0;      // PBS depth since the last flush
     uint32_t refs = 0;
+    uint64_t ready_tick = 0; // MAT produced by a scheduled (not yet enqueued) job level: the tick that writes it
     Bid src = 0;             // PBS: input block
     uint64_t *dev = nullptr; // MAT: device ciphertext (2049 u64)
     std::vector<Term> terms; // LIN
@@ -69,6 +71,15 @@ class Engine {
     int64_t sum_c2(Bid b) const;
 
     int flush();
+    // ---- level-skewed batching of independent jobs (fhs_submit / fhs_pump) ----------------------------------------
+    // submit() plans the pending PBS as a JOB and schedules its dependency levels on consecutive TICKS starting at the
+    // next one (later if an input is produced by an earlier job that has not run yet); pump(n) enqueues the next n ticks,
+    // each as ONE launch group (lincomb -> keyswitch -> blind rotation) over the union of every job's level scheduled for
+    // it.  With one submit + one pump per request the narrow tail levels of request k ride in the wide launch of
+    // request k + 1 instead of paying one bootstrap latency each on an almost empty GPU.  flush() drains all ticks.
+    int submit();
+    int pump(size_t n_ticks);
+    bool has_scheduled() const { return !sched_.empty(); }
     // Level-parallel execution INSIDE the library (fhs_dist_level_parallel): every rank holds the same ciphertexts and
     // records the same DAG; flush() then runs slice [rank*cap, (rank+1)*cap) of every level, all-gathers the slices on
     // the context's stream (ctx.dist: RCCL, no host wait between levels) and installs the gathered level.
@@ -129,6 +140,18 @@ class Engine {
         std::vector<CaptureRec> recs;        // per planned PBS (only filled while capturing)
         size_t off_desc = 0, off_terms = 0, off_lut = 0, off_out = 0, max_width = 0;
     } plan_;
+
+    struct TickLevel {
+        std::vector<LinDesc> descs;       // first_term relative to `terms`
+        std::vector<LinTerm> terms;
+        std::vector<uint32_t> lut;
+        std::vector<uint64_t *> out;
+    };
+    std::map<uint64_t, std::vector<TickLevel>> sched_;            // tick -> job levels to run in that launch group
+    std::map<uint64_t, std::vector<uint64_t *>> free_after_;      // blocks reusable once that tick has been enqueued
+    uint64_t next_tick_ = 1, last_sched_tick_ = 0;
+    DevBuf tick_buf_;
+    int run_tick(std::vector<TickLevel> &levels);
 
     Bid new_node();
     int materialize_lin(Bid b);

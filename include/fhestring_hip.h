@@ -126,6 +126,15 @@ int fhs_flush(fhs_ctx *ctx);                                             /* run 
  * or the next fhs_flush waits).  Lets several contexts on one GPU overlap: the narrow tail levels of one
  * operation run beside the wide first level of the next (bench.py --pipelines). */
 int fhs_flush_async(fhs_ctx *ctx);
+/* Level-skewed batching of independent requests (a server's steady state).  fhs_submit plans everything recorded since
+ * the last submit / flush as one JOB and schedules its dependency levels on consecutive TICKS; fhs_pump(ctx, n) enqueues
+ * the next n ticks, each as ONE launch group over the union of every job's level scheduled for it.  With one submit + one
+ * pump per request, the narrow tail levels of request k ride in the wide launch of request k + 1 (a 64-char contains has
+ * levels 496 / 62 / 5 / 1 wide: alone, the last three pay one bootstrap latency each on an almost empty GPU).  A job
+ * that consumes results of an unfinished job is scheduled behind it.  Results are complete after fhs_flush (which
+ * drains every tick) or a download. */
+int fhs_submit(fhs_ctx *ctx);
+int fhs_pump(fhs_ctx *ctx, size_t n_ticks);
 int fhs_download(fhs_ctx *ctx, fhs_char_t a, uint64_t *blocks /*[4][2049]*/);
 /* device-to-device import/export of one char (multi-GPU gather of partial results) */
 int fhs_export_device(fhs_ctx *ctx, fhs_char_t a, uint64_t *d_blocks /*[4][2049] device*/);

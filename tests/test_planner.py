@@ -99,3 +99,29 @@ def test_split_beyond_u8_buffer_index_plans(sk):
     st = sk.stats()
     assert len(r.buffers) == 301 and st["max_input_sum_c2"] <= BUDGET
     assert st["pbs_executed"] < 3_000_000 and st["levels"] < 400
+
+
+def test_level_skewed_batching_schedule(sk):
+    """fhs_submit / fhs_pump: one submit + one pump per request puts level l of request k into the launch group of
+    request k + l - 1 (4 requests of a 64-char contains: widths 496 / 62 / 5 / 1 each)."""
+    sk.set_mode(1)
+    strings = [sk.dummy_string(65) for _ in range(4)]
+    sk.stats(reset=True)
+    keep = []
+    for s in strings:
+        keep.append(sk.contains_clear(s, "abcd"))
+        sk.submit()
+        sk.pump(1)
+    assert sk.level_widths() == [496, 62, 496, 5, 62, 496, 1, 5, 62, 496]        # ticks 1..4 (older jobs first)
+    sk.flush()                                                                   # drains ticks 5, 6, 7
+    assert sk.level_widths()[10:] == [1, 5, 62, 1, 5, 1]
+    st = sk.stats()
+    assert st["pbs_executed"] == 4 * 564 and st["levels"] == 16
+    # a job that consumes another job's result is scheduled behind it, not beside it
+    sk.stats(reset=True)
+    a = sk.contains_clear(strings[0], "abcd")
+    sk.submit()                                       # ticks t .. t+3, nothing pumped yet
+    b = sk.flags_or([a, keep[0]])                     # needs a's last level
+    sk.submit()
+    sk.flush()
+    assert sk.level_widths() == [496, 62, 5, 1, 1]
