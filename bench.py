@@ -59,9 +59,9 @@ def parse():
                          "two-prime exact NTT (library default).  The other one is timed too (other_arithmetic)")
     ap.add_argument("--pipelines", type=int, default=None,
                     help="0 = ONE context with level-skewed batching (fhs_submit + fhs_pump per step: the narrow tail "
-                         "levels of step k ride in the wide launch of step k+1; default for contains on one GPU); "
-                         "P >= 1 = P independent contexts (own HIP stream, scratch, block pool, communicator), step k on "
-                         "pipeline k mod P (default 3 for contains on several GPUs, 1 for the other ops)")
+                         "levels of step k ride in the wide launch of step k+1, and with several GPUs the exchange + OR "
+                         "of step k-4 too; default for contains); P >= 1 = P independent contexts (own HIP stream, "
+                         "scratch, block pool, communicator), step k on pipeline k mod P (default 1 for the other ops)")
     ap.add_argument("--repeats", type=int, default=5, help="extra repeats for the median (0 = skip)")
     ap.add_argument("--skip-secondary", action="store_true", help="do not time the other arithmetic")
     ap.add_argument("--skip-single-op", action="store_true", help="skip single-op latency / end-to-end / as-written")
@@ -79,7 +79,7 @@ def parse():
         a.strings = 8 if a.op == "contains" else 1
     if a.pipelines is None:
         world = int(os.environ.get("WORLD_SIZE", "1"))
-        a.pipelines = (0 if world == 1 else 3) if a.op == "contains" else 1
+        a.pipelines = 0 if a.op == "contains" else 1
     return a
 
 
@@ -355,8 +355,8 @@ def main():
                          "or more (src/server_key/mod.rs:1025-1027); lower --chars")
     ck = MyClientKey(SEED)                      # insecure seeded client: identical keys on every rank (synthetic data)
     SKEW = args.pipelines == 0
-    if SKEW and world > 1:
-        raise SystemExit("--pipelines 0 (level-skewed batching) is a single-GPU mode: the sharded ops flush at their exchange")
+    if SKEW and world > 1 and args.op != "contains":
+        raise SystemExit("--pipelines 0 (level-skewed batching) with several GPUs is implemented for contains only")
     P = max(1, args.pipelines)
     sks = [MyServerKey.from_client_key(ck, local_rank, arith=1) for _ in range(P)]   # Fourier-domain key as well
     ARITH = {"fft": sks[0].ctx.ARITH_F64_FFT, "exact": sks[0].ctx.ARITH_EXACT_NTT}
@@ -371,15 +371,37 @@ def main():
             D.level_parallel(True)
     step_no = [0]
 
+    import collections
+    inflight = collections.deque()           # skewed multi-GPU contains: local flags whose exchange is still to come
+    last_outs = [None]
+
+    def exchange_oldest():
+        """all-gather + OR of the oldest in-flight step: its local flags finished in a tick that is already enqueued,
+        so the exchange goes into the stream behind it and the OR level joins the next launch group"""
+        loc = inflight.popleft()
+        parts = dists[0].allgather_flags(loc)
+        last_outs[0] = [sks[0].flags_or([parts[r][i] for r in range(world)]) for i in range(len(loc))]
+
     def step():
         k = step_no[0] % P
         step_no[0] += 1
+        if SKEW and world > 1:
+            sk = sks[0]
+            local = [sk.contains_clear(sh, wl.pattern) if len(sh) >= wl.m else sk.trivial(0)
+                     for sh, _, _ in wl.inputs[0]["shards"]]
+            if len(inflight) >= 4:           # step j-4 finished its 4th level in tick j-1
+                exchange_oldest()
+            sk.submit()
+            sk.pump(1)
+            inflight.append(local)
+            return last_outs[0]
         outs = wl.step(k)
         if SKEW:                             # plan this step as a job, enqueue ONE launch group (this step's first level
             sks[0].submit()                  # + the later levels of the previous steps); drained by sync()
             sks[0].pump(1)
         else:
             sks[k].flush(wait=(P == 1))      # P > 1: enqueue only; sync() below waits for every stream
+        last_outs[0] = outs
         return outs
 
     def all_stats(reset=False):
@@ -408,6 +430,9 @@ def main():
     def sync():
         if SKEW:
             sks[0].flush(wait=False)         # drain the ticks still scheduled (the last steps' narrow levels)
+            while inflight:                  # ... and the exchanges + OR levels of the last steps
+                exchange_oldest()
+                sks[0].flush(wait=False)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -420,9 +445,9 @@ def main():
         t0 = time.perf_counter()
         outs = None
         for _ in range(n_steps):
-            outs = step()
+            step()
         sync()
-        return time.perf_counter() - t0, outs, all_stats(), all_timing()
+        return time.perf_counter() - t0, last_outs[0], all_stats(), all_timing()
 
     for _ in range(args.warmup):
         step()
@@ -480,7 +505,7 @@ def main():
         set_arith(other)
         for _ in range(P):
             step()
-        n2 = max(1, min(args.steps, 2 * P))
+        n2 = 6 if SKEW else max(1, min(args.steps, 2 * P))
         dt2, outs2, st2, kt2 = timed(n2)
         wl.check(outs2)
         secondary = {"arithmetic": other, "pbs_local": float(st2["pbs_executed"]), "dt": dt2, "steps": n2, "kt": kt2}

@@ -397,7 +397,22 @@ int Engine::gather_blocks(const Bid *local, size_t n, std::vector<Bid> &out) {
     if (!ctx.dist.active()) return ctx.fail(-3, "no distributed transport (fhs_dist_init)");
     if (n == 0) return 0;
     const size_t world = (size_t)ctx.dist.world, row = (size_t)BIG_CT * 8;
-    int rc = flush();                                             // the local DAG (or the level-parallel one)
+    // The partial blocks must be in the stream before the exchange is enqueued -- nothing more: unsubmitted work is
+    // submitted as a job and only the ticks that produce these blocks are pumped, so jobs of later requests that are
+    // scheduled (level-skewed batching) stay scheduled.  Level-parallel mode and linear-combination blocks drain.
+    int rc = 0;
+    bool drain = level_parallel;
+    if (!drain && !pending_.empty()) rc = submit();
+    if (rc) return rc;
+    uint64_t need = 0;
+    for (size_t k = 0; k < n; k++) {
+        const BlockNode &b = nodes_[local[k]];
+        if (b.kind == BlockNode::LIN || b.kind == BlockNode::PBS) drain = true;
+        else if (b.kind == BlockNode::MAT) need = std::max(need, b.ready_tick);
+    }
+    if (drain) rc = flush();
+    else
+        while (!rc && !sched_.empty() && sched_.begin()->first <= need) rc = pump(1);
     if (rc) return rc;
     if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
     if (ctx.xchg_send.cap < n * row || ctx.xchg_recv.cap < world * n * row) {
@@ -407,7 +422,7 @@ int Engine::gather_blocks(const Bid *local, size_t n, std::vector<Bid> &out) {
         if (e != hipSuccess) return ctx.hip_fail(e, "exchange buffers");
     }
     for (size_t k = 0; k < n; k++)
-        if ((rc = copy_block_to_device(local[k], ctx.xchg_send.as<uint64_t>() + k * BIG_CT, false))) return rc;
+        if ((rc = copy_block_to_device(local[k], ctx.xchg_send.as<uint64_t>() + k * BIG_CT, false, false))) return rc;
     if ((rc = ctx.dist.all_gather(ctx.xchg_send.ptr, ctx.xchg_recv.ptr, n * row, ctx.stream, ctx.err))) return rc;
     out.reserve(world * n);
     for (size_t i = 0; i < world * n; i++) {
@@ -664,10 +679,10 @@ int Engine::read_block(Bid b, uint64_t *host_out) {
     return 0;
 }
 
-int Engine::copy_block_to_device(Bid b, uint64_t *d_out, bool wait) {
+int Engine::copy_block_to_device(Bid b, uint64_t *d_out, bool wait, bool do_flush) {
     if (planner) return ctx.fail(-3, "planner context: nothing is computed");
     (void)hipSetDevice(ctx.device);
-    int rc = flush();
+    int rc = do_flush ? flush() : 0;
     if (rc) return rc;
     hipError_t e;
     if (nodes_[b].kind == BlockNode::TRIV) {

@@ -98,7 +98,8 @@ class Engine {
     int exec_level(size_t k, size_t lo, size_t hi, uint64_t *dense_out);
     int commit_level(size_t k, const uint64_t *d_all);
     int read_block(Bid b, uint64_t *host_out);        // flushes if needed
-    int copy_block_to_device(Bid b, uint64_t *d_out, bool wait = true);  // flushes if needed; wait=false: enqueue only
+    // flushes if needed (do_flush = false: the caller has made sure the block's tick is enqueued); wait=false: enqueue only
+    int copy_block_to_device(Bid b, uint64_t *d_out, bool wait = true, bool do_flush = true);
     uint64_t blocks_live() const { return live_dev_blocks_; }
 
     // ---- debug: capture of PBS inputs (the linear-combination results entering keyswitch) ----

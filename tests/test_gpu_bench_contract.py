@@ -63,3 +63,22 @@ def test_bench_other_ops(op):
     d = _run("--op", op, "--cpu-pbs", "0", "--skip-secondary", "--repeats", "0", "--skip-single-op")
     assert d["scaling"] == "strong" and d["value"] > 5_000
     assert op.split("_")[0] in d["config"]["workload"]
+
+
+@pytest.mark.parametrize("extra", [[], ["--pipelines", "3"], ["--op", "find_enc"], ["--op", "replace", "--chars", "96"],
+                                   ["--op", "le", "--chars", "256"]],
+                         ids=["contains_skewed", "contains_pipelines", "find_enc", "replace_level_parallel", "le"])
+def test_bench_two_ranks_on_one_gpu(extra):
+    """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one rank per process), rehearsed
+    with two ranks sharing this GPU: FHS_BENCH_BACKEND=gloo makes the library carry its all-gathers through the host
+    transport (RCCL refuses two ranks on one device); everything else is the code the 8-GPU run executes."""
+    env = dict(os.environ, FHS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--cpu-pbs", "0", "--skip-secondary", "--skip-extras", "--repeats", "0"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 1000 and "GPU(s)" in d["config"]["parallelism"]
