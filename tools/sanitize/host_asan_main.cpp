@@ -102,6 +102,30 @@ int main() {
         uint64_t blocks[FHS_CHAR_WORDS];
         CHECK(fhs_download(c, r, blocks) == FHS_ERR_STATE);      // a planner computes nothing
     }
+    {   // level-skewed batching: jobs on ticks, dependent jobs, handles released while their levels are still scheduled
+        CHECK(fhs_set_mode(c, 1) == FHS_OK);
+        std::vector<fhs_char_t> keep;
+        for (int k = 0; k < 6; k++) {
+            auto s = dummy(c, 30);
+            fhs_char_t r = 0, f = 0;
+            CHECK(fhs_str_contains_clear(c, s.data(), s.size(), "abc", 3, &r) == FHS_OK);
+            CHECK(fhs_str_find_clear(c, s.data(), s.size(), "abc", 3, &f) == FHS_OK);
+            CHECK(fhs_submit(c) == FHS_OK);
+            for (fhs_char_t h : s) CHECK(fhs_release(c, h) == FHS_OK);      // inputs dropped before their ticks run
+            if (k & 1) CHECK(fhs_release(c, f) == FHS_OK); else keep.push_back(f);
+            if (!keep.empty() && k == 3) {                                   // a job consuming an unfinished job
+                fhs_char_t e = fhs_eq(c, keep[0], r);
+                CHECK(e != 0 && fhs_submit(c) == FHS_OK);
+                keep.push_back(e);
+            }
+            keep.push_back(r);
+            CHECK(fhs_pump(c, 1) == FHS_OK);
+        }
+        CHECK(fhs_flush(c) == FHS_OK);
+        size_t nl = 0;
+        CHECK(fhs_level_widths(c, nullptr, 0, &nl) == FHS_OK && nl > 20);
+        for (fhs_char_t h : keep) CHECK(fhs_release(c, h) == FHS_OK);
+    }
     fhs_stats st;
     CHECK(fhs_get_stats(c, &st) == FHS_OK && st.pbs_executed > 1000 && st.max_input_sum_c2 <= FHS_NOISE_BUDGET_SUM_C2);
     size_t w0, w1, c0, c1;
