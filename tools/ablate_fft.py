@@ -29,7 +29,12 @@ VARIANTS = {
 }
 VARIANTS["hb2"] = [("constexpr int HB = 4;", "constexpr int HB = 2;")]
 VARIANTS["hb8"] = [("constexpr int HB = 4;", "constexpr int HB = 8;")]
-FLAGS = {"sched_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+P1, P2, P0 = "__builtin_amdgcn_s_setprio(1);", "__builtin_amdgcn_s_setprio(2);", "__builtin_amdgcn_s_setprio(0);"
+VARIANTS["prio_2_3_0"] = [(P2, "__builtin_amdgcn_s_setprio(3);"), (P1, "__builtin_amdgcn_s_setprio(2);")]
+VARIANTS["prio_0_2_1"] = [(P0, "__builtin_amdgcn_s_setprio(9);"), (P1, P0), ("__builtin_amdgcn_s_setprio(9);", P1)]
+VARIANTS["prio_1_3_0"] = [(P2, "__builtin_amdgcn_s_setprio(3);")]
+VARIANTS["prio_2_3_1"] = [(P0, "__builtin_amdgcn_s_setprio(9);"), (P2, "__builtin_amdgcn_s_setprio(3);"), (P1, P2), ("__builtin_amdgcn_s_setprio(9);", P1)]
+FLAGS = {"sched_default": [], "sched_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
          "sched_memclause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]}
 VARIANTS["sched_maxilp"] = []
 VARIANTS["sched_memclause"] = []
@@ -50,7 +55,7 @@ def build():
         open(src, "w").write(t)
         obj = src.replace(".hip", ".o")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", SRC,
-                               "-Wno-unused-function", "-c", src, "-o", obj] + FLAGS.get(name, []))
+                               "-Wno-unused-function", "-c", src, "-o", obj] + FLAGS.get(name, ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]))
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
                                os.path.join(OUT, "libfhs_%s.so" % name), obj] + objs + ["-lpthread", "-ldl"])
         os.remove(obj)
