@@ -243,7 +243,7 @@ class CaptureRec(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("pbs_executed", C.c_uint64), ("pbs_folded", C.c_uint64), ("levels", C.c_uint64),
-                ("max_level_width", C.c_uint64), ("blocks_live", C.c_uint64), ("max_input_sum_c2", C.c_uint64)]
+                ("max_level_width", C.c_uint64), ("blocks_live", C.c_uint64), ("max_input_sum_c2", C.c_uint64), ("pbs_shared", C.c_uint64)]
 
 
 def fft_tables():

@@ -413,6 +413,7 @@ int fhs_get_stats(fhs_ctx *c, fhs_stats *out) {
     out->max_level_width = c->eng.stats.max_level_width;
     out->blocks_live = c->eng.blocks_live();
     out->max_input_sum_c2 = c->eng.stats.max_input_sum_c2;
+    out->pbs_shared = c->eng.stats.pbs_shared;
     return FHS_OK;
 }
 int fhs_level_widths(fhs_ctx *c, uint32_t *out, size_t cap, size_t *n) {

@@ -74,7 +74,9 @@ Bid Engine::new_node() {
         nodes_.emplace_back();
     }
     BlockNode &n = nodes_[id];
+    const uint32_t g = n.gen + 1;
     n = BlockNode();
+    n.gen = g;
     n.refs = 1;
     return id;
 }
@@ -194,6 +196,34 @@ Bid Engine::pbs(Bid x, int lut) {
         return triv(lut_eval(lut, s.triv));
     }
     const uint32_t lvl = s.level + 1;
+    // fused mode: an identical bootstrap (same LUT on the same linear combination of the same blocks) is computed once,
+    // e.g. the high-nibble test of a character against pattern characters that share their high nibble
+    std::vector<int64_t> key;
+    uint64_t h = 0;
+    if (mode == 1 && (s.kind == BlockNode::LIN || s.kind == BlockNode::MAT || s.kind == BlockNode::PBS)) {
+        key.push_back(lut);
+        if (s.kind == BlockNode::LIN) {
+            key.push_back(s.konst);
+            std::vector<Term> ts(s.terms);
+            std::sort(ts.begin(), ts.end(), [](const Term &a, const Term &b) { return a.blk < b.blk; });
+            for (const Term &t : ts) { key.push_back(t.blk); key.push_back(nodes_[t.blk].gen); key.push_back(t.coef); }
+        } else {
+            key.push_back(0); key.push_back(x); key.push_back(s.gen); key.push_back(1);
+        }
+        for (int64_t v : key) h = (h ^ (uint64_t)v) * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull;
+        auto it = cse_.find(h);
+        if (it != cse_.end())
+            for (auto &e : it->second)
+                if (e.first == key) {
+                    const Bid id = e.second.first;
+                    const BlockNode &c = nodes_[id];
+                    if (c.gen == e.second.second && c.refs > 0 && (c.kind == BlockNode::PBS || c.kind == BlockNode::MAT)) {
+                        stats.pbs_shared++;
+                        retain(id);
+                        return id;
+                    }
+                }
+    }
     retain(x);
     Bid id = new_node();
     BlockNode &n = nodes_[id];
@@ -202,6 +232,14 @@ Bid Engine::pbs(Bid x, int lut) {
     n.lut = (uint16_t)lut;
     n.level = lvl;
     pending_.push_back(id);
+    if (!key.empty()) {
+        if (cse_entries_ > (1u << 21)) { cse_.clear(); cse_entries_ = 0; }   // bounded: stale entries are only dead weight
+        auto &bucket = cse_[h];
+        bool replaced = false;
+        for (auto &e : bucket)
+            if (e.first == key) { e.second = {id, n.gen}; replaced = true; }
+        if (!replaced) { bucket.push_back({std::move(key), {id, n.gen}}); cse_entries_++; }
+    }
     return id;
 }
 

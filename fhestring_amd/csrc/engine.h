@@ -8,6 +8,7 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -31,6 +32,7 @@ struct BlockNode {
     int32_t konst = 0;       // LIN: constant (mod 32)
     uint32_t level = 0;      // PBS depth since the last flush
     uint32_t refs = 0;
+    uint32_t gen = 0;        // bumped every time the slot is handed out again (common-subexpression table keys)
     uint64_t ready_tick = 0; // MAT produced by a scheduled (not yet enqueued) job level: the tick that writes it
     Bid src = 0;             // PBS: input block
     uint64_t *dev = nullptr; // MAT: device ciphertext (2049 u64)
@@ -39,6 +41,7 @@ struct BlockNode {
 
 struct EngineStats {
     uint64_t pbs_executed = 0, pbs_folded = 0, levels = 0, max_level_width = 0;
+    uint64_t pbs_shared = 0;         // bootstraps not run because an identical one (same input combination, same LUT) exists
     uint64_t max_input_sum_c2 = 0;   // largest sum of squared coefficients of any executed bootstrap's input
     std::vector<uint32_t> level_widths;   // width of every dependency level executed since the last reset (capped)
 };
@@ -153,6 +156,11 @@ class Engine {
     uint64_t next_tick_ = 1, last_sched_tick_ = 0;
     DevBuf tick_buf_;
     int run_tick(std::vector<TickLevel> &levels);
+
+    // Common-subexpression table of the fused string layer: (LUT, constant, [(block, generation, coefficient)...]) ->
+    // the bootstrap node that already computes it.  Nodes are immutable, so an entry stays valid while its node lives.
+    std::unordered_map<uint64_t, std::vector<std::pair<std::vector<int64_t>, std::pair<Bid, uint32_t>>>> cse_;
+    size_t cse_entries_ = 0;
 
     Bid new_node();
     int materialize_lin(Bid b);

@@ -780,13 +780,14 @@ std::vector<Ref> Strings::block_eq_flags(const FChar &a_in, const FChar &b_in) {
     std::vector<Ref> f;
     for (int h = 0; h < 2; h++) {
         Ref *blk[4] = {&a.b[2 * h], &a.b[2 * h + 1], &b.b[2 * h], &b.b[2 * h + 1]};
-        const int64_t w2[4] = {1, 16, 1, 16};
-        int64_t tot = 0;
-        for (int k = 0; k < 4; k++) tot += w2[k] * e_->sum_c2(blk[k]->id());
-        if (tot > FHS_NOISE_BUDGET_SUM_C2)
+        Ref d = lin(e_, {{1, &a.b[2 * h]}, {4, &a.b[2 * h + 1]}, {-1, &b.b[2 * h]}, {-4, &b.b[2 * h + 1]}});
+        // measured on the FLATTENED combination: blocks that share bootstrap outputs (common subexpressions) add
+        // their coefficients before squaring
+        if (e_->sum_c2(d.id()) > FHS_NOISE_BUDGET_SUM_C2) {
             for (int k = 0; k < 4; k++)
                 if (e_->sum_c2(blk[k]->id()) > 1) *blk[k] = pbs(*blk[k], LUT_MSG);
-        Ref d = lin(e_, {{1, &a.b[2 * h]}, {4, &a.b[2 * h + 1]}, {-1, &b.b[2 * h]}, {-4, &b.b[2 * h + 1]}});
+            d = lin(e_, {{1, &a.b[2 * h]}, {4, &a.b[2 * h + 1]}, {-1, &b.b[2 * h]}, {-4, &b.b[2 * h + 1]}});
+        }
         f.push_back(pbs(d, LUT_IS0));
     }
     return f;

@@ -287,6 +287,9 @@ typedef struct {
     uint64_t max_input_sum_c2; /* largest sum of squared coefficients of a bootstrap's input (flattened linear
                                 * combination of bootstrap outputs / uploads): its noise variance in units of one
                                 * bootstrap output's.  The string layer keeps it <= FHS_NOISE_BUDGET_SUM_C2. */
+    uint64_t pbs_shared;       /* fused mode: PBS not run because an identical one (same LUT on the same linear combination
+                                * of the same blocks) already exists -- e.g. the high-nibble tests of one character
+                                * against pattern characters that share their high nibble */
 } fhs_stats;
 /* Design rule of the fused DAGs: with a measured bootstrap-output sigma of 2^48.9 a sum with
  * sum c^2 <= 64 adds sigma <= 2^51.9 to the 2^55.2 of keyswitch + modulus switch (+0.8 %): the reference parameter

@@ -60,8 +60,10 @@ def test_config_dag_shapes(sk):
         assert st["max_input_sum_c2"] <= BUDGET, st
         return st, sk.level_widths()
     s65, s257, p4 = sk.dummy_string(65), sk.dummy_string(257), sk.dummy_string(4)
-    st, w = run(lambda: sk.contains_clear(s65, "abcd"))
+    st, w = run(lambda: sk.contains_clear(s65, "a2S$"))               # no two pattern characters share a nibble
     assert (st["pbs_executed"], st["levels"]) == (564, 4) and w == [496, 62, 5, 1]
+    st, w = run(lambda: sk.contains_clear(s65, "abcd"))               # one shared high nibble: tested once per position
+    assert st["pbs_executed"] + st["pbs_shared"] == 564 and w == [313, 62, 5, 1]
     st, w = run(lambda: sk.find(s257, p4))
     assert st["pbs_executed"] < 3200 and st["levels"] <= 12
     s1025, f5, t5 = sk.dummy_string(1025), sk.dummy_string(5), sk.dummy_string(5)
@@ -109,7 +111,7 @@ def test_level_skewed_batching_schedule(sk):
     sk.stats(reset=True)
     keep = []
     for s in strings:
-        keep.append(sk.contains_clear(s, "abcd"))
+        keep.append(sk.contains_clear(s, "a2S$"))
         sk.submit()
         sk.pump(1)
     assert sk.level_widths() == [496, 62, 496, 5, 62, 496, 1, 5, 62, 496]        # ticks 1..4 (older jobs first)
@@ -119,7 +121,7 @@ def test_level_skewed_batching_schedule(sk):
     assert st["pbs_executed"] == 4 * 564 and st["levels"] == 16
     # a job that consumes another job's result is scheduled behind it, not beside it
     sk.stats(reset=True)
-    a = sk.contains_clear(strings[0], "abcd")
+    a = sk.contains_clear(strings[0], "b3T%")
     sk.submit()                                       # ticks t .. t+3, nothing pumped yet
     b = sk.flags_or([a, keep[0]])                     # needs a's last level
     sk.submit()
