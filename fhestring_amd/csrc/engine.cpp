@@ -33,6 +33,11 @@ void Engine::shutdown() {
     free_blocks_.clear();
     if (d_luts_) (void)hipFree(d_luts_);
     d_luts_ = nullptr;
+    for (Staging &c : staging_) {
+        if (c.done) (void)hipEventDestroy(c.done);
+        if (c.p) (void)hipHostFree(c.p);
+    }
+    staging_.clear();
     plan_buf_.release();
     tick_buf_.release();
     batch_in_.release();
@@ -343,6 +348,33 @@ int Engine::pump(size_t n_ticks) {
     return 0;
 }
 
+int Engine::upload_plan(void *d_dst, const void *src, size_t bytes) {
+    Staging *st = nullptr;
+    for (Staging &c : staging_)
+        if (!c.busy || hipEventQuery(c.done) == hipSuccess) { c.busy = false; if (!st || c.cap >= bytes) st = &c; }
+    if (!st && staging_.size() < 8) { staging_.emplace_back(); st = &staging_.back(); }
+    if (!st) {                                           // every buffer is in flight: wait for the oldest
+        st = &staging_[0];
+        if (hipEventSynchronize(st->done) != hipSuccess) return ctx.fail(-2, "staging wait failed");
+        st->busy = false;
+    }
+    if (st->cap < bytes) {
+        if (st->p) (void)hipHostFree(st->p);
+        st->p = nullptr; st->cap = 0;
+        const size_t want = std::max(bytes + bytes / 2, (size_t)1 << 20);
+        if (hipHostMalloc(&st->p, want) != hipSuccess) return ctx.fail(-2, "hipHostMalloc (plan staging) failed");
+        st->cap = want;
+    }
+    if (!st->done && hipEventCreateWithFlags(&st->done, hipEventDisableTiming) != hipSuccess)
+        return ctx.fail(-2, "hipEventCreate failed");
+    std::memcpy(st->p, src, bytes);
+    hipError_t e = hipMemcpyAsync(d_dst, st->p, bytes, hipMemcpyHostToDevice, ctx.stream);
+    if (e == hipSuccess) e = hipEventRecord(st->done, ctx.stream);
+    if (e != hipSuccess) return ctx.hip_fail(e, "plan upload");
+    st->busy = true;
+    return 0;
+}
+
 // one launch group over the union of the job levels scheduled for a tick
 int Engine::run_tick(std::vector<TickLevel> &levels) {
     size_t width = 0, n_terms = 0;
@@ -390,9 +422,8 @@ int Engine::run_tick(std::vector<TickLevel> &levels) {
         if (e == hipSuccess) e = ctx.ks_buf.reserve(width * SMALL_CT * 8);
     }
     if (e != hipSuccess) return ctx.hip_fail(e, "tick buffers");
-    // stream-ordered after the previous tick's kernels, which read the old contents (pageable source: consumed on return)
-    e = hipMemcpyAsync(tick_buf_.ptr, host.data(), total, hipMemcpyHostToDevice, ctx.stream);
-    if (e != hipSuccess) return ctx.hip_fail(e, "tick plan upload");
+    // stream-ordered after the previous tick's kernels, which read the old contents; pinned staging: the host goes on
+    if (int rc = upload_plan(tick_buf_.ptr, host.data(), total)) return rc;
     const uint8_t *dp = tick_buf_.as<uint8_t>();
     e = launch_lincomb(reinterpret_cast<const LinDesc *>(dp + off_desc), reinterpret_cast<const LinTerm *>(dp + off_terms),
                        batch_in_.as<uint64_t>(), (int)width, ctx.stream);
@@ -575,8 +606,7 @@ int Engine::plan_flush() {
     hipError_t e = plan_buf_.cap >= total ? hipSuccess : hipStreamSynchronize(ctx.stream);
     if (e == hipSuccess) e = plan_buf_.reserve(total);
     if (e != hipSuccess) return ctx.hip_fail(e, "plan buffer");
-    e = hipMemcpyAsync(plan_buf_.ptr, host.data(), total, hipMemcpyHostToDevice, ctx.stream);
-    if (e != hipSuccess) return ctx.hip_fail(e, "plan upload");
+    if (int rc = upload_plan(plan_buf_.ptr, host.data(), total)) return rc;
     if (batch_in_.cap < max_width * BIG_CT * 8) {
         e = hipStreamSynchronize(ctx.stream);
         if (e == hipSuccess) e = batch_in_.reserve(max_width * BIG_CT * 8);

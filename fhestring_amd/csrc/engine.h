@@ -156,6 +156,12 @@ class Engine {
     uint64_t next_tick_ = 1, last_sched_tick_ = 0;
     DevBuf tick_buf_;
     int run_tick(std::vector<TickLevel> &levels);
+    // Pinned staging for plan uploads: a hipMemcpyAsync from PAGEABLE memory blocks the host until the stream reaches
+    // the copy, i.e. until the previous launch group has finished -- the host could never plan ahead of the GPU.  A small
+    // ring of pinned buffers, each guarded by an event recorded after its copy, keeps the upload asynchronous.
+    struct Staging { void *p = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+    std::vector<Staging> staging_;
+    int upload_plan(void *d_dst, const void *src, size_t bytes);
 
     // Common-subexpression table of the fused string layer: (LUT, constant, [(block, generation, coefficient)...]) ->
     // the bootstrap node that already computes it.  Nodes are immutable, so an entry stays valid while its node lives.
