@@ -511,6 +511,23 @@ def main():
         secondary = {"arithmetic": other, "pbs_local": float(st2["pbs_executed"]), "dt": dt2, "steps": n2, "kt": kt2}
         set_arith(args.arith)
 
+    # the same workload with twice the strings per step (one GPU, default run): how much of the gap to the kernel-only
+    # rate is batch size (narrow-level drain, keyswitch and the emptier last round of a launch group weigh half as much)
+    larger = None
+    if args.op == "contains" and SKEW and world == 1 and not args.skip_extras and args.mode == "fused":
+        big = Workload(args, ck, sks[:1], dists[:1], rank, world, strings=2 * args.strings)
+        saved = wl
+        wl = big
+        for _ in range(3):
+            step()
+        n3 = 8
+        dtb, outsb, stb, _ = timed(n3)
+        big.check(outsb)
+        larger = {"strings_per_step": big.n_strings, "value": stb["pbs_executed"] / dtb, "unit": "PBS/s",
+                  "ms_per_step": dtb / n3 * 1e3, "ms_per_op": dtb / n3 / big.n_strings * 1e3, "steps": n3}
+        wl = saved
+        del big
+
     # BASELINE configs 3-5 at their fixed sizes, once each over the same ranks (default run only)
     extras = None
     if args.op == "contains" and not args.skip_extras and args.mode == "fused":
@@ -630,6 +647,8 @@ def main():
                 "ms_per_step": secondary["dt"] / secondary["steps"] * 1e3,
                 "roofline": roofline_for(okern, k2[0]["pbs"] / max(1, k2[0]["n"]), k2[0]["ms"], k2[0]["n"], counters,
                                          traffic.get(okern + "_hbm_bytes_per_launch"))}
+        if larger:
+            line["larger_batch"] = larger
         if extras:
             line["configs"] = {}
             names = {"find_enc": "cfg3_find_encrypted_256", "replace": "cfg4_replace_1024",

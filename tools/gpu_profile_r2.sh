@@ -1,7 +1,9 @@
 #!/bin/bash
-# round 2, GPU call H: final profiles of the committed kernels (stats, SQ counters, fabric traffic) + default bench
+# round-2 profile recipe (ONE gpurun call): kernel stats, SQ counters (three passes for the FFT kernel, two for the exact
+# kernel), fabric traffic (one TCC-derived counter per pass) under the bench command; summaries go to profiles/ through
+# tools/pmc_to_json.py and tools/traffic_to_json.py
 set -o pipefail
-O=gpurun_out/r2h
+O=gpurun_out/profile_r2
 mkdir -p $O
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
