@@ -196,6 +196,8 @@ def _declare(L):
     L.fhs_debug_capture_pbs_inputs.restype = i
     L.fhs_debug_capture_read.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.fhs_debug_capture_read.restype = i
+    L.fhs_set_auto_flush.argtypes = [vp, sz]
+    L.fhs_set_auto_flush.restype = i
     L.fhs_submit.argtypes = [vp]
     L.fhs_submit.restype = i
     L.fhs_pump.argtypes = [vp, sz]

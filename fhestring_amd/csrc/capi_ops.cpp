@@ -127,6 +127,11 @@ int fhs_flush(fhs_ctx *c) {
     if (hipStreamSynchronize(c->eng.ctx.stream) != hipSuccess) return c->eng.ctx.fail(FHS_ERR_HIP, "stream sync failed");
     return FHS_OK;
 }
+int fhs_set_auto_flush(fhs_ctx *c, size_t n_pending) {
+    if (!c) return FHS_ERR_ARG;
+    c->eng.auto_flush_pending = n_pending;
+    return FHS_OK;
+}
 int fhs_submit(fhs_ctx *c) {
     if (!c) return FHS_ERR_ARG;
     return c->eng.submit();

@@ -89,6 +89,10 @@ Bid Engine::new_node() {
 void Engine::retain(Bid b) { nodes_[b].refs++; }
 
 void Engine::release(Bid b) {
+    if (nodes_[b].refs > 1) {                                 // the common case: no heap traffic, nothing dies
+        nodes_[b].refs--;
+        return;
+    }
     // iterative: chains of pending nodes can be tens of thousands deep (as-written `len`)
     std::vector<Bid> stack{b};
     while (!stack.empty()) {
@@ -203,31 +207,36 @@ Bid Engine::pbs(Bid x, int lut) {
     const uint32_t lvl = s.level + 1;
     // fused mode: an identical bootstrap (same LUT on the same linear combination of the same blocks) is computed once,
     // e.g. the high-nibble test of a character against pattern characters that share their high nibble
-    std::vector<int64_t> key;
-    uint64_t h = 0;
-    if (mode == 1 && (s.kind == BlockNode::LIN || s.kind == BlockNode::MAT || s.kind == BlockNode::PBS)) {
-        key.push_back(lut);
+    uint64_t h1 = 0, h2 = 0;
+    const bool share = mode == 1;
+    if (share) {
+        auto mix = [](uint64_t v, uint64_t k) {
+            v = (v ^ (v >> 31)) * k;
+            v = (v ^ (v >> 29)) * 0xBF58476D1CE4E5B9ull;
+            return v ^ (v >> 32);
+        };
+        auto term = [&](uint64_t blk, uint64_t gen, int64_t coef) {      // commutative: the order of terms is irrelevant
+            const uint64_t v = (blk << 32 | gen) + 0x9E3779B97F4A7C15ull * (uint64_t)coef;
+            h1 += mix(v, 0x94D049BB133111EBull);
+            h2 += mix(v + 0x632BE59BD9B4E019ull, 0xD6E8FEB86659FD93ull);
+        };
         if (s.kind == BlockNode::LIN) {
-            key.push_back(s.konst);
-            std::vector<Term> ts(s.terms);
-            std::sort(ts.begin(), ts.end(), [](const Term &a, const Term &b) { return a.blk < b.blk; });
-            for (const Term &t : ts) { key.push_back(t.blk); key.push_back(nodes_[t.blk].gen); key.push_back(t.coef); }
-        } else {
-            key.push_back(0); key.push_back(x); key.push_back(s.gen); key.push_back(1);
+            for (const Term &t : s.terms) term(t.blk, nodes_[t.blk].gen, t.coef);
+            h1 += mix((uint64_t)(uint32_t)s.konst + 77, 0x94D049BB133111EBull);
+            h2 += mix((uint64_t)(uint32_t)s.konst + 131, 0xD6E8FEB86659FD93ull);
+        } else term(x, s.gen, 1);
+        h1 = mix(h1 + (uint64_t)lut * 0x9E3779B97F4A7C15ull, 0xD6E8FEB86659FD93ull);
+        h2 = mix(h2 ^ ((uint64_t)lut << 40), 0x94D049BB133111EBull);
+        auto it = cse_.find(h1);
+        if (it != cse_.end() && it->second.h2 == h2) {
+            const Bid id = it->second.id;
+            const BlockNode &c = nodes_[id];
+            if (c.gen == it->second.gen && c.refs > 0 && (c.kind == BlockNode::PBS || c.kind == BlockNode::MAT)) {
+                stats.pbs_shared++;
+                retain(id);
+                return id;
+            }
         }
-        for (int64_t v : key) h = (h ^ (uint64_t)v) * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull;
-        auto it = cse_.find(h);
-        if (it != cse_.end())
-            for (auto &e : it->second)
-                if (e.first == key) {
-                    const Bid id = e.second.first;
-                    const BlockNode &c = nodes_[id];
-                    if (c.gen == e.second.second && c.refs > 0 && (c.kind == BlockNode::PBS || c.kind == BlockNode::MAT)) {
-                        stats.pbs_shared++;
-                        retain(id);
-                        return id;
-                    }
-                }
     }
     retain(x);
     Bid id = new_node();
@@ -237,13 +246,16 @@ Bid Engine::pbs(Bid x, int lut) {
     n.lut = (uint16_t)lut;
     n.level = lvl;
     pending_.push_back(id);
-    if (!key.empty()) {
-        if (cse_entries_ > (1u << 21)) { cse_.clear(); cse_entries_ = 0; }   // bounded: stale entries are only dead weight
-        auto &bucket = cse_[h];
-        bool replaced = false;
-        for (auto &e : bucket)
-            if (e.first == key) { e.second = {id, n.gen}; replaced = true; }
-        if (!replaced) { bucket.push_back({std::move(key), {id, n.gen}}); cse_entries_++; }
+    if (auto_flush_pending && pending_.size() >= auto_flush_pending && !manual_jobs_ && !capture_max_rows &&
+        !in_auto_flush_ && sched_.empty() && !(dist_world > 1 && !level_parallel) && (planner || ctx.key_loaded)) {
+        in_auto_flush_ = true;                                // everything recorded so far starts running now
+        (void)plan_job(true);                                 // an error here resurfaces at the caller's flush
+        in_auto_flush_ = false;
+    }
+    if (share) {
+        if (cse_.empty()) cse_.reserve(1u << 18);
+        if (cse_.size() > (1u << 21)) cse_.clear();           // bounded: stale entries are only dead weight
+        cse_[h1] = CseEntry{h2, id, n.gen};
     }
     return id;
 }
@@ -254,10 +266,14 @@ Bid Engine::pbs(Bid x, int lut) {
 int Engine::flush() {
     while (!sched_.empty())                                   // drain the scheduled ticks of submitted jobs first
         if (int rc = pump(1)) return rc;
-    if (level_parallel && ctx.dist.active()) return flush_level_parallel();   // world 1 too: same stream-ordered path
+    if (level_parallel && ctx.dist.active()) {                // world 1 too: same stream-ordered path
+        if (!ctx.dist.active()) return ctx.fail(-3, "level-parallel flush without a transport (fhs_dist_init)");
+        return plan_job(true);
+    }
     if (dist_world > 1 && !pending_.empty())
         return ctx.fail(-3, "distributed context: pending PBS must be run with fhs_flush_plan/level_exec/level_commit");
-    int rc = plan_flush();
+    if (!capture_max_rows) return plan_job(true);             // level by level: planning overlaps execution
+    int rc = plan_flush();                                    // capture mode: the all-at-once plan keeps the records
     if (rc) return rc;
     for (size_t k = 0; k < plan_.levels.size(); k++)
         if ((rc = exec_level(k, 0, plan_.levels[k].count, nullptr))) return rc;
@@ -268,9 +284,10 @@ int Engine::flush() {
 // ------------------------------------------------------------------------------------------
 // level-skewed batching: jobs, ticks
 // ------------------------------------------------------------------------------------------
-int Engine::submit() {
+int Engine::plan_job(bool run_now) {
     if (pending_.empty()) return 0;
-    if (level_parallel && ctx.dist.active()) return ctx.fail(-3, "fhs_submit is not available in level-parallel mode");
+    if (!run_now && level_parallel && ctx.dist.active())
+        return ctx.fail(-3, "fhs_submit is not available in level-parallel mode");
     if (!planner && !ctx.key_loaded) return ctx.fail(-3, "server key not loaded");
     std::map<uint32_t, std::vector<Bid>> by_level;
     for (Bid b : pending_)
@@ -312,6 +329,22 @@ int Engine::submit() {
             uint64_t *o = alloc_block();
             if (!o) return ctx.fail(-2, "device block pool exhausted (hipMalloc failed)");
             tl.out.push_back(o);
+        }
+        if (run_now) {
+            // nothing is scheduled (flush drained it): enqueue this level right away, then plan the next one meanwhile
+            std::vector<TickLevel> one;
+            one.push_back(std::move(tl));
+            if (int rc = run_tick(one, level_parallel && ctx.dist.active())) return rc;
+            for (size_t k = 0; k < lv.size(); k++) {
+                BlockNode &n = nodes_[lv[k]];
+                const Bid src = n.src;
+                n.kind = BlockNode::MAT;
+                n.dev = one[0].out[k];
+                n.src = 0;
+                n.level = 0;
+                release(src);                                // immediate recycling is safe: stream order
+            }
+            continue;
         }
         tick = std::max(tick + 1, need + 1);
         last_sched_tick_ = std::max(last_sched_tick_, tick);  // before the releases below: their frees wait for this tick
@@ -376,7 +409,7 @@ int Engine::upload_plan(void *d_dst, const void *src, size_t bytes) {
 }
 
 // one launch group over the union of the job levels scheduled for a tick
-int Engine::run_tick(std::vector<TickLevel> &levels) {
+int Engine::run_tick(std::vector<TickLevel> &levels, bool sharded) {
     size_t width = 0, n_terms = 0;
     for (auto &l : levels) { width += l.descs.size(); n_terms += l.terms.size(); }
     if (width == 0) return 0;
@@ -385,7 +418,10 @@ int Engine::run_tick(std::vector<TickLevel> &levels) {
         if (stats.level_widths.size() < (1u << 20)) stats.level_widths.push_back((uint32_t)l.descs.size());
         stats.max_level_width = std::max<uint64_t>(stats.max_level_width, l.descs.size());
     }
-    stats.pbs_executed += width;
+    const size_t world = sharded ? (size_t)ctx.dist.world : 1, rank = sharded ? (size_t)ctx.dist.rank : 0;
+    const size_t cap = (width + world - 1) / world;
+    const size_t lo = std::min(width, rank * cap), hi = std::min(width, lo + cap), cnt = hi - lo;
+    stats.pbs_executed += cnt;
     if (planner) return 0;
     if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
     const size_t off_desc = 0;
@@ -425,39 +461,34 @@ int Engine::run_tick(std::vector<TickLevel> &levels) {
     // stream-ordered after the previous tick's kernels, which read the old contents; pinned staging: the host goes on
     if (int rc = upload_plan(tick_buf_.ptr, host.data(), total)) return rc;
     const uint8_t *dp = tick_buf_.as<uint8_t>();
-    e = launch_lincomb(reinterpret_cast<const LinDesc *>(dp + off_desc), reinterpret_cast<const LinTerm *>(dp + off_terms),
-                       batch_in_.as<uint64_t>(), (int)width, ctx.stream);
-    if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
-    if (int rc = ctx.keyswitch(batch_in_.as<uint64_t>(), width, ctx.stream)) return rc;
-    return ctx.blind_rotate(ctx.ks_buf.as<uint64_t>(), reinterpret_cast<const uint32_t *>(dp + off_lut), d_luts_, nullptr,
-                            reinterpret_cast<uint64_t *const *>(dp + off_out), width, ctx.stream);
-}
-
-// All levels and all exchanges are enqueued back to back: with RCCL nothing waits on the host.
-int Engine::flush_level_parallel() {
-    int rc = plan_flush();
-    if (rc) return rc;
-    if (plan_.levels.empty()) return 0;
-    if (!ctx.dist.active()) return ctx.fail(-3, "level-parallel flush without a transport (fhs_dist_init)");
-    const size_t world = (size_t)ctx.dist.world, rank = (size_t)ctx.dist.rank;
-    const size_t cap_max = (plan_.max_width + world - 1) / world;
-    if (ctx.xchg_send.cap < cap_max * BIG_CT * 8 || ctx.xchg_recv.cap < world * cap_max * BIG_CT * 8) {
-        hipError_t e = hipStreamSynchronize(ctx.stream);          // queued work may still read the old buffers
-        if (e == hipSuccess) e = ctx.xchg_send.reserve(cap_max * BIG_CT * 8);
-        if (e == hipSuccess) e = ctx.xchg_recv.reserve(world * cap_max * BIG_CT * 8);
+    const LinDesc *d_desc = reinterpret_cast<const LinDesc *>(dp + off_desc);
+    const LinTerm *d_terms = reinterpret_cast<const LinTerm *>(dp + off_terms);
+    const uint32_t *d_lut = reinterpret_cast<const uint32_t *>(dp + off_lut);
+    uint64_t *const *d_out = reinterpret_cast<uint64_t *const *>(dp + off_out);
+    if (!sharded) {
+        e = launch_lincomb(d_desc, d_terms, batch_in_.as<uint64_t>(), (int)width, ctx.stream);
+        if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
+        if (int rc = ctx.keyswitch(batch_in_.as<uint64_t>(), width, ctx.stream)) return rc;
+        return ctx.blind_rotate(ctx.ks_buf.as<uint64_t>(), d_lut, d_luts_, nullptr, d_out, width, ctx.stream);
+    }
+    // level-parallel: own slice -> dense exchange buffer -> all-gather -> scatter (all enqueued, no host wait with RCCL)
+    if (ctx.xchg_send.cap < cap * BIG_CT * 8 || ctx.xchg_recv.cap < world * cap * BIG_CT * 8) {
+        e = hipStreamSynchronize(ctx.stream);
+        if (e == hipSuccess) e = ctx.xchg_send.reserve(cap * BIG_CT * 8);
+        if (e == hipSuccess) e = ctx.xchg_recv.reserve(world * cap * BIG_CT * 8);
         if (e != hipSuccess) return ctx.hip_fail(e, "level exchange buffers");
     }
-    const size_t n_levels = plan_.levels.size();
-    for (size_t k = 0; k < n_levels; k++) {
-        const size_t w = plan_.levels[k].count, cap = (w + world - 1) / world;
-        const size_t lo = std::min(w, rank * cap), hi = std::min(w, lo + cap);
-        if ((rc = exec_level(k, lo, hi, ctx.xchg_send.as<uint64_t>()))) return rc;
-        if (hi == lo) { stats.levels += 1; }                      // a rank without a slice still takes part
-        if ((rc = ctx.dist.all_gather(ctx.xchg_send.ptr, ctx.xchg_recv.ptr, cap * BIG_CT * 8, ctx.stream, ctx.err)))
+    if (cnt) {
+        e = launch_lincomb(d_desc + lo, d_terms, batch_in_.as<uint64_t>(), (int)cnt, ctx.stream);
+        if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
+        if (int rc = ctx.keyswitch(batch_in_.as<uint64_t>(), cnt, ctx.stream)) return rc;
+        if (int rc = ctx.blind_rotate(ctx.ks_buf.as<uint64_t>(), d_lut + lo, d_luts_, ctx.xchg_send.as<uint64_t>(), nullptr, cnt,
+                                      ctx.stream))
             return rc;
-        if ((rc = commit_level(k, ctx.xchg_recv.as<uint64_t>()))) return rc;
     }
-    plan_.levels.clear();
+    if (int rc = ctx.dist.all_gather(ctx.xchg_send.ptr, ctx.xchg_recv.ptr, cap * BIG_CT * 8, ctx.stream, ctx.err)) return rc;
+    e = launch_scatter_blocks(ctx.xchg_recv.as<uint64_t>(), d_out, (int)width, ctx.stream);
+    if (e != hipSuccess) return ctx.hip_fail(e, "scatter launch");
     return 0;
 }
 

@@ -80,7 +80,12 @@ class Engine {
     // each as ONE launch group (lincomb -> keyswitch -> blind rotation) over the union of every job's level scheduled for
     // it.  With one submit + one pump per request the narrow tail levels of request k ride in the wide launch of
     // request k + 1 instead of paying one bootstrap latency each on an almost empty GPU.  flush() drains all ticks.
-    int submit();
+    // Automatic partial flush: once this many bootstraps are pending, what has been recorded so far is planned and
+    // enqueued while the caller keeps building the rest of the DAG (a 1024-character replace records 256 k bootstraps in
+    // ~0.25 s of host time: without this the GPU idles through all of it, and with 8 GPUs that is longer than the
+    // computation).  0 = off.  Not used while jobs are being scheduled by hand (submit / pump) or inputs are captured.
+    size_t auto_flush_pending = 16384;
+    int submit() { manual_jobs_ = true; return plan_job(false); }
     int pump(size_t n_ticks);
     bool has_scheduled() const { return !sched_.empty(); }
     // Level-parallel execution INSIDE the library (fhs_dist_level_parallel): every rank holds the same ciphertexts and
@@ -154,8 +159,15 @@ class Engine {
     std::map<uint64_t, std::vector<TickLevel>> sched_;            // tick -> job levels to run in that launch group
     std::map<uint64_t, std::vector<uint64_t *>> free_after_;      // blocks reusable once that tick has been enqueued
     uint64_t next_tick_ = 1, last_sched_tick_ = 0;
+    bool manual_jobs_ = false;           // the caller schedules jobs itself (fhs_submit): no automatic partial flushes
+    bool in_auto_flush_ = false;
     DevBuf tick_buf_;
-    int run_tick(std::vector<TickLevel> &levels);
+    // sharded: level-parallel mode -- this rank runs slice [rank*cap, (rank+1)*cap) of the group into the exchange buffer,
+    // the slices are all-gathered on the stream and scattered into the nodes' blocks
+    int run_tick(std::vector<TickLevel> &levels, bool sharded = false);
+    // plans the pending PBS level by level; run_now: every level is enqueued as soon as it is planned (the host plans level
+    // k + 1 while the GPU runs level k), otherwise the levels are scheduled on ticks (submit)
+    int plan_job(bool run_now);
     // Pinned staging for plan uploads: a hipMemcpyAsync from PAGEABLE memory blocks the host until the stream reaches
     // the copy, i.e. until the previous launch group has finished -- the host could never plan ahead of the GPU.  A small
     // ring of pinned buffers, each guarded by an event recorded after its copy, keeps the upload asynchronous.
@@ -165,12 +177,13 @@ class Engine {
 
     // Common-subexpression table of the fused string layer: (LUT, constant, [(block, generation, coefficient)...]) ->
     // the bootstrap node that already computes it.  Nodes are immutable, so an entry stays valid while its node lives.
-    std::unordered_map<uint64_t, std::vector<std::pair<std::vector<int64_t>, std::pair<Bid, uint32_t>>>> cse_;
-    size_t cse_entries_ = 0;
+    // Keys are 128-bit order-independent hashes of the terms (two independent 64-bit mixes: a false match needs both to
+    // collide, ~2^-128 per pair), so a lookup allocates nothing.
+    struct CseEntry { uint64_t h2; Bid id; uint32_t gen; };
+    std::unordered_map<uint64_t, CseEntry> cse_;
 
     Bid new_node();
     int materialize_lin(Bid b);
-    int flush_level_parallel();
 };
 
 // RAII reference to a block

@@ -134,6 +134,11 @@ int fhs_flush_async(fhs_ctx *ctx);
  * that consumes results of an unfinished job is scheduled behind it.  Results are complete after fhs_flush (which
  * drains every tick) or a download. */
 int fhs_submit(fhs_ctx *ctx);
+/* Automatic partial flush: once `n_pending` bootstraps are recorded, they are planned and enqueued while the caller keeps
+ * recording the rest of the operation (default 16384; 0 = off).  Hides the host time of building large DAGs (a
+ * 1024-character replace records 256 k bootstraps) behind GPU work.  Contexts driven with fhs_submit never flush on
+ * their own. */
+int fhs_set_auto_flush(fhs_ctx *ctx, size_t n_pending);
 int fhs_pump(fhs_ctx *ctx, size_t n_ticks);
 int fhs_download(fhs_ctx *ctx, fhs_char_t a, uint64_t *blocks /*[4][2049]*/);
 /* device-to-device import/export of one char (multi-GPU gather of partial results) */
