@@ -420,6 +420,10 @@ class MyServerKey:
         """fhs_pump: enqueue the next n ticks (one launch group each over every job's level scheduled for it)."""
         self.ctx._check(self.ctx._L.fhs_pump(self.ctx._h, int(n_ticks)))
 
+    def set_auto_flush(self, n_depth1):
+        """fhs_set_auto_flush: peel the ready level once n_depth1 bootstraps of it are recorded (0 = off)."""
+        self.ctx._check(self.ctx._L.fhs_set_auto_flush(self.ctx._h, int(n_depth1)))
+
     def stream_sync(self):
         self.ctx._check(self.ctx._L.fhs_stream_sync(self.ctx._h))
 

@@ -33,6 +33,8 @@ void Engine::shutdown() {
     free_blocks_.clear();
     if (d_luts_) (void)hipFree(d_luts_);
     d_luts_ = nullptr;
+    if (last_group_done_) (void)hipEventDestroy(last_group_done_);
+    last_group_done_ = nullptr;
     for (Staging &c : staging_) {
         if (c.done) (void)hipEventDestroy(c.done);
         if (c.p) (void)hipHostFree(c.p);
@@ -208,7 +210,8 @@ Bid Engine::pbs(Bid x, int lut) {
     // fused mode: an identical bootstrap (same LUT on the same linear combination of the same blocks) is computed once,
     // e.g. the high-nibble test of a character against pattern characters that share their high nibble
     uint64_t h1 = 0, h2 = 0;
-    const bool share = mode == 1;
+    static const bool no_cse = std::getenv("FHS_NO_CSE") != nullptr;      // debugging switch
+    const bool share = mode == 1 && !no_cse;
     if (share) {
         auto mix = [](uint64_t v, uint64_t k) {
             v = (v ^ (v >> 31)) * k;
@@ -245,12 +248,23 @@ Bid Engine::pbs(Bid x, int lut) {
     n.src = x;
     n.lut = (uint16_t)lut;
     n.level = lvl;
-    pending_.push_back(id);
-    if (auto_flush_pending && pending_.size() >= auto_flush_pending && !manual_jobs_ && !capture_max_rows &&
-        !in_auto_flush_ && sched_.empty() && !(dist_world > 1 && !level_parallel) && (planner || ctx.key_loaded)) {
-        in_auto_flush_ = true;                                // everything recorded so far starts running now
-        (void)plan_job(true);                                 // an error here resurfaces at the caller's flush
-        in_auto_flush_ = false;
+    pending_.push_back({id, n.gen});
+    if (lvl == 1) n_depth1_++;
+    static const bool no_auto = std::getenv("FHS_NO_AUTO_FLUSH") != nullptr;   // debugging switch
+    if (auto_flush_pending && !no_auto && !manual_jobs_ && !capture_max_rows && !in_auto_flush_ &&
+        sched_.empty() && !(dist_world > 1 && !level_parallel) && (planner || ctx.key_loaded)) {
+        // peel the ready level when a whole batch has accumulated -- or, on a real device, as soon as a grid's worth is
+        // ready and the previous launch group has finished (polled every 256 recorded bootstraps): the GPU never idles
+        // while the host is still recording, and nothing narrower than one full round of workgroups is launched early
+        // (level-parallel ranks must all take the same decisions: there only the deterministic count rule applies)
+        bool go = n_depth1_ >= auto_flush_pending;
+        if (!go && n_depth1_ >= 1024 && !planner && !level_parallel && last_group_done_ && (++idle_poll_ & 255) == 0)
+            go = hipEventQuery(last_group_done_) == hipSuccess;
+        if (go) {
+            in_auto_flush_ = true;
+            (void)plan_job(true, true);                       // an error here resurfaces at the caller's flush
+            in_auto_flush_ = false;
+        }
     }
     if (share) {
         if (cse_.empty()) cse_.reserve(1u << 18);
@@ -284,15 +298,32 @@ int Engine::flush() {
 // ------------------------------------------------------------------------------------------
 // level-skewed batching: jobs, ticks
 // ------------------------------------------------------------------------------------------
-int Engine::plan_job(bool run_now) {
+int Engine::plan_job(bool run_now, bool first_level_only) {
     if (pending_.empty()) return 0;
     if (!run_now && level_parallel && ctx.dist.active())
         return ctx.fail(-3, "fhs_submit is not available in level-parallel mode");
     if (!planner && !ctx.key_loaded) return ctx.fail(-3, "server key not loaded");
     std::map<uint32_t, std::vector<Bid>> by_level;
-    for (Bid b : pending_)
-        if (nodes_[b].kind == BlockNode::PBS) by_level[nodes_[b].level].push_back(b);
-    pending_.clear();
+    if (first_level_only) {
+        // peel depth 1 only: the other pending nodes stay pending, one level shallower than before
+        std::vector<Pend> rest;
+        n_depth1_ = 0;
+        for (const Pend &p : pending_) {
+            BlockNode &n = nodes_[p.id];
+            if (n.kind != BlockNode::PBS || n.gen != p.gen) continue;
+            if (n.level <= 1) by_level[1].push_back(p.id);
+            else {
+                if (--n.level == 1) n_depth1_++;
+                rest.push_back(p);
+            }
+        }
+        pending_.swap(rest);
+    } else {
+        for (const Pend &p : pending_)
+            if (nodes_[p.id].kind == BlockNode::PBS && nodes_[p.id].gen == p.gen) by_level[nodes_[p.id].level].push_back(p.id);
+        pending_.clear();
+        n_depth1_ = 0;
+    }
     uint64_t tick = next_tick_ - 1;                           // the job's first level goes to next_tick_ at the earliest
     for (auto &kv : by_level) {
         std::vector<Bid> &lv = kv.second;
@@ -321,7 +352,10 @@ int Engine::plan_job(bool run_now) {
                 d.n_terms = (uint32_t)s.terms.size();
                 d.konst_body = (uint64_t)(s.konst & 31) << DELTA_LOG;
             } else {
-                return ctx.fail(-3, "internal: PBS source is neither MAT nor LIN");
+                return ctx.fail(-3, "internal: PBS source is neither MAT nor LIN (node " + std::to_string(b) + " level " +
+                                        std::to_string(n.level) + " lut " + std::to_string(n.lut) + ", source " +
+                                        std::to_string(n.src) + " kind " + std::to_string((int)s.kind) + " level " +
+                                        std::to_string(s.level) + " refs " + std::to_string(s.refs) + ")");
             }
             stats.max_input_sum_c2 = std::max<uint64_t>(stats.max_input_sum_c2, (uint64_t)c2);
             tl.descs.push_back(d);
@@ -469,7 +503,10 @@ int Engine::run_tick(std::vector<TickLevel> &levels, bool sharded) {
         e = launch_lincomb(d_desc, d_terms, batch_in_.as<uint64_t>(), (int)width, ctx.stream);
         if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
         if (int rc = ctx.keyswitch(batch_in_.as<uint64_t>(), width, ctx.stream)) return rc;
-        return ctx.blind_rotate(ctx.ks_buf.as<uint64_t>(), d_lut, d_luts_, nullptr, d_out, width, ctx.stream);
+        if (int rc = ctx.blind_rotate(ctx.ks_buf.as<uint64_t>(), d_lut, d_luts_, nullptr, d_out, width, ctx.stream)) return rc;
+        if (!last_group_done_) (void)hipEventCreateWithFlags(&last_group_done_, hipEventDisableTiming);
+        if (last_group_done_) (void)hipEventRecord(last_group_done_, ctx.stream);
+        return 0;
     }
     // level-parallel: own slice -> dense exchange buffer -> all-gather -> scatter (all enqueued, no host wait with RCCL)
     if (ctx.xchg_send.cap < cap * BIG_CT * 8 || ctx.xchg_recv.cap < world * cap * BIG_CT * 8) {
@@ -489,6 +526,8 @@ int Engine::run_tick(std::vector<TickLevel> &levels, bool sharded) {
     if (int rc = ctx.dist.all_gather(ctx.xchg_send.ptr, ctx.xchg_recv.ptr, cap * BIG_CT * 8, ctx.stream, ctx.err)) return rc;
     e = launch_scatter_blocks(ctx.xchg_recv.as<uint64_t>(), d_out, (int)width, ctx.stream);
     if (e != hipSuccess) return ctx.hip_fail(e, "scatter launch");
+    if (!last_group_done_) (void)hipEventCreateWithFlags(&last_group_done_, hipEventDisableTiming);
+    if (last_group_done_) (void)hipEventRecord(last_group_done_, ctx.stream);
     return 0;
 }
 
@@ -548,9 +587,10 @@ int Engine::plan_flush() {
     }
 
     std::map<uint32_t, std::vector<Bid>> by_level;
-    for (Bid b : pending_)
-        if (nodes_[b].kind == BlockNode::PBS) by_level[nodes_[b].level].push_back(b);
+    for (const Pend &p : pending_)
+        if (nodes_[p.id].kind == BlockNode::PBS && nodes_[p.id].gen == p.gen) by_level[nodes_[p.id].level].push_back(p.id);
     pending_.clear();
+    n_depth1_ = 0;
     if (by_level.empty()) return 0;
 
     std::vector<LevelPlan> &levels = plan_.levels;

@@ -80,11 +80,12 @@ class Engine {
     // each as ONE launch group (lincomb -> keyswitch -> blind rotation) over the union of every job's level scheduled for
     // it.  With one submit + one pump per request the narrow tail levels of request k ride in the wide launch of
     // request k + 1 instead of paying one bootstrap latency each on an almost empty GPU.  flush() drains all ticks.
-    // Automatic partial flush: once this many bootstraps are pending, what has been recorded so far is planned and
-    // enqueued while the caller keeps building the rest of the DAG (a 1024-character replace records 256 k bootstraps in
-    // ~0.25 s of host time: without this the GPU idles through all of it, and with 8 GPUs that is longer than the
-    // computation).  0 = off.  Not used while jobs are being scheduled by hand (submit / pump) or inputs are captured.
-    size_t auto_flush_pending = 16384;
+    // Automatic partial flush: once this many pending bootstraps have all their inputs available (depth 1), THAT level is
+    // planned and enqueued while the caller keeps building the rest of the DAG; deeper nodes stay pending (their depth
+    // drops by one), so the narrow later levels still merge across the whole operation.  A 1024-character replace records
+    // 256 k bootstraps in ~0.25 s of host time: without this the GPU idles through all of it, and with 8 GPUs that is as
+    // long as the computation.  0 = off.  Not used while jobs are scheduled by hand (submit / pump) or inputs are captured.
+    size_t auto_flush_pending = 8192;
     int submit() { manual_jobs_ = true; return plan_job(false); }
     int pump(size_t n_ticks);
     bool has_scheduled() const { return !sched_.empty(); }
@@ -128,7 +129,8 @@ class Engine {
   private:
     std::vector<BlockNode> nodes_{1};   // slot 0 reserved
     std::vector<Bid> free_nodes_;
-    std::vector<Bid> pending_;
+    struct Pend { Bid id; uint32_t gen; };                    // gen: a released pending node's slot may be reused before
+    std::vector<Pend> pending_;                               // the flush; the stale entry must not stand for the new node
     std::vector<CharRec> chars_;
     std::vector<uint64_t> free_chars_;
 
@@ -167,7 +169,10 @@ class Engine {
     int run_tick(std::vector<TickLevel> &levels, bool sharded = false);
     // plans the pending PBS level by level; run_now: every level is enqueued as soon as it is planned (the host plans level
     // k + 1 while the GPU runs level k), otherwise the levels are scheduled on ticks (submit)
-    int plan_job(bool run_now);
+    int plan_job(bool run_now, bool first_level_only = false);
+    size_t n_depth1_ = 0;                // pending bootstraps whose inputs are all available
+    hipEvent_t last_group_done_ = nullptr;   // recorded behind every launch group: tells whether the GPU has run dry
+    uint32_t idle_poll_ = 0;
     // Pinned staging for plan uploads: a hipMemcpyAsync from PAGEABLE memory blocks the host until the stream reaches
     // the copy, i.e. until the previous launch group has finished -- the host could never plan ahead of the GPU.  A small
     // ring of pinned buffers, each guarded by an event recorded after its copy, keeps the upload asynchronous.

@@ -134,10 +134,12 @@ int fhs_flush_async(fhs_ctx *ctx);
  * that consumes results of an unfinished job is scheduled behind it.  Results are complete after fhs_flush (which
  * drains every tick) or a download. */
 int fhs_submit(fhs_ctx *ctx);
-/* Automatic partial flush: once `n_pending` bootstraps are recorded, they are planned and enqueued while the caller keeps
- * recording the rest of the operation (default 16384; 0 = off).  Hides the host time of building large DAGs (a
- * 1024-character replace records 256 k bootstraps) behind GPU work.  Contexts driven with fhs_submit never flush on
- * their own. */
+/* Automatic partial flush: once `n_pending` bootstraps whose inputs are all available (dependency depth 1) are recorded,
+ * that level is planned and enqueued while the caller keeps recording the rest of the operation; the other pending
+ * bootstraps stay pending, one level shallower (default 8192; 0 = off).  On a device the level is also peeled as soon as
+ * a grid's worth (1024) is ready and the previous launch group has finished.  Hides the host time of building large
+ * DAGs (a 1024-character replace records 256 k bootstraps) behind GPU work.  Contexts driven with fhs_submit never
+ * flush on their own. */
 int fhs_set_auto_flush(fhs_ctx *ctx, size_t n_pending);
 int fhs_pump(fhs_ctx *ctx, size_t n_ticks);
 int fhs_download(fhs_ctx *ctx, fhs_char_t a, uint64_t *blocks /*[4][2049]*/);

@@ -55,3 +55,31 @@ def test_job_consuming_an_unfinished_job(product):
     mid = sk.len(a)                              # a plain flush in between drains what is scheduled
     assert ck.decrypt_char(mid) == 11
     assert ck.decrypt_char(same) == 1 and ck.decrypt_char(other) == 1 and ck.decrypt(low) == "hello world"
+
+
+def test_automatic_partial_flush_decrypts_correctly(product):
+    """fhs_set_auto_flush with a tiny threshold: the ready level is peeled hundreds of times while the DAGs are still
+    being recorded (released pending nodes whose slots are reused, shared bootstraps, intermediate drops)."""
+    ck, sk = product
+    sk.set_auto_flush(48)
+    try:
+        rnd = random.Random(5)
+        t = "".join(chr(rnd.randint(0x61, 0x7A)) for _ in range(96))
+        t = t[:20] + "~from" + t[25:60] + "~from" + t[65:]
+        es = ck.encrypt(t, 1, None, sk)
+        sk.stats(reset=True)
+        rep = sk.replace(es, ck.encrypt_no_padding("~from", sk), ck.encrypt_no_padding("[to]", sk))
+        tmp = sk.to_upper(es)
+        del tmp                                      # recorded, partly run, then dropped
+        pos = sk.rfind(es, ck.encrypt_no_padding("~from", sk))
+        parts = sk.split(ck.encrypt("a,b,,c", 1, None, sk), ck.encrypt_no_padding(",", sk))
+        sk.flush()
+        st = sk.stats()
+        assert ck.decrypt(rep) == t.replace("~from", "[to]")
+        assert ck.decrypt_char(pos) == t.rfind("~from")
+        from fhestring_amd.api import FheSplit
+        bufs, found = FheSplit.decrypt(parts, ck)
+        assert found == 1 and bufs[:4] == ["a", "b", "", "c"] and all(b == "" for b in bufs[4:])
+        assert st["max_input_sum_c2"] <= 64 and st["levels"] > 200
+    finally:
+        sk.set_auto_flush(8192)

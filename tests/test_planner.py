@@ -127,3 +127,26 @@ def test_level_skewed_batching_schedule(sk):
     sk.submit()
     sk.flush()
     assert sk.level_widths() == [496, 62, 5, 1, 1]
+
+
+def test_automatic_partial_flush_plans_the_same_bootstraps(sk):
+    """fhs_set_auto_flush: the depth-1 level is peeled while the DAG is still being recorded.  With a threshold of 64 a
+    256-char replace is peeled hundreds of times -- released pending nodes whose slots are reused in between, shared
+    (CSE) nodes and stale LIN levels included -- and must plan the same DAG.  (Counts differ a little: a result that is
+    dropped before the one-shot flush is never computed, and one that has already run and been recycled cannot be shared
+    with a later identical request.)"""
+    sk.set_mode(1)
+    def run(threshold):
+        sk.set_auto_flush(threshold)
+        s, f, t = sk.dummy_string(257), sk.dummy_string(5), sk.dummy_string(5)
+        sk.stats(reset=True)
+        keep = [sk.replace(s, f, t), sk.find(s, f), sk.split(sk.dummy_string(33), sk.dummy_string(2))]
+        sk.flush()
+        st = sk.stats()
+        assert st["max_input_sum_c2"] <= BUDGET
+        return st["pbs_executed"], st["pbs_shared"], st["levels"]
+    one_shot = run(0)
+    peeled = run(64)
+    assert one_shot[0] > 10_000 and one_shot[0] <= peeled[0] <= 1.1 * one_shot[0]
+    assert peeled[2] > one_shot[2]                     # more, narrower launches: it really did peel
+    sk.set_auto_flush(8192)
