@@ -16,6 +16,7 @@ def product(request):
     ck = MyClientKey(SEED)
     sk = ck.get_server_key(0, arith=1 if request.param == "f64_fft" else 0)
     sk.set_mode(1)
+    sk.test_arith = 1 if request.param == "f64_fft" else 0
     yield ck, sk
     sk.close()
     ck.close()
@@ -60,7 +61,9 @@ def test_job_consuming_an_unfinished_job(product):
 def test_automatic_partial_flush_decrypts_correctly(product):
     """fhs_set_auto_flush with a tiny threshold: the ready level is peeled hundreds of times while the DAGs are still
     being recorded (released pending nodes whose slots are reused, shared bootstraps, intermediate drops)."""
-    ck, sk = product
+    ck, shared = product
+    sk = ck.get_server_key(0, arith=shared.test_arith)    # a context driven with fhs_submit never flushes on its own: fresh one
+    sk.set_mode(1)
     sk.set_auto_flush(48)
     try:
         rnd = random.Random(5)
@@ -82,4 +85,4 @@ def test_automatic_partial_flush_decrypts_correctly(product):
         assert found == 1 and bufs[:4] == ["a", "b", "", "c"] and all(b == "" for b in bufs[4:])
         assert st["max_input_sum_c2"] <= 64 and st["levels"] > 200
     finally:
-        sk.set_auto_flush(8192)
+        sk.close()
