@@ -220,6 +220,12 @@ def _declare(L):
     L.fhs_client_bsk.restype = C.POINTER(C.c_uint64)
     L.fhs_client_ksk.argtypes = [vp]
     L.fhs_client_ksk.restype = C.POINTER(C.c_uint64)
+    L.fhs_client_bsk_mb2.argtypes = [vp]
+    L.fhs_client_bsk_mb2.restype = C.POINTER(C.c_uint64)
+    L.fhs_debug_blind_rotate_batch.argtypes = [vp, vp, vp, vp, sz, vp, sz]
+    L.fhs_debug_blind_rotate_batch.restype = i
+    L.fhs_load_multibit_key.argtypes = [vp, vp]
+    L.fhs_load_multibit_key.restype = i
     L.fhs_client_encrypt_char.argtypes = [vp, u8, vp]
     L.fhs_client_encrypt_char.restype = i
     L.fhs_client_decrypt_char.argtypes = [vp, vp, C.POINTER(u8)]

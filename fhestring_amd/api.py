@@ -50,9 +50,11 @@ class Context:
 
     ARITH_EXACT_NTT = 0
     ARITH_F64_FFT = 1
+    ARITH_F64_FFT_MB2 = 2
 
     def set_arithmetic(self, arith):
-        """fhs_set_arithmetic: ARITH_EXACT_NTT (default) or ARITH_F64_FFT (select before load_server_key)."""
+        """fhs_set_arithmetic: 0 ARITH_EXACT_NTT (default), 1 ARITH_F64_FFT, 2 ARITH_F64_FFT_MB2 (select before
+        load_server_key; mode 2 also needs load_multibit_key)."""
         self._check(self._L.fhs_set_arithmetic(self._h, int(arith)))
 
     def set_fft4_max_batch(self, n):
@@ -68,6 +70,22 @@ class Context:
         ksk = np.ascontiguousarray(ksk, np.uint64)
         assert bsk.size == 742 * 4 * 2048 and ksk.size == 2048 * 5 * 743
         self._check(self._L.fhs_load_server_key(self._h, _ptr(bsk), _ptr(ksk)))
+
+    def blind_rotate_batch(self, ks, lut_idx, luts):
+        """fhs_debug_blind_rotate_batch: blind rotation + sample extraction from given keyswitched LWEs [B, 743]."""
+        ks = np.ascontiguousarray(ks, np.uint64).reshape(-1, 743)
+        luts = np.ascontiguousarray(luts, np.uint64).reshape(-1, POLY_N)
+        lut_idx = np.ascontiguousarray(lut_idx, np.uint32)
+        out = np.zeros((ks.shape[0], BIG_CT), np.uint64)
+        self._check(self._L.fhs_debug_blind_rotate_batch(self._h, _ptr(ks), _ptr(lut_idx), _ptr(luts), luts.shape[0],
+                                                         _ptr(out), ks.shape[0]))
+        return out
+
+    def load_multibit_key(self, bsk_mb2):
+        """fhs_load_multibit_key: pair key of ARITH_F64_FFT_MB2, after load_server_key in arithmetic 1 or 2."""
+        bsk_mb2 = np.ascontiguousarray(bsk_mb2, np.uint64)
+        assert bsk_mb2.size == 371 * 3 * 4 * 2048
+        self._check(self._L.fhs_load_multibit_key(self._h, _ptr(bsk_mb2)))
 
     def pbs_batch(self, cts, lut_idx, luts):
         cts = np.ascontiguousarray(cts, np.uint64).reshape(-1, BIG_CT)
@@ -177,6 +195,10 @@ class MyClientKey:
 
     def ksk(self):
         return np.ctypeslib.as_array(self._L.fhs_client_ksk(self._h), shape=(2048 * 5 * 743,))
+
+    def bsk_mb2(self):
+        """fhs_client_bsk_mb2: pair key of ARITH_F64_FFT_MB2 (generated on first use)."""
+        return np.ctypeslib.as_array(self._L.fhs_client_bsk_mb2(self._h), shape=(371 * 3 * 4 * 2048,))
 
     def secret_keys(self):
         lwe = np.zeros(742, np.uint64)
@@ -347,6 +369,8 @@ class MyServerKey:
         ctx = Context(device_id)
         ctx.set_arithmetic(arith)
         ctx.load_server_key(client_key.bsk(), client_key.ksk())
+        if arith == 2:
+            ctx.load_multibit_key(client_key.bsk_mb2())
         return cls(ctx)
 
     @classmethod
@@ -367,10 +391,12 @@ class MyServerKey:
         return cls(ctx)
 
     @classmethod
-    def from_raw_keys(cls, bsk, ksk, device_id=0, arith=0):
+    def from_raw_keys(cls, bsk, ksk, device_id=0, arith=0, bsk_mb2=None):
         ctx = Context(device_id)
         ctx.set_arithmetic(arith)
         ctx.load_server_key(bsk, ksk)
+        if bsk_mb2 is not None:
+            ctx.load_multibit_key(bsk_mb2)
         return cls(ctx)
 
     def close(self):

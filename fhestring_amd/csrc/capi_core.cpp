@@ -45,6 +45,13 @@ int fhs_load_server_key(fhs_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk) 
     return ctx->eng.on_key_loaded();
 }
 
+int fhs_load_multibit_key(fhs_ctx *ctx, const uint64_t *bsk_mb2) {
+    if (!ctx) return FHS_ERR_ARG;
+    if (ctx->eng.planner) return FHS_OK;
+    if (int rc = ctx->eng.flush()) return rc;
+    return ctx->eng.ctx.load_multibit_key(bsk_mb2);
+}
+
 int fhs_set_arithmetic(fhs_ctx *ctx, int arith) {
     if (!ctx) return FHS_ERR_ARG;
     if (int rc = ctx->eng.flush()) return rc;   // pending work runs in the arithmetic it was built under
@@ -68,6 +75,12 @@ void fhs_fft_tables(double *w_re, double *w_im, double *u_re, double *u_im) {
     std::copy(t.u_im.begin(), t.u_im.end(), u_im);
 }
 
+void fhs_fft_mono_table(double *mono /*[4096][2]*/) {
+    fhs::HostFftTables t;
+    fhs::build_fft_tables(t);
+    std::copy(t.mono.begin(), t.mono.end(), mono);
+}
+
 int fhs_read_server_key_file(const char *path, std::vector<uint64_t> &bsk, std::vector<uint64_t> &ksk);
 
 int fhs_load_server_key_file(fhs_ctx *ctx, const char *path) {
@@ -82,6 +95,13 @@ int fhs_pbs_batch(fhs_ctx *ctx, const uint64_t *in, const uint32_t *lut_idx, con
                   size_t n_luts, uint64_t *out, size_t B) {
     if (!ctx) return FHS_ERR_ARG;
     return ctx->eng.ctx.pbs_batch_host(in, lut_idx, luts, n_luts, out, B);
+}
+
+int fhs_debug_blind_rotate_batch(fhs_ctx *ctx, const uint64_t *ks, const uint32_t *lut_idx, const uint64_t *luts,
+                                 size_t n_luts, uint64_t *out, size_t B) {
+    if (!ctx) return FHS_ERR_ARG;
+    if (ctx->eng.planner) return ctx->eng.ctx.fail(FHS_ERR_STATE, "planner context: nothing is computed");
+    return ctx->eng.ctx.blind_rotate_host(ks, lut_idx, luts, n_luts, out, B);
 }
 
 int fhs_keyswitch_modswitch_batch(fhs_ctx *ctx, const uint64_t *in, uint32_t *ms_out, size_t B) {

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -104,6 +105,8 @@ struct fhs_client {
     uint64_t seed = 0;            // only meaningful for insecure seeded clients (0 otherwise); kept in key files
     ChaKey key{};
     std::vector<uint64_t> lwe_sk, glwe_sk, bsk, ksk;
+    std::vector<uint64_t> bsk_mb2;   // pair key of FHS_ARITH_F64_FFT_MB2, generated on first use
+    std::mutex mb2_mu;
     Rng enc_mask, enc_noise;      // encryption streams: public masks and noise never share a stream
 };
 
@@ -168,6 +171,39 @@ void keygen(fhs_client *ck) {
     for (auto &x : th) x.join();
 }
 
+// Pair key of the two-bits-per-product blind rotation (fftmb_kernels.hip): for every pair (s, s') = (lwe_sk[2p],
+// lwe_sk[2p+1]) three GGSWs, of s(1-s'), (1-s)s' and s s', with the bootstrapping key's own parameters (GLWE noise, one
+// level of base 2^23, 58-bit grid) and their own mask / noise streams.
+void keygen_mb2(fhs_client *ck) {
+    ck->bsk_mb2.assign((size_t)(LWE_N / 2) * 3 * 4 * POLY_N, 0);
+    const uint64_t qmask = ~((1ull << BSK_QUANT_BITS) - 1), qhalf = 1ull << (BSK_QUANT_BITS - 1);
+    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    auto work = [&](unsigned tid) {
+        std::vector<uint64_t> prod(POLY_N);
+        for (int g = tid; g < (LWE_N / 2) * 3; g += nt) {
+            const int p = g / 3, t = g % 3;
+            const uint64_t s1 = ck->lwe_sk[2 * p], s2 = ck->lwe_sk[2 * p + 1];
+            const uint64_t msg = t == 0 ? s1 & (1 - s2) : t == 1 ? (1 - s1) & s2 : s1 & s2;
+            Rng gm(ck->key, 2000000 + g, DOM_MASK), e(ck->key, 2000000 + g, DOM_NOISE);
+            for (int row = 0; row < 2; row++) {
+                uint64_t *mask = ck->bsk_mb2.data() + (((size_t)g * 2 + row) * 2 + 0) * POLY_N;
+                uint64_t *body = mask + POLY_N;
+                for (int n = 0; n < POLY_N; n++) mask[n] = gm.next() & qmask;
+                mul_binary(mask, ck->glwe_sk.data(), prod.data());
+                for (int n = 0; n < POLY_N; n++) {
+                    uint64_t m;
+                    if (row == 0) m = (uint64_t)0 - ((msg * ck->glwe_sk[n]) << (64 - PBS_BASE_LOG));
+                    else m = n == 0 ? msg << (64 - PBS_BASE_LOG) : 0;
+                    body[n] = (prod[n] + e.noise(GLWE_NOISE) + m + qhalf) & qmask;
+                }
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] { work(t); });
+    for (auto &x : th) x.join();
+}
+
 void encrypt_block(fhs_client *ck, uint64_t m, uint64_t *ct) {
     uint64_t acc = 0;
     for (int j = 0; j < BIG_N; j++) {
@@ -220,6 +256,12 @@ int fhs_client_create_insecure_seeded(uint64_t seed, fhs_client **out) {   // te
 void fhs_client_destroy(fhs_client *ck) { delete ck; }
 const uint64_t *fhs_client_bsk(const fhs_client *ck) { return ck ? ck->bsk.data() : nullptr; }
 const uint64_t *fhs_client_ksk(const fhs_client *ck) { return ck ? ck->ksk.data() : nullptr; }
+const uint64_t *fhs_client_bsk_mb2(fhs_client *ck) {
+    if (!ck) return nullptr;
+    std::lock_guard<std::mutex> lk(ck->mb2_mu);
+    if (ck->bsk_mb2.empty()) keygen_mb2(ck);
+    return ck->bsk_mb2.data();
+}
 
 int fhs_client_encrypt_char(fhs_client *ck, uint8_t v, uint64_t *blocks) {   // FheAsciiChar::encrypt (fheasciichar.rs:27-29)
     if (!ck || !blocks) return FHS_ERR_ARG;

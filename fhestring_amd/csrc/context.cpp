@@ -117,6 +117,8 @@ void Context::shutdown() {
     if (d_work_counter) (void)hipFree(d_work_counter);
     d_work_counter = nullptr;
     if (d_bsk_fft) (void)hipFree(d_bsk_fft);
+    if (d_bsk_mb) (void)hipFree(d_bsk_mb);
+    d_bsk_mb = nullptr;
     if (d_fft_tables) (void)hipFree(d_fft_tables);
     d_bsk_fft = nullptr;
     d_fft_tables = nullptr;
@@ -172,7 +174,7 @@ int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
         if (fu != ht.fwd_uni || iu != ht.inv_uni || c != ht.crt_c)
             return fail(-3, "ntt_consts.inc does not match the derived twiddle tables (regenerate it)");
     }
-    if (arith == 1) {
+    if (arith >= 1) {
         HostFftTables ft;
         build_fft_tables(ft);
         {   // the kernel's literal twiddles must equal the libm-derived ones
@@ -185,6 +187,8 @@ int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
         }
         std::vector<double> flat(ft.lanetab);
         flat.insert(flat.end(), ft.weff.begin(), ft.weff.end());
+        flat.insert(flat.end(), ft.mono.begin(), ft.mono.end());
+        flat.insert(flat.end(), ft.r16.begin(), ft.r16.end());
         if (!d_fft_tables) HIP_TRY(hipMalloc(&d_fft_tables, flat.size() * sizeof(double)), "hipMalloc fft tables");
         HIP_TRY(hipMemcpy(d_fft_tables, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice),
                 "copy fft tables");
@@ -218,10 +222,33 @@ int Context::keyswitch(const uint64_t *d_in, size_t B, hipStream_t s) {
 }
 
 int Context::set_arithmetic(int mode) {
-    if (mode != 0 && mode != 1) return fail(-1, "unknown arithmetic mode");
-    if (mode == 1 && key_loaded && !d_bsk_fft)
+    if (mode < 0 || mode > 2) return fail(-1, "unknown arithmetic mode");
+    if (mode >= 1 && key_loaded && !d_bsk_fft)
         return fail(-3, "select the f64-FFT arithmetic before loading the server key");
+    if (mode == 2 && key_loaded && !d_bsk_mb)
+        return fail(-3, "the two-bits-per-product arithmetic needs the pair key (fhs_load_multibit_key)");
     arith = mode;
+    return 0;
+}
+
+// Pair key of the two-bits-per-product blind rotation: transformed with the device's own forward transform like the
+// classic key (fftmb_kernels.hip).
+int Context::load_multibit_key(const uint64_t *bsk_mb2) {
+    if (!bsk_mb2) return fail(-1, "null key pointer");
+    if (!key_loaded || !d_fft_tables)
+        return fail(-3, "load the server key in an f64-FFT arithmetic (fhs_set_arithmetic 1 or 2) before the pair key");
+    HIP_TRY(hipSetDevice(device), "hipSetDevice");
+    const int n_polys = (LWE_N / 2) * 3 * 4;
+    const size_t n = (size_t)n_polys * POLY_N;            // u64 in, doubles out (1024 complex per polynomial)
+    uint64_t *d_std = nullptr;
+    HIP_TRY(hipMalloc(&d_std, n * sizeof(uint64_t)), "hipMalloc pair key staging");
+    hipError_t e = hipSuccess;
+    if (!d_bsk_mb) e = hipMalloc(&d_bsk_mb, n * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(d_std, bsk_mb2, n * sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_bsk_to_fft(d_std, d_bsk_mb, d_fft_tables, stream, n_polys);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_std);
+    HIP_TRY(e, "pair key -> Fourier domain");
     return 0;
 }
 
@@ -230,7 +257,19 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
     hipError_t e;
     const bool four = arith == 1 && B <= (size_t)fft4_max_batch;
     timer.begin(four ? 2 : 0, B, s);
-    if (arith == 1) {
+    if (arith == 2) {
+        if (!d_bsk_mb) return fail(-3, "pair key not loaded (fhs_load_multibit_key)");
+        BlindRotateMb2Params p{};
+        p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;
+        p.bsk_mb = d_bsk_mb;
+        p.lanetab = d_fft_tables;
+        p.mono = d_fft_tables + 12 * 64 + 2 * 1024;
+        p.r16 = p.mono + 2 * 4096;
+        p.work_counter = d_work_counter;
+        p.slots = wg_slots;
+        p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
+        e = launch_blind_rotate_mb2(p, s);
+    } else if (arith == 1) {
         if (!d_bsk_fft) return fail(-3, "Fourier-domain key not loaded");
         BlindRotateFftParams p{};
         p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;
@@ -281,6 +320,31 @@ int Context::pbs_batch_host(const uint64_t *in, const uint32_t *lut_idx, const u
     int rc = pbs_batch_device(in_buf.as<uint64_t>(), lutidx_buf.as<uint32_t>(), luts_buf.as<uint64_t>(),
                               out_buf.as<uint64_t>(), B, stream);
     if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, out_buf.ptr, B * BIG_CT * 8, hipMemcpyDeviceToHost, stream), "D2H");
+    HIP_TRY(hipStreamSynchronize(stream), "sync");
+    return 0;
+}
+
+// kernel-level tests: blind rotation + sample extraction only, from given keyswitched LWEs (u64 torus, mod-switched in
+// the kernel like always), in the selected arithmetic
+int Context::blind_rotate_host(const uint64_t *ks, const uint32_t *lut_idx, const uint64_t *luts, size_t n_luts,
+                               uint64_t *out, size_t B) {
+    if (!key_loaded) return fail(-3, "server key not loaded");
+    if (!ks || !lut_idx || !luts || !out) return fail(-1, "null pointer");
+    if (B == 0) return 0;
+    for (size_t b = 0; b < B; b++)
+        if (lut_idx[b] >= n_luts) return fail(-1, "lut_idx out of range");
+    HIP_TRY(hipSetDevice(device), "hipSetDevice");
+    HIP_TRY(ks_buf.reserve(B * SMALL_CT * 8), "hipMalloc");
+    HIP_TRY(out_buf.reserve(B * BIG_CT * 8), "hipMalloc");
+    HIP_TRY(lutidx_buf.reserve(B * 4), "hipMalloc");
+    HIP_TRY(luts_buf.reserve(n_luts * POLY_N * 8), "hipMalloc");
+    HIP_TRY(hipMemcpyAsync(ks_buf.ptr, ks, B * SMALL_CT * 8, hipMemcpyHostToDevice, stream), "H2D");
+    HIP_TRY(hipMemcpyAsync(lutidx_buf.ptr, lut_idx, B * 4, hipMemcpyHostToDevice, stream), "H2D");
+    HIP_TRY(hipMemcpyAsync(luts_buf.ptr, luts, n_luts * POLY_N * 8, hipMemcpyHostToDevice, stream), "H2D");
+    if (int rc = blind_rotate(ks_buf.as<uint64_t>(), lutidx_buf.as<uint32_t>(), luts_buf.as<uint64_t>(),
+                              out_buf.as<uint64_t>(), nullptr, B, stream))
+        return rc;
     HIP_TRY(hipMemcpyAsync(out, out_buf.ptr, B * BIG_CT * 8, hipMemcpyDeviceToHost, stream), "D2H");
     HIP_TRY(hipStreamSynchronize(stream), "sync");
     return 0;

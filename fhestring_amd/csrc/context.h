@@ -59,9 +59,12 @@ class Context {
     // Select before load_server_key: the Fourier-domain key is only built when the mode asks for it.
     int arith = 0;
     double *d_bsk_fft = nullptr;
-    double *d_fft_tables = nullptr;   // lanetab[12][64] | weff[1024][2]
+    double *d_fft_tables = nullptr;   // lanetab[12][64] | weff[1024][2] | mono[4096][2] | r16[16][2]
     uint32_t *d_work_counter = nullptr;   // persistent-workgroup ciphertext counter of the 2-wavefront FFT kernel
     int wg_slots = 1024;                  // 4 workgroups per CU
+    // arith 2 (FHS_ARITH_F64_FFT_MB2): two key bits per external product (fftmb_kernels.hip); needs the pair key
+    double *d_bsk_mb = nullptr;       // [371][K1,K2,K3][4][1024] complex
+    int load_multibit_key(const uint64_t *bsk_mb2);   // [371][K1,K2,K3][4][2048] u64 standard domain (fhs_client_bsk_mb2)
     int fft4_max_batch = 512;         // batches up to this size use the 4-wavefront kernel (lower latency)
     int set_arithmetic(int mode);
     // keyswitch of a dense batch into ks_buf (timed as kernel kind 1); ks_buf must hold B rows
@@ -91,6 +94,8 @@ class Context {
     int pbs_batch_host(const uint64_t *in, const uint32_t *lut_idx, const uint64_t *luts, size_t n_luts,
                        uint64_t *out, size_t B);
     int ks_ms_batch_host(const uint64_t *in, uint32_t *ms_out, size_t B);
+    int blind_rotate_host(const uint64_t *ks, const uint32_t *lut_idx, const uint64_t *luts, size_t n_luts,
+                          uint64_t *out, size_t B);
 };
 
 }  // namespace fhs

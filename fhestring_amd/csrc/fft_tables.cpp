@@ -43,6 +43,21 @@ void build_fft_tables(HostFftTables &t) {
         t.lanetab[10 * 64 + L] = t.w_re[512 + 8 * L];
         t.lanetab[11 * 64 + L] = t.w_im[512 + 8 * L];
     }
+    // called through volatile pointers: a compiler that fuses the pair into one sincos() call gets a libm routine
+    // whose results differ from cos() / sin() in the last place for a few arguments (seen: gcc vs clang, 2 of 8192
+    // entries); the CPU oracle builds its copy of this table the same way
+    static double (*volatile p_cos)(double) = std::cos;
+    static double (*volatile p_sin)(double) = std::sin;
+    t.mono.assign(2 * 4096, 0.0);
+    for (int k = 0; k < 4096; k++) {
+        t.mono[2 * k] = p_cos(PI * (double)k / 2048.0);
+        t.mono[2 * k + 1] = p_sin(PI * (double)k / 2048.0);
+    }
+    t.r16.assign(2 * 16, 0.0);
+    for (int k = 0; k < 16; k++) {                        // the same table values, so that rho^e is consistent
+        t.r16[2 * k] = t.mono[2 * (256 * k)];
+        t.r16[2 * k + 1] = t.mono[2 * (256 * k) + 1];
+    }
     // effective twiddles (see fft_tables.h)
     t.weff.assign(2 * FM, 0.0);
     auto put = [&](int idx, double re, double im) { t.weff[2 * idx] = re; t.weff[2 * idx + 1] = im; };

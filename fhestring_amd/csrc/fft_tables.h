@@ -16,6 +16,8 @@ struct HostFftTables {
     // rotation by i for odd offsets.  The 4-wavefront kernel loads its per-lane twiddles from this table, which is
     // what keeps the two kernels bit-identical.
     std::vector<double> weff;
+    // two-bits-per-product kernel (fftmb_kernels.hip): mono [4096][2] = exp(i*pi*k/2048), r16 [16][2] = exp(i*pi*k/8)
+    std::vector<double> mono, r16;
 };
 void build_fft_tables(HostFftTables &t);
 

@@ -60,6 +60,22 @@ struct BlindRotateFftParams {
     int B;
 };
 
+// Two key bits per external product (fftmb_kernels.hip, FHS_ARITH_F64_FFT_MB2); same inputs/outputs again.
+struct BlindRotateMb2Params {
+    const uint64_t *ks;
+    const uint32_t *lut_idx;
+    const uint64_t *luts;
+    const double *bsk_mb;     // [371 pairs][K1,K2,K3][row 2][col 2][16][64 lanes][2 re,im], pre-scaled by 2^-74
+    const double *lanetab;    // [12][64] per-lane twiddle bases (fft_tables.cpp)
+    const double *mono;       // [4096][2] exp(i*pi*k/2048): monomial evaluation table
+    const double *r16;        // [16][2]   exp(i*pi*k/8)
+    uint32_t *work_counter;
+    int slots;
+    uint64_t *out;
+    uint64_t *const *out_ptrs;
+    int B;
+};
+
 // One lincomb output: out[dst] = sum_t coef[t] * src[t] + konst * 2^59 (body only)
 struct LinDesc {
     uint32_t first_term;
@@ -78,8 +94,10 @@ hipError_t read_device_ntt_consts(double *fwd_uni /*[64]*/, double *inv_uni /*[1
 hipError_t launch_blind_rotate(const BlindRotateParams &p, hipStream_t s);
 hipError_t launch_blind_rotate_fft(const BlindRotateFftParams &p, hipStream_t s);    // 2 wavefronts per ciphertext
 hipError_t launch_blind_rotate_fft4(const BlindRotateFftParams &p, hipStream_t s);   // 4 wavefronts per ciphertext
-// standard-domain key [742*4][2048] u64 -> Fourier-domain key, with the device's own forward transform
-hipError_t launch_bsk_to_fft(const uint64_t *d_bsk_std, double *d_out, const double *d_lanetab, hipStream_t s);
+// standard-domain key [n_polys][2048] u64 -> Fourier-domain key, with the device's own forward transform
+hipError_t launch_bsk_to_fft(const uint64_t *d_bsk_std, double *d_out, const double *d_lanetab, hipStream_t s,
+                             int n_polys = LWE_N * 4);
+hipError_t launch_blind_rotate_mb2(const BlindRotateMb2Params &p, hipStream_t s);    // 2 wavefronts per ciphertext
 // the scalar twiddle literals baked into fft_kernels.hip: W[16] (index 1 and even indices used), U[3]
 void fft_uniform_consts(double *w_re, double *w_im, double *u_re, double *u_im);
 // matrix-core keyswitch (ks_kernels.hip): KSK as 8 planes of balanced signed bytes in MFMA fragment order

@@ -69,6 +69,15 @@ int fhs_load_server_key(fhs_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk);
  * allowed. */
 #define FHS_ARITH_EXACT_NTT 0
 #define FHS_ARITH_F64_FFT 1
+/* F64_FFT_MB2: the f64 FFT arithmetic with TWO LWE key bits per GGSW x GLWE external product (371 products per bootstrap
+ * instead of 742; the "multi-bit" blind rotation of Joye-Paillier / tfhe-rs' GPU backend at group size 2, here on the
+ * reference's own parameter set: dimensions, bases, noise distributions and keyswitch unchanged).  Needs the pair key
+ * (three GGSWs per pair of key bits, fhs_client_bsk_mb2) loaded with fhs_load_multibit_key AFTER fhs_load_server_key in
+ * arithmetic 1 or 2.  Same inputs, same outputs up to noise (measured lower than the classic kernel's: half as many
+ * decomposition roundings), bit-exact against mode 4 of the CPU oracle.  csrc/fftmb_kernels.hip. */
+#define FHS_ARITH_F64_FFT_MB2 2
+#define FHS_BSK_MB2_WORDS ((size_t)371 * 3 * 4 * 2048)
+int fhs_load_multibit_key(fhs_ctx *ctx, const uint64_t *bsk_mb2 /*[371][3][2 rows][2 cols][2048]*/);
 int fhs_set_arithmetic(fhs_ctx *ctx, int arith);
 int fhs_get_arithmetic(const fhs_ctx *ctx);
 /* Tuning knob of the F64_FFT arithmetic: batches of at most `max_batch` ciphertexts run on the 4-wavefront kernel
@@ -77,6 +86,8 @@ int fhs_get_arithmetic(const fhs_ctx *ctx);
 int fhs_set_fft4_max_batch(fhs_ctx *ctx, int max_batch);
 /* Diagnostic: the host-derived twiddle tables of the F64_FFT mode (W[1024] re/im; U[16] re/im, 3 used). */
 void fhs_fft_tables(double *w_re, double *w_im, double *u_re, double *u_im);
+/* ... and the monomial evaluation table of the F64_FFT_MB2 mode: exp(i*pi*k/2048), k < 4096, (re, im) pairs. */
+void fhs_fft_mono_table(double *mono /*[4096][2]*/);
 
 /* ---- raw batched PBS (the hot path; kernel-level parity tests use these) ----
  * replaces: tfhe::shortint::ServerKey::apply_lookup_table on B blocks.
@@ -85,6 +96,10 @@ int fhs_pbs_batch(fhs_ctx *ctx, const uint64_t *in, const uint32_t *lut_idx, con
                   size_t n_luts, uint64_t *out, size_t B);
 /* keyswitch + modulus switch only: ms_out[B][743] values in [0,4096) */
 int fhs_keyswitch_modswitch_batch(fhs_ctx *ctx, const uint64_t *in, uint32_t *ms_out, size_t B);
+/* Kernel-level tests: blind rotation + sample extraction only, in the selected arithmetic, from GIVEN keyswitched LWEs
+ * ks[B][743] (u64 torus; the kernels apply the modulus switch to 2N = 4096 themselves) -> out[B][2049]. */
+int fhs_debug_blind_rotate_batch(fhs_ctx *ctx, const uint64_t *ks, const uint32_t *lut_idx, const uint64_t *luts,
+                                 size_t n_luts, uint64_t *out, size_t B);
 /* Device-resident variant: all pointers are device pointers (e.g. torch tensors' data_ptr); work is enqueued
  * on `hip_stream` (0 = default).  A context owns one set of scratch buffers and one work counter: calls on it
  * must be ordered (one stream at a time); use several contexts for concurrent streams. */
@@ -321,6 +336,9 @@ void fhs_chacha20_block(const uint32_t key[8], uint32_t counter, const uint32_t 
 void fhs_client_destroy(fhs_client *ck);
 const uint64_t *fhs_client_bsk(const fhs_client *ck);                    /* get_server_key :37-39 */
 const uint64_t *fhs_client_ksk(const fhs_client *ck);
+/* pair key of FHS_ARITH_F64_FFT_MB2 (generated on first call; FHS_BSK_MB2_WORDS words): for each pair of LWE key bits
+ * (s, s') GGSW encryptions of s(1-s'), (1-s)s' and s s' */
+const uint64_t *fhs_client_bsk_mb2(fhs_client *ck);
 int fhs_client_encrypt_char(fhs_client *ck, uint8_t v, uint64_t *blocks /*[4][2049]*/); /* encrypt_char :85-87 */
 int fhs_client_decrypt_char(const fhs_client *ck, const uint64_t *blocks, uint8_t *out); /* decrypt_char :81-83 */
 /* encrypt :45-65 (ASCII, no NUL, `padding` NULs appended): out[(len+padding)][4][2049] */

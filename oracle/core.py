@@ -50,6 +50,10 @@ def lib():
         L.orc_bsk_quantize.restype = None
         L.orc_server_key_new.argtypes = [_u64p, _u64p]
         L.orc_server_key_new.restype = C.c_void_p
+        L.orc_keygen_mb2.argtypes = [C.c_uint64, _u64p, _u64p, _u64p]
+        L.orc_keygen_mb2.restype = None
+        L.orc_server_key_set_mb2.argtypes = [C.c_void_p, _u64p]
+        L.orc_server_key_set_mb2.restype = None
         L.orc_server_key_free.argtypes = [C.c_void_p]
         L.orc_server_key_free.restype = None
         L.orc_encrypt_block.argtypes = [_u64p, C.c_uint64, C.POINTER(C.c_uint64), _u64p]
@@ -93,6 +97,14 @@ class Keys:
         lib().orc_keygen(self.seed, self.lwe_sk, self.glwe_sk, self.bsk, self.ksk)
         self._rng = C.c_uint64((self.seed * 0x9E3779B97F4A7C15 + 0x1234567) & (2**64 - 1))
 
+    @property
+    def bsk_mb2(self):
+        """Pair key of mode 4 (two key bits per external product), generated on first use: [371 * 3 * 4 * 2048]."""
+        if getattr(self, "_bsk_mb2", None) is None:
+            self._bsk_mb2 = np.zeros((LWE_N // 2) * 3 * 4 * BIG_N, np.uint64)
+            lib().orc_keygen_mb2(self.seed, self.lwe_sk, self.glwe_sk, self._bsk_mb2)
+        return self._bsk_mb2
+
     # client side -----------------------------------------------------------
     def encrypt_block(self, m):
         ct = np.zeros(BIG_CT, np.uint64)
@@ -124,6 +136,11 @@ class ServerKey:
             bsk = keys_or_bsk
         self._h = lib().orc_server_key_new(np.ascontiguousarray(bsk, np.uint64),
                                            np.ascontiguousarray(ksk, np.uint64))
+
+    def set_mb2(self, bsk_mb2):
+        """orc_server_key_set_mb2: pair key for mode 4."""
+        lib().orc_server_key_set_mb2(self._h, np.ascontiguousarray(bsk_mb2, np.uint64))
+        return self
 
     def __del__(self):
         try:

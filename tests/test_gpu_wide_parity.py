@@ -5,6 +5,7 @@
 * full PBS at B = 1024 (exact NTT) and B = 3968 (exact NTT, and the f64-FFT arithmetic on both of its kernels):
   >= 32 sampled rows -- first, last, and rows that a persistent workgroup takes in its 2nd, 3rd and 4th round --
   against oracle mode 0 / mode 3, every output word.
+* the two-bits-per-product arithmetic (FHS_ARITH_F64_FFT_MB2) at B = 3968 against oracle mode 4, same sampling.
 * the same sampled check through the engine's flush (per-ciphertext `out_ptrs` scatter), through
   fhs_flush_level_exec/commit with two ranks' slices, and through fhs_pbs_batch_device (device pointers).
 
@@ -110,6 +111,31 @@ def test_fft_pbs_sampled_rows_at_bench_width(fft_ctx, wide_inputs, oracle_sk, ke
     finally:
         fft_ctx.set_fft4_max_batch(512)
     _check_sampled(got, cts[:B], idx, luts, _sample_rows(B, 7 if kernel == "waves2" else 8), oracle_sk, mode=3)
+
+
+def test_mb2_pbs_sampled_rows_at_bench_width(fft_ctx, oracle_keys, wide_inputs, oracle_sk):
+    """FHS_ARITH_F64_FFT_MB2 (two key bits per external product, csrc/fftmb_kernels.hip) against oracle mode 4, every
+    output word of the sampled rows at B = 3968, plus a narrow batch; the same context switches back to the classic
+    kernel afterwards (both keys stay loaded)."""
+    B = 3968
+    _, cts = wide_inputs
+    luts = _luts()
+    idx = (np.arange(B) % len(NAMES)).astype(np.uint32)
+    oracle_sk.set_mb2(oracle_keys.bsk_mb2)
+    fft_ctx.load_multibit_key(oracle_keys.bsk_mb2)
+    fft_ctx.set_arithmetic(fft_ctx.ARITH_F64_FFT_MB2)
+    try:
+        got = fft_ctx.pbs_batch(cts[:B], idx, luts)
+        small = fft_ctx.pbs_batch(cts[:5], idx[:5], luts)
+    finally:
+        fft_ctx.set_arithmetic(fft_ctx.ARITH_F64_FFT)
+    _check_sampled(got, cts[:B], idx, luts, _sample_rows(B, 9), oracle_sk, mode=4)
+    assert np.array_equal(small, got[:5])
+    # same function as the classic kernel: every sampled row decrypts to the same block value
+    rows = _sample_rows(B, 9)
+    classic = fft_ctx.pbs_batch(cts[rows], idx[rows], luts)
+    for k, r in enumerate(rows):
+        assert oracle_keys.decrypt_block(got[r]) == oracle_keys.decrypt_block(classic[k]), r
 
 
 def test_pbs_batch_device_sampled_rows(fft_ctx, exact_ctx, wide_inputs, oracle_sk):

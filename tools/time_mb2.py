@@ -1,0 +1,37 @@
+"""Classic f64-FFT blind rotation vs two key bits per product: kernel time per 3968-wide batch and a decryption check
+(python tools/time_mb2.py [B ...], GPU box)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+import torch  # noqa: F401  (before the library: same-SONAME HIP runtime)
+import fhestring_amd
+from fhestring_amd.api import MyClientKey
+
+ck = MyClientKey(0xF5E57121)
+sizes = [int(a) for a in sys.argv[1:]] or [3968]
+import os
+for arith in ((2,) if os.environ.get('FHS_MB2_VARIANT') else (1, 2)):
+    t = time.time()
+    sk = ck.get_server_key(0, arith=arith)
+    print("arith %d: key load %.2fs" % (arith, time.time() - t), flush=True)
+    sk.set_mode(1)
+    # correctness: a few string ops through the whole stack
+    es = ck.encrypt("Hello, MI355X world!", 1, None, sk)
+    up, found, pos = sk.to_upper(es), sk.contains_clear(es, "355"), sk.find_clear(es, "world")
+    sk.flush()
+    print("   to_upper %r contains %d find %d" % (ck.decrypt(up), ck.decrypt_char(found), ck.decrypt_char(pos)), flush=True)
+    ctx = sk.ctx
+    rng = np.random.default_rng(0)
+    luts = rng.integers(0, 2**64, (2, 2048), dtype=np.uint64)
+    for B in sizes:
+        cts = rng.integers(0, 2**64, (B, 2049), dtype=np.uint64)
+        idx = (np.arange(B) % 2).astype(np.uint32)
+        ctx.pbs_batch(cts, idx, luts)
+        ctx.kernel_timing(reset=True)
+        for _ in range(3):
+            ctx.pbs_batch(cts, idx, luts)
+        kt = ctx.kernel_timing(reset=True)
+        print("   B=%5d  blind_rotate %.2f ms  keyswitch %.3f ms -> %.0f PBS/s (blind rotation only %.0f)" % (
+            B, kt["blind_rotate_ms"], kt["keyswitch_ms"], B / ((kt["blind_rotate_ms"] + kt["keyswitch_ms"]) * 1e-3),
+            B / (kt["blind_rotate_ms"] * 1e-3)), flush=True)
+    sk.close()
