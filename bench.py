@@ -53,10 +53,13 @@ def parse():
                          "in 4 dependent levels and cannot fill 256 CUs; 1 for the other ops)")
     ap.add_argument("--mode", choices=["fused", "as_written"], default="fused")
     ap.add_argument("--cpu-pbs", type=int, default=-1, help="PBS in the CPU-baseline throughput sample (0 = skip)")
-    ap.add_argument("--arith", choices=["fft", "exact"], default="fft",
+    ap.add_argument("--arith", choices=["fft", "exact", "mb2"], default="fft",
                     help="arithmetic of the negacyclic products in blind rotation: 'fft' = f64 complex FFT (the "
                          "reference engine's algorithm class, fhs_set_arithmetic(FHS_ARITH_F64_FFT)); 'exact' = "
-                         "two-prime exact NTT (library default).  The other one is timed too (other_arithmetic)")
+                         "two-prime exact NTT (library default); 'mb2' = f64 FFT with two LWE key bits per external "
+                         "product (FHS_ARITH_F64_FFT_MB2: needs the pair key from the client; tfhe-rs calls this a "
+                         "multi-bit PBS, the reference's CPU engine runs the classic one).  With fft (the default) "
+                         "the other two are timed too (other_arithmetic, multi_bit)")
     ap.add_argument("--pipelines", type=int, default=None,
                     help="0 = ONE context with level-skewed batching (fhs_submit + fhs_pump per step: the narrow tail "
                          "levels of step k ride in the wide launch of step k+1, and with several GPUs the exchange + OR "
@@ -359,7 +362,14 @@ def main():
         raise SystemExit("--pipelines 0 (level-skewed batching) with several GPUs is implemented for contains only")
     P = max(1, args.pipelines)
     sks = [MyServerKey.from_client_key(ck, local_rank, arith=1) for _ in range(P)]   # Fourier-domain key as well
-    ARITH = {"fft": sks[0].ctx.ARITH_F64_FFT, "exact": sks[0].ctx.ARITH_EXACT_NTT}
+    ARITH = {"fft": sks[0].ctx.ARITH_F64_FFT, "exact": sks[0].ctx.ARITH_EXACT_NTT, "mb2": sks[0].ctx.ARITH_F64_FFT_MB2}
+    KERNEL = {"fft": "blind_rotate_fft_kernel", "exact": "blind_rotate_kernel", "mb2": "blind_rotate_mb2_kernel"}
+    ARITH_NAME = {"fft": "f64-FFT", "exact": "exact-NTT", "mb2": "f64-FFT, two key bits per external product"}
+    want_mb2 = args.arith == "mb2" or (args.arith == "fft" and not args.skip_extras and args.op == "contains" and world == 1)
+    if want_mb2:
+        pair_key = ck.bsk_mb2()
+        for x in sks:
+            x.ctx.load_multibit_key(pair_key)
     dists = []
     for x in sks:
         x.ctx.set_arithmetic(ARITH[args.arith])
@@ -511,6 +521,18 @@ def main():
         secondary = {"arithmetic": other, "pbs_local": float(st2["pbs_executed"]), "dt": dt2, "steps": n2, "kt": kt2}
         set_arith(args.arith)
 
+    # the same workload in the two-bits-per-product arithmetic (default run only; its own object in the JSON line)
+    multi_bit = None
+    if args.arith == "fft" and want_mb2:
+        set_arith("mb2")
+        for _ in range(P):
+            step()
+        n3 = max(6, min(args.steps, 12)) if SKEW else max(1, min(args.steps, 2 * P))
+        dt3, outs3, st3, kt3 = timed(n3)
+        wl.check(outs3)
+        multi_bit = {"pbs_local": float(st3["pbs_executed"]), "dt": dt3, "steps": n3, "kt": kt3}
+        set_arith(args.arith)
+
     # the same workload with twice the strings per step (one GPU, default run): how much of the gap to the kernel-only
     # rate is batch size (narrow-level drain, keyswitch and the emptier last round of a launch group weigh half as much)
     larger = None
@@ -575,6 +597,8 @@ def main():
         pbs_total = float(pbs_local)
         if secondary:
             secondary["pbs_total"] = secondary["pbs_local"]
+        if multi_bit:
+            multi_bit["pbs_total"] = multi_bit["pbs_local"]
         if extras:
             for e in extras.values():
                 e["ms"], e["pbs"] = e["ms_local"], e["pbs_local"]
@@ -587,7 +611,7 @@ def main():
         except Exception:
             pass
         wide, narrow = kt[0], kt[2]
-        kernel = "blind_rotate_fft_kernel" if args.arith == "fft" else "blind_rotate_kernel"
+        kernel = KERNEL[args.arith]
         if wide["n"] == 0 and narrow["n"]:          # every level ran on the narrow-level kernel
             wide, kernel = narrow, "blind_rotate_fft4_kernel"
         ppl = wide["pbs"] / max(1, wide["n"])
@@ -602,10 +626,9 @@ def main():
             "higher_is_better": True,
             "scaling": wl.scaling,
             "vs_baseline": None,
-            "dtype": "f64" if args.arith == "fft" else "u64",
+            "dtype": "u64" if args.arith == "exact" else "f64",
             "data": "synthetic",
-            "config": {"workload": "%s, %s DAG, %s arithmetic" % (wl.describe(), args.mode,
-                                                                   "f64-FFT" if args.arith == "fft" else "exact-NTT"),
+            "config": {"workload": "%s, %s DAG, %s arithmetic" % (wl.describe(), args.mode, ARITH_NAME[args.arith]),
                        "pipelines": args.pipelines,
                        "scheduling": ("level-skewed batching: one context, fhs_submit + fhs_pump per step, the narrow "
                                       "levels of step k ride in the wide launch of step k+1" if SKEW else
@@ -647,6 +670,18 @@ def main():
                 "ms_per_step": secondary["dt"] / secondary["steps"] * 1e3,
                 "roofline": roofline_for(okern, k2[0]["pbs"] / max(1, k2[0]["n"]), k2[0]["ms"], k2[0]["n"], counters,
                                          traffic.get(okern + "_hbm_bytes_per_launch"))}
+        if multi_bit:
+            k3 = multi_bit["kt"]
+            line["multi_bit"] = {
+                "arithmetic": "f64 FFT, two LWE key bits per GGSW x GLWE external product (FHS_ARITH_F64_FFT_MB2, "
+                              "csrc/fftmb_kernels.hip): 371 products per bootstrap instead of 742, same parameter set, "
+                              "needs the pair key (3 GGSWs per pair of key bits) from the client; bit-exact vs oracle "
+                              "mode 4; NOT the headline because the reference's engine runs the classic bootstrap",
+                "value": multi_bit["pbs_total"] / multi_bit["dt"], "unit": "PBS/s", "steps": multi_bit["steps"],
+                "ms_per_step": multi_bit["dt"] / multi_bit["steps"] * 1e3,
+                "ms_per_op": multi_bit["dt"] / multi_bit["steps"] / wl.n_strings * 1e3,
+                "roofline": roofline_for("blind_rotate_mb2_kernel", k3[0]["pbs"] / max(1, k3[0]["n"]), k3[0]["ms"],
+                                         k3[0]["n"], counters, traffic.get("blind_rotate_mb2_kernel_hbm_bytes_per_launch"))}
         if larger:
             line["larger_batch"] = larger
         if extras:

@@ -256,9 +256,10 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
                           uint64_t *const *d_out_ptrs, size_t B, hipStream_t s) {
     hipError_t e;
     const bool four = arith == 1 && B <= (size_t)fft4_max_batch;
+    if (arith == 2 && !d_bsk_mb) return fail(-3, "pair key not loaded (fhs_load_multibit_key)");
+    if (arith == 1 && !d_bsk_fft) return fail(-3, "Fourier-domain key not loaded");
     timer.begin(four ? 2 : 0, B, s);
     if (arith == 2) {
-        if (!d_bsk_mb) return fail(-3, "pair key not loaded (fhs_load_multibit_key)");
         BlindRotateMb2Params p{};
         p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;
         p.bsk_mb = d_bsk_mb;
@@ -270,7 +271,6 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
         p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
         e = launch_blind_rotate_mb2(p, s);
     } else if (arith == 1) {
-        if (!d_bsk_fft) return fail(-3, "Fourier-domain key not loaded");
         BlindRotateFftParams p{};
         p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;
         p.bsk_fft = d_bsk_fft;

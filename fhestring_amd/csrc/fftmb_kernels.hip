@@ -10,8 +10,10 @@
 // The bracket is formed in the Fourier domain, where multiplying by a monomial is a pointwise multiplication by the
 // evaluation point raised to the exponent.  This is the "multi-bit" bootstrap of tfhe-rs' GPU backend (Joye-Paillier
 // 2022; Bourse et al. 2018) at group size 2, on the reference's own parameter set: LWE dimension, polynomial size,
-// bases, noise distributions and the keyswitch are unchanged; the measured output noise is LOWER than the classic
-// kernel's (half as many decomposition roundings; tests/test_gpu_noise.py).
+// bases, noise distributions and the keyswitch are unchanged.  The price is noise: the bootstrap output's sigma is
+// 2^49.62 instead of 2^48.87 (the decomposition rounding enters through (X^e - 1), and the f64 rounding of three GGSW
+// products per pair instead of one per bit dominates; measured in tests/test_gpu_noise.py, which holds the string layer's
+// DAGs to the same margins in this arithmetic: total error at the design limit 9.05 instead of 8.98 units of 2^52).
 //
 // Per pair and point (root rho = w^(4j+1), w = exp(i pi/2048), j = bitrev of the point's position):
 //     a = rho^e1, b = rho^e2;   A_row = K1 (a - 1) + K2 (b - 1) + K3 (a b - 1);     out = F_own A_own + F_partner A_partner

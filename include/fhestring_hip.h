@@ -73,8 +73,9 @@ int fhs_load_server_key(fhs_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk);
  * instead of 742; the "multi-bit" blind rotation of Joye-Paillier / tfhe-rs' GPU backend at group size 2, here on the
  * reference's own parameter set: dimensions, bases, noise distributions and keyswitch unchanged).  Needs the pair key
  * (three GGSWs per pair of key bits, fhs_client_bsk_mb2) loaded with fhs_load_multibit_key AFTER fhs_load_server_key in
- * arithmetic 1 or 2.  Same inputs, same outputs up to noise (measured lower than the classic kernel's: half as many
- * decomposition roundings), bit-exact against mode 4 of the CPU oracle.  csrc/fftmb_kernels.hip. */
+ * arithmetic 1 or 2.  Same inputs, same outputs up to noise (bootstrap output sigma 2^49.62 instead of 2^48.87; the
+ * string layer's noise margins hold in this arithmetic too, tests/test_gpu_noise.py), bit-exact against mode 4 of the
+ * CPU oracle.  csrc/fftmb_kernels.hip. */
 #define FHS_ARITH_F64_FFT_MB2 2
 #define FHS_BSK_MB2_WORDS ((size_t)371 * 3 * 4 * 2048)
 int fhs_load_multibit_key(fhs_ctx *ctx, const uint64_t *bsk_mb2 /*[371][3][2 rows][2 cols][2048]*/);

@@ -13,6 +13,13 @@ the decoding threshold (half a LUT box = 64 units of 2^52):
   linear combinations add sigma <= 2^52 = 1 unit to the ~9 units of keyswitch + modulus switch;
 * per construct (LUT, sum c^2), pooled over the ops: sigma of the total error <= 1.05 x the fresh-ciphertext floor of
   the SAME key, and no sampled error beyond 48 of the 64 units;
+* FHS_ARITH_F64_FFT_MB2 (two key bits per external product) has a NOISIER bootstrap output: sigma 2^49.62 instead of
+  2^48.87 (bound here: 2^49.9).  Its decomposition rounding enters through (X^e - 1) (1.5x the classic variance) and
+  the f64 rounding of three GGSW products per pair instead of one per bit dominates (it grows with the gadget base:
+  2^50.3 at base 2^24, 2^51.4 at 2^25, also with a noise-free key; 2^23 is the optimum).  The linear combinations then
+  add at most 8 x 2^49.62 = 1.54 units instead of 1.0 to the ~9 units of keyswitch + modulus switch: total error at the
+  design limit 9.05 instead of 8.98 units on an average key (log2 p_fail -39.2 instead of -39.8); all other bounds
+  below are the same for the three arithmetics;
 * the floor itself: 64 / sigma >= 6.6.  (Averaged over keys the parameter set gives 8.92 units = 7.17 sigma =
   2^-40.3; the balanced keyswitch digits [-4, 3] have mean -1/2, so a given key shifts the error by
   -1/2 * sum(ksk noise) ~ N(0, 1.5 units): the test key's floor is 9.4 units = 6.8 sigma.  tfhe-rs has the same term.)
@@ -28,13 +35,14 @@ import noise_util as nu
 pytestmark = pytest.mark.gpu
 SEED = 0xF5E57121
 NOISE_BUDGET = 64            # include/fhestring_hip.h FHS_NOISE_BUDGET_SUM_C2
+PBS_SIGMA_LOG2_BOUND = {"f64_fft": 49.2, "exact_ntt": 49.2, "f64_fft_mb2": 49.9}
 
 
-@pytest.fixture(scope="module", params=["f64_fft", "exact_ntt"])
+@pytest.fixture(scope="module", params=["f64_fft", "exact_ntt", "f64_fft_mb2"])
 def product(request):
     from fhestring_amd.api import MyClientKey
     ck = MyClientKey(SEED)
-    sk = ck.get_server_key(0, arith=1 if request.param == "f64_fft" else 0)
+    sk = ck.get_server_key(0, arith={"exact_ntt": 0, "f64_fft": 1, "f64_fft_mb2": 2}[request.param])
     sk.set_mode(1)
     yield ck, sk, request.param
     sk.close()
@@ -52,7 +60,7 @@ def test_bootstrap_output_and_floor(product):
     print("\n[%s] one bootstrap output: sigma 2^%.2f max 2^%.2f; fresh ct -> KS+MS: sigma %.2f units (z = %.2f, "
           "log2 p_fail %.1f), max %.0f" % (arith, math.log2(s_pbs), math.log2(max_pbs), s_floor, 64 / s_floor,
                                            nu.log2_pfail(64 / s_floor), max_floor))
-    assert math.log2(s_pbs) <= 49.2
+    assert math.log2(s_pbs) <= PBS_SIGMA_LOG2_BOUND[arith]
     assert 64 / s_floor >= 6.6 and max_floor < 48
 
 
@@ -110,9 +118,9 @@ def test_fused_dags_stay_inside_the_noise_budget(product):
                                                                                 math.log2(max(s_in, 1)), s_tot, mx, 64 / s_tot))
         assert key[1] <= NOISE_BUDGET
         assert mx < 48, (key, mx)
-        # what the linear combination adds: sigma_in <= sqrt(sum c^2) x a bootstrap output's sigma (2^49.2 bound)
+        # what the linear combination adds: sigma_in <= sqrt(sum c^2) x a bootstrap output's sigma (its bound above)
         if len(ei) >= 64:
-            assert s_in <= math.sqrt(key[1]) * 2 ** 49.2 * 1.15, (key, math.log2(s_in))
+            assert s_in <= math.sqrt(key[1]) * 2 ** PBS_SIGMA_LOG2_BOUND[arith] * 1.15, (key, math.log2(s_in))
         # the total error entering blind rotation stays at the fresh-ciphertext floor (statistical slack by sample size)
         if len(et) >= 256:
             slack = 1.05 + 3.0 / math.sqrt(2 * len(et))

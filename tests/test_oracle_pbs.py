@@ -75,6 +75,43 @@ def test_fft_mirror_mode_decrypts_and_tracks_the_exact_path(oracle_keys, oracle_
     assert np.allclose(w_re[1:] ** 2 + w_im[1:] ** 2, 1.0, atol=1e-15)
 
 
+def test_two_key_bits_per_product_mode_decrypts_and_tracks_the_exact_path(oracle_keys, oracle_sk):
+    """mode 4 mirrors the product's FHS_ARITH_F64_FFT_MB2 kernel (csrc/fftmb_kernels.hip: one external product per PAIR
+    of LWE key bits, pair key = GGSWs of s(1-s'), (1-s)s', s s'); the GPU tests assert bit-equality with it.  Here: same
+    plaintexts as the exact classic bootstrap on the same inputs, phase within 2^52 of it, including a padding-bit
+    input (negacyclic wrap) and an all-zero mask row."""
+    oracle_sk.set_mb2(oracle_keys.bsk_mb2)
+    names = ["msg", "carry", "eq_biv", "sign"]
+    luts = np.stack([radix.lut_poly(n) for n in names])
+    rng = np.random.default_rng(41)
+    msgs = rng.integers(0, 16, 12)
+    idx = (np.arange(12) % 4).astype(np.uint32)
+    cts = np.stack([oracle_keys.encrypt_block(int(m)) for m in msgs])
+    outs = oracle_sk.pbs_batch(cts, idx, luts, mode=4)
+    exact = oracle_sk.pbs_batch(cts, idx, luts, mode=0)
+    for b in range(12):
+        assert oracle_keys.decrypt_block(outs[b]) == radix.lut_eval(names[idx[b]], int(msgs[b]))
+        d = (oracle_keys.phase(outs[b]) - oracle_keys.phase(exact[b])) & (2**64 - 1)
+        assert min(d, 2**64 - d) < 2**52
+    # blind rotation alone on an all-zero mask: no product is executed, the accumulator is the rotated LUT
+    ms = np.zeros(743, np.uint32); ms[742] = 3
+    acc4, acc0 = oracle_sk.blind_rotate(ms, luts[0], mode=4), oracle_sk.blind_rotate(ms, luts[0], mode=0)
+    assert np.array_equal(acc4, acc0)
+    # chosen masks: one element of a pair zero, odd exponents, exponents >= 2048 -- same plaintext as the classic rotation
+    def extract(acc):
+        out = np.zeros(2049, np.uint64)
+        out[0] = acc[0]; out[1:2048] = np.uint64(0) - acc[2047:0:-1]; out[2048] = acc[2048]
+        return out
+    for e1, e2 in ((1500, 0), (0, 1500), (663, 447), (2049, 4095), (1, 1)):
+        ms = rng.integers(0, 4096, 743).astype(np.uint32)
+        ms[10] = e1; ms[11] = e2
+        o4 = extract(oracle_sk.blind_rotate(ms, luts[0], mode=4))
+        o0 = extract(oracle_sk.blind_rotate(ms, luts[0], mode=0))
+        assert oracle_keys.decrypt_block(o4) == oracle_keys.decrypt_block(o0)
+        d = (oracle_keys.phase(o4) - oracle_keys.phase(o0)) & (2**64 - 1)
+        assert min(d, 2**64 - d) < 2**52
+
+
 def test_negacyclic_padding_bit_rule(oracle_keys, oracle_sk):
     # an input with the padding bit set (v+16) yields -f(v): what lt/le/gt/ge rely on
     lut = radix.lut_poly("sign")

@@ -12,16 +12,24 @@ import sys
 from collections import defaultdict
 
 
+def kname(n):
+    """'void fhs::blind_rotate_mb2_kernel<1>(fhs::...)' -> 'fhs::blind_rotate_mb2_kernel'"""
+    n = n.split("(")[0]
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("<")[0]
+
+
 def rows(d):
     for f in glob.glob(d + "/**/*.db", recursive=True):
         con = sqlite3.connect(f)
         for name, cname, val, disp, dur in con.execute(
                 "select kernel_name, counter_name, value, dispatch_id, duration from counters_collection"):
-            yield name.split("(")[0], cname, float(val), (f, disp), float(dur or 0)
+            yield kname(name), cname, float(val), (f, disp), float(dur or 0)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             dur = float(r.get("End_Timestamp", 0) or 0) - float(r.get("Start_Timestamp", 0) or 0)
-            yield r["Kernel_Name"].split("(")[0], r["Counter_Name"], float(r["Counter_Value"]), (f, r["Dispatch_Id"]), dur
+            yield kname(r["Kernel_Name"]), r["Counter_Name"], float(r["Counter_Value"]), (f, r["Dispatch_Id"]), dur
 
 
 def main():
