@@ -310,9 +310,11 @@ def roofline_for(kernel, pbs_per_launch, launch_ms, n_launches, counters, traffi
         r["frac"] = r["achieved"] / FP64_VALU_PEAK_TFLOPS
     r["counters"] = {k: c.get(k) for k in ("fp64_flop_per_pbs", "valu_insts_per_pbs", "fp64_insts_per_pbs",
                                            "valu_busy_frac_of_simd", "lds_array_busy_frac", "wave_wait_frac",
-                                           "wave_issue_stall_frac", "clock_ghz", "profile")}
+                                           "wave_issue_stall_frac", "clock_ghz", "l1_hit_frac", "l2_hit_frac", "profile")}
     if launch_ms > 0:
-        comp = COMPULSORY_KEY_BYTES + pbs_per_launch * 65_552
+        # keys streamed once per launch at least: Fourier-domain BSK (pair key: 371 x 12 polynomials x 16 KiB) + KSK planes
+        key_bytes = (371 * 12 * 16384 + 2048 * 5 * 743 * 8) if kernel == "blind_rotate_mb2_kernel" else COMPULSORY_KEY_BYTES
+        comp = key_bytes + pbs_per_launch * 65_552
         r["hbm"] = {"note": "NOT the bound: one key sweep out of L2 / Infinity Cache serves the whole launch",
                     "compulsory_bytes_per_launch": comp,
                     "compulsory_gbs": comp / (launch_ms * 1e-3) / 1e9,
