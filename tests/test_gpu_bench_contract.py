@@ -53,6 +53,10 @@ def test_bench_json_line_contract():
     aw = d["single_op"]["as_written"]
     assert aw["levels"] > 4 * d["single_op"]["levels"] and aw["pbs"] > d["single_op"]["pbs"]
     assert d["max_input_sum_c2"] <= 64
+    # the two-key-bits-per-product arithmetic on the same workload, in its own object (not the headline)
+    mb = d["multi_bit"]
+    assert mb["unit"] == "PBS/s" and mb["value"] > d["value"] and mb["roofline"]["kernel"] == "blind_rotate_mb2_kernel"
+    _check_roofline(mb["roofline"])
     # BASELINE configs 3-5 at their fixed sizes in the same run
     for k in ("cfg3_find_encrypted_256", "cfg4_replace_1024", "cfg5_eq_ignore_case_4096", "cfg5_le_4096"):
         assert d["configs"][k]["ms_per_op"] > 0 and d["configs"][k]["pbs"] > 1000
@@ -66,8 +70,9 @@ def test_bench_other_ops(op):
 
 
 @pytest.mark.parametrize("extra", [[], ["--pipelines", "3"], ["--op", "find_enc"], ["--op", "replace", "--chars", "96"],
-                                   ["--op", "le", "--chars", "256"]],
-                         ids=["contains_skewed", "contains_pipelines", "find_enc", "replace_level_parallel", "le"])
+                                   ["--op", "le", "--chars", "256"], ["--arith", "mb2"]],
+                         ids=["contains_skewed", "contains_pipelines", "find_enc", "replace_level_parallel", "le",
+                              "contains_skewed_two_key_bits_per_product"])
 def test_bench_two_ranks_on_one_gpu(extra):
     """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one rank per process), rehearsed
     with two ranks sharing this GPU: FHS_BENCH_BACKEND=gloo makes the library carry its all-gathers through the host

@@ -49,7 +49,9 @@ int main() {
         fhs::build_ntt_tables(ht);
         fhs::HostFftTables ft;
         fhs::build_fft_tables(ft);
-        CHECK(ht.fwd_uni.size() == 64 && ft.w_re.size() == 1024);
+        CHECK(ht.fwd_uni.size() == 64 && ft.w_re.size() == 1024 && ft.mono.size() == 2 * 4096 && ft.r16.size() == 32);
+        const uint64_t *mb = fhs_client_bsk_mb2(ck);              // pair key of FHS_ARITH_F64_FFT_MB2 (generated here)
+        CHECK(mb != nullptr && (mb[0] & 63) == 0 && fhs_client_bsk_mb2(ck) == mb);
         std::vector<double> out((size_t)4 * 2 * 2 * 2048);       // one GGSW
         std::vector<uint64_t> one(fhs_client_bsk(ck), fhs_client_bsk(ck) + 4 * 2048);
         // convert_bsk_to_ntt walks all 742 GGSWs: give it the real key (reads only)

@@ -22,6 +22,8 @@ void orc_pbs_batch(const orc_server_key *k, const u64 *in, const u32 *lut_idx, c
 void orc_negacyclic_schoolbook(const i64 *d, const u64 *b, u64 *res);
 void orc_negacyclic_ntt(const i64 *d, const u64 *b_quantised, u64 *res);
 void orc_bsk_quantize(u64 *bsk, u64 n);
+void orc_keygen_mb2(u64 seed, const u64 *lwe_sk, const u64 *glwe_sk, u64 *bsk_mb2);
+void orc_server_key_set_mb2(orc_server_key *k, const u64 *bsk_mb2);
 u64 orc_bsk_words(void);
 u64 orc_ksk_words(void);
 
@@ -38,6 +40,15 @@ int main(void) {
         orc_encrypt_block(glwe, 7, &rng, in);
         orc_pbs(K, in, lut, out, mode);
         if (orc_decrypt_block(glwe, out) != tab[7]) { printf("mode %d wrong\n", mode); bad = 1; }
+    }
+    {   /* mode 4: two key bits per external product, with its pair key */
+        u64 *mb = calloc((size_t)371 * 3 * 4 * 2048, 8);
+        orc_keygen_mb2(12345, lwe, glwe, mb);
+        orc_server_key_set_mb2(K, mb);
+        orc_encrypt_block(glwe, 11, &rng, in);
+        orc_pbs(K, in, lut, out, 4);
+        if (orc_decrypt_block(glwe, out) != tab[11]) { printf("mode 4 wrong\n"); bad = 1; }
+        free(mb);
     }
     u32 ms[743], idx[4] = {0, 0, 0, 0};
     orc_keyswitch_modswitch(K, in, ms);
