@@ -53,13 +53,14 @@ def parse():
                          "in 4 dependent levels and cannot fill 256 CUs; 1 for the other ops)")
     ap.add_argument("--mode", choices=["fused", "as_written"], default="fused")
     ap.add_argument("--cpu-pbs", type=int, default=-1, help="PBS in the CPU-baseline throughput sample (0 = skip)")
-    ap.add_argument("--arith", choices=["fft", "exact", "mb2"], default="fft",
+    ap.add_argument("--arith", choices=["fft", "exact", "mb2", "exact_mb2"], default="fft",
                     help="arithmetic of the negacyclic products in blind rotation: 'fft' = f64 complex FFT (the "
                          "reference engine's algorithm class, fhs_set_arithmetic(FHS_ARITH_F64_FFT)); 'exact' = "
                          "two-prime exact NTT (library default); 'mb2' = f64 FFT with two LWE key bits per external "
                          "product (FHS_ARITH_F64_FFT_MB2: needs the pair key from the client; tfhe-rs calls this a "
-                         "multi-bit PBS, the reference's CPU engine runs the classic one).  With fft (the default) "
-                         "the other two are timed too (other_arithmetic, multi_bit)")
+                         "multi-bit PBS, the reference's CPU engine runs the classic one); 'exact_mb2' = the same in "
+                         "exact two-prime NTT arithmetic (FHS_ARITH_EXACT_NTT_MB2).  With fft (the default) the others "
+                         "are timed too (other_arithmetic, multi_bit, multi_bit.exact)")
     ap.add_argument("--pipelines", type=int, default=None,
                     help="0 = ONE context with level-skewed batching (fhs_submit + fhs_pump per step: the narrow tail "
                          "levels of step k ride in the wide launch of step k+1, and with several GPUs the exchange + OR "
@@ -313,7 +314,8 @@ def roofline_for(kernel, pbs_per_launch, launch_ms, n_launches, counters, traffi
                                            "wave_issue_stall_frac", "clock_ghz", "l1_hit_frac", "l2_hit_frac", "profile")}
     if launch_ms > 0:
         # keys streamed once per launch at least: Fourier-domain BSK (pair key: 371 x 12 polynomials x 16 KiB) + KSK planes
-        key_bytes = (371 * 12 * 16384 + 2048 * 5 * 743 * 8) if kernel == "blind_rotate_mb2_kernel" else COMPULSORY_KEY_BYTES
+        key_bytes = {"blind_rotate_mb2_kernel": 371 * 12 * 16384 + 2048 * 5 * 743 * 8,
+                     "blind_rotate_ntt_mb2_kernel": 371 * 12 * 32768 + 2048 * 5 * 743 * 8}.get(kernel, COMPULSORY_KEY_BYTES)
         comp = key_bytes + pbs_per_launch * 65_552
         r["hbm"] = {"note": "NOT the bound: one key sweep out of L2 / Infinity Cache serves the whole launch",
                     "compulsory_bytes_per_launch": comp,
@@ -364,14 +366,23 @@ def main():
         raise SystemExit("--pipelines 0 (level-skewed batching) with several GPUs is implemented for contains only")
     P = max(1, args.pipelines)
     sks = [MyServerKey.from_client_key(ck, local_rank, arith=1) for _ in range(P)]   # Fourier-domain key as well
-    ARITH = {"fft": sks[0].ctx.ARITH_F64_FFT, "exact": sks[0].ctx.ARITH_EXACT_NTT, "mb2": sks[0].ctx.ARITH_F64_FFT_MB2}
-    KERNEL = {"fft": "blind_rotate_fft_kernel", "exact": "blind_rotate_kernel", "mb2": "blind_rotate_mb2_kernel"}
-    ARITH_NAME = {"fft": "f64-FFT", "exact": "exact-NTT", "mb2": "f64-FFT, two key bits per external product"}
-    want_mb2 = args.arith == "mb2" or (args.arith == "fft" and not args.skip_extras and args.op == "contains" and world == 1)
+    ARITH = {"fft": sks[0].ctx.ARITH_F64_FFT, "exact": sks[0].ctx.ARITH_EXACT_NTT, "mb2": sks[0].ctx.ARITH_F64_FFT_MB2,
+             "exact_mb2": sks[0].ctx.ARITH_EXACT_NTT_MB2}
+    KERNEL = {"fft": "blind_rotate_fft_kernel", "exact": "blind_rotate_kernel", "mb2": "blind_rotate_mb2_kernel",
+              "exact_mb2": "blind_rotate_ntt_mb2_kernel"}
+    ARITH_NAME = {"fft": "f64-FFT", "exact": "exact-NTT", "mb2": "f64-FFT, two key bits per external product",
+                  "exact_mb2": "exact-NTT, two key bits per external product"}
+    extras_mb = args.arith == "fft" and not args.skip_extras and args.op == "contains" and world == 1
+    want_mb2 = args.arith in ("mb2", "exact_mb2") or extras_mb
     if want_mb2:
         pair_key = ck.bsk_mb2()
-        for x in sks:
-            x.ctx.load_multibit_key(pair_key)
+        for x in sks:                                    # the pair key is converted for the arithmetic selected at the time
+            if args.arith != "exact_mb2":
+                x.ctx.load_multibit_key(pair_key)        # arithmetic 1: Fourier domain
+            if args.arith == "exact_mb2" or extras_mb:
+                x.ctx.set_arithmetic(ARITH["exact"])
+                x.ctx.load_multibit_key(pair_key)        # arithmetic 0: residues modulo the two NTT primes
+                x.ctx.set_arithmetic(ARITH["fft"])
     dists = []
     for x in sks:
         x.ctx.set_arithmetic(ARITH[args.arith])
@@ -533,6 +544,13 @@ def main():
         dt3, outs3, st3, kt3 = timed(n3)
         wl.check(outs3)
         multi_bit = {"pbs_local": float(st3["pbs_executed"]), "dt": dt3, "steps": n3, "kt": kt3}
+        set_arith("exact_mb2")
+        for _ in range(P):
+            step()
+        n4 = 6 if SKEW else max(1, min(args.steps, 2 * P))
+        dt4, outs4, st4, kt4 = timed(n4)
+        wl.check(outs4)
+        multi_bit["exact"] = {"pbs_local": float(st4["pbs_executed"]), "dt": dt4, "steps": n4, "kt": kt4}
         set_arith(args.arith)
 
     # the same workload with twice the strings per step (one GPU, default run): how much of the gap to the kernel-only
@@ -601,6 +619,7 @@ def main():
             secondary["pbs_total"] = secondary["pbs_local"]
         if multi_bit:
             multi_bit["pbs_total"] = multi_bit["pbs_local"]
+            multi_bit["exact"]["pbs_total"] = multi_bit["exact"]["pbs_local"]
         if extras:
             for e in extras.values():
                 e["ms"], e["pbs"] = e["ms_local"], e["pbs_local"]
@@ -628,7 +647,7 @@ def main():
             "higher_is_better": True,
             "scaling": wl.scaling,
             "vs_baseline": None,
-            "dtype": "u64" if args.arith == "exact" else "f64",
+            "dtype": "u64" if args.arith in ("exact", "exact_mb2") else "f64",
             "data": "synthetic",
             "config": {"workload": "%s, %s DAG, %s arithmetic" % (wl.describe(), args.mode, ARITH_NAME[args.arith]),
                        "pipelines": args.pipelines,
@@ -684,6 +703,15 @@ def main():
                 "ms_per_op": multi_bit["dt"] / multi_bit["steps"] / wl.n_strings * 1e3,
                 "roofline": roofline_for("blind_rotate_mb2_kernel", k3[0]["pbs"] / max(1, k3[0]["n"]), k3[0]["ms"],
                                          k3[0]["n"], counters, traffic.get("blind_rotate_mb2_kernel_hbm_bytes_per_launch"))}
+            mx = multi_bit["exact"]
+            k4 = mx["kt"]
+            line["multi_bit"]["exact"] = {
+                "arithmetic": "the same blind rotation in exact two-prime NTT arithmetic (FHS_ARITH_EXACT_NTT_MB2, "
+                              "csrc/nttmb_kernels.hip); bit-exact vs oracle mode 5 (an independent exact algorithm)",
+                "value": mx["pbs_total"] / mx["dt"], "unit": "PBS/s", "steps": mx["steps"],
+                "ms_per_step": mx["dt"] / mx["steps"] * 1e3,
+                "roofline": roofline_for("blind_rotate_ntt_mb2_kernel", k4[0]["pbs"] / max(1, k4[0]["n"]), k4[0]["ms"],
+                                         k4[0]["n"], counters, None)}
         if larger:
             line["larger_batch"] = larger
         if extras:

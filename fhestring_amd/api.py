@@ -51,6 +51,7 @@ class Context:
     ARITH_EXACT_NTT = 0
     ARITH_F64_FFT = 1
     ARITH_F64_FFT_MB2 = 2
+    ARITH_EXACT_NTT_MB2 = 3
 
     def set_arithmetic(self, arith):
         """fhs_set_arithmetic: 0 ARITH_EXACT_NTT (default), 1 ARITH_F64_FFT, 2 ARITH_F64_FFT_MB2 (select before
@@ -369,7 +370,7 @@ class MyServerKey:
         ctx = Context(device_id)
         ctx.set_arithmetic(arith)
         ctx.load_server_key(client_key.bsk(), client_key.ksk())
-        if arith == 2:
+        if arith in (2, 3):
             ctx.load_multibit_key(client_key.bsk_mb2())
         return cls(ctx)
 

@@ -119,6 +119,8 @@ void Context::shutdown() {
     if (d_bsk_fft) (void)hipFree(d_bsk_fft);
     if (d_bsk_mb) (void)hipFree(d_bsk_mb);
     d_bsk_mb = nullptr;
+    if (d_bsk_ntt_mb) (void)hipFree(d_bsk_ntt_mb);
+    d_bsk_ntt_mb = nullptr;
     if (d_fft_tables) (void)hipFree(d_fft_tables);
     d_bsk_fft = nullptr;
     d_fft_tables = nullptr;
@@ -153,7 +155,7 @@ int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
     }
     HostNttTables ht;
     build_ntt_tables(ht);
-    const size_t n_tab = ht.fwd_uni.size() + ht.fwd_lane.size() + ht.inv_uni.size() + ht.inv_lane.size();
+    const size_t n_tab = ht.fwd_uni.size() + ht.fwd_lane.size() + ht.inv_uni.size() + ht.inv_lane.size() + ht.mono.size();
     if (!d_tables) HIP_TRY(hipMalloc(&d_tables, n_tab * sizeof(double)), "hipMalloc tables");
     double *pd = d_tables;
     auto up = [&](const std::vector<double> &v, const double *&slot) -> hipError_t {
@@ -166,6 +168,7 @@ int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
     HIP_TRY(up(ht.fwd_lane, tw.fwd_lane), "copy tables");
     HIP_TRY(up(ht.inv_uni, tw.inv_uni), "copy tables");
     HIP_TRY(up(ht.inv_lane, tw.inv_lane), "copy tables");
+    HIP_TRY(up(ht.mono, d_ntt_mono), "copy tables");
     crt_c = ht.crt_c;
     {   // the kernel's baked-in uniform twiddles must equal the exactly derived ones
         std::vector<double> fu(64), iu(128);
@@ -174,7 +177,7 @@ int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
         if (fu != ht.fwd_uni || iu != ht.inv_uni || c != ht.crt_c)
             return fail(-3, "ntt_consts.inc does not match the derived twiddle tables (regenerate it)");
     }
-    if (arith >= 1) {
+    if (arith == 1 || arith == 2) {
         HostFftTables ft;
         build_fft_tables(ft);
         {   // the kernel's literal twiddles must equal the libm-derived ones
@@ -222,11 +225,14 @@ int Context::keyswitch(const uint64_t *d_in, size_t B, hipStream_t s) {
 }
 
 int Context::set_arithmetic(int mode) {
-    if (mode < 0 || mode > 2) return fail(-1, "unknown arithmetic mode");
-    if (mode >= 1 && key_loaded && !d_bsk_fft)
+    if (mode < 0 || mode > 3) return fail(-1, "unknown arithmetic mode");
+    if ((mode == 1 || mode == 2) && key_loaded && !d_bsk_fft)
         return fail(-3, "select the f64-FFT arithmetic before loading the server key");
     if (mode == 2 && key_loaded && !d_bsk_mb)
         return fail(-3, "the two-bits-per-product arithmetic needs the pair key (fhs_load_multibit_key)");
+    if (mode == 3 && key_loaded && !d_bsk_ntt_mb)
+        return fail(-3, "the exact two-bits-per-product arithmetic needs the pair key, loaded in that arithmetic "
+                        "(fhs_set_arithmetic 3, then fhs_load_multibit_key)");
     arith = mode;
     return 0;
 }
@@ -235,9 +241,22 @@ int Context::set_arithmetic(int mode) {
 // classic key (fftmb_kernels.hip).
 int Context::load_multibit_key(const uint64_t *bsk_mb2) {
     if (!bsk_mb2) return fail(-1, "null key pointer");
-    if (!key_loaded || !d_fft_tables)
-        return fail(-3, "load the server key in an f64-FFT arithmetic (fhs_set_arithmetic 1 or 2) before the pair key");
+    if (!key_loaded) return fail(-3, "load the server key before the pair key");
     HIP_TRY(hipSetDevice(device), "hipSetDevice");
+    if (arith == 0 || arith == 3) {
+        // exact arithmetic: residues of the pair key modulo the two NTT primes, on the 57-bit torus grid (nttmb_kernels.hip)
+        if (!ntt_slot_roots_are_bitreversed()) return fail(-3, "internal: NTT slot order is not bit-reversed");
+        const size_t n_d = (size_t)(LWE_N / 2) * 3 * 4 * 2 * POLY_N;
+        std::vector<double> host(n_d);
+        unsigned hc = std::thread::hardware_concurrency();
+        convert_bsk_to_ntt(bsk_mb2, host.data(), (int)std::min(32u, std::max(1u, hc)), (LWE_N / 2) * 3, 7);
+        if (!d_bsk_ntt_mb) HIP_TRY(hipMalloc(&d_bsk_ntt_mb, n_d * sizeof(double)), "hipMalloc pair key (NTT)");
+        HIP_TRY(hipMemcpy(d_bsk_ntt_mb, host.data(), n_d * sizeof(double), hipMemcpyHostToDevice), "copy pair key");
+        HIP_TRY(prepare_device_for_ntt_mb2(), "kernel attributes");
+        return 0;
+    }
+    if (!d_fft_tables)
+        return fail(-3, "load the server key in an f64-FFT arithmetic (fhs_set_arithmetic 1 or 2) before the pair key");
     const int n_polys = (LWE_N / 2) * 3 * 4;
     const size_t n = (size_t)n_polys * POLY_N;            // u64 in, doubles out (1024 complex per polynomial)
     uint64_t *d_std = nullptr;
@@ -257,9 +276,16 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
     hipError_t e;
     const bool four = arith == 1 && B <= (size_t)fft4_max_batch;
     if (arith == 2 && !d_bsk_mb) return fail(-3, "pair key not loaded (fhs_load_multibit_key)");
+    if (arith == 3 && !d_bsk_ntt_mb) return fail(-3, "pair key not loaded in the exact arithmetic (fhs_load_multibit_key)");
     if (arith == 1 && !d_bsk_fft) return fail(-3, "Fourier-domain key not loaded");
     timer.begin(four ? 2 : 0, B, s);
-    if (arith == 2) {
+    if (arith == 3) {
+        BlindRotateNttMb2Params p{};
+        p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;
+        p.bsk_ntt_mb = d_bsk_ntt_mb; p.tw = tw; p.crt_c = crt_c; p.mono = d_ntt_mono;
+        p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
+        e = launch_blind_rotate_ntt_mb2(p, s);
+    } else if (arith == 2) {
         BlindRotateMb2Params p{};
         p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;
         p.bsk_mb = d_bsk_mb;

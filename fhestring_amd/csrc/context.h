@@ -64,6 +64,8 @@ class Context {
     int wg_slots = 1024;                  // 4 workgroups per CU
     // arith 2 (FHS_ARITH_F64_FFT_MB2): two key bits per external product (fftmb_kernels.hip); needs the pair key
     double *d_bsk_mb = nullptr;       // [371][K1,K2,K3][4][1024] complex
+    double *d_bsk_ntt_mb = nullptr;   // arith 3 (FHS_ARITH_EXACT_NTT_MB2): [371][K1,K2,K3][4][2 primes][2048] residues
+    const double *d_ntt_mono = nullptr;   // [2][4096] inside d_tables
     int load_multibit_key(const uint64_t *bsk_mb2);   // [371][K1,K2,K3][4][2048] u64 standard domain (fhs_client_bsk_mb2)
     int fft4_max_batch = 512;         // batches up to this size use the 4-wavefront kernel (lower latency)
     int set_arithmetic(int mode);

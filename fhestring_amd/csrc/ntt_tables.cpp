@@ -92,10 +92,35 @@ void build_ntt_tables(HostNttTables &t) {
         }
     }
     t.crt_c = centred(powm(NTT_P0 % NTT_P1, NTT_P1 - 2, NTT_P1), NTT_P1);
+    t.mono.assign(2 * 4096, 0.0);
+    const uint64_t psis[2] = {NTT_PSI0, NTT_PSI1};
+    for (int q = 0; q < 2; q++) {
+        const PrimeTables &pt = prime(q);
+        uint64_t a = 1;
+        for (int k = 0; k < 4096; k++) {
+            t.mono[q * 4096 + k] = centred(a, pt.p);
+            a = mulm(a, psis[q], pt.p);
+        }
+    }
 }
 
-void convert_bsk_to_ntt(const uint64_t *bsk_std, double *out, int nthreads) {
-    const size_t n_polys = (size_t)LWE_N * 4;
+// The slot at array index idx of the device's forward transform holds the evaluation at psi^(2 bitrev11(idx) + 1):
+// checked once per process on the monomial X (Context::load_multibit_key refuses to run otherwise).
+bool ntt_slot_roots_are_bitreversed() {
+    for (int q = 0; q < 2; q++) {
+        const PrimeTables &pt = prime(q);
+        std::vector<uint64_t> a(POLY_N, 0);
+        a[1] = 1;
+        ntt_forward_exact(a.data(), pt);
+        const uint64_t psi = q ? NTT_PSI1 : NTT_PSI0;
+        for (unsigned idx = 0; idx < (unsigned)POLY_N; idx++)
+            if (a[idx] != powm(psi, 2 * bitrev11(idx) + 1, pt.p)) return false;
+    }
+    return true;
+}
+
+void convert_bsk_to_ntt(const uint64_t *bsk_std, double *out, int nthreads, int n_ggsw, int quant_bits) {
+    const size_t n_polys = (size_t)n_ggsw * 4;
     if (nthreads < 1) nthreads = 1;
     auto work = [&](int tid) {
         std::vector<uint64_t> a(POLY_N);
@@ -105,8 +130,8 @@ void convert_bsk_to_ntt(const uint64_t *bsk_std, double *out, int nthreads) {
                 const PrimeTables &pt = prime(q);
                 for (int n = 0; n < POLY_N; n++) {
                     // round to the 58-bit grid, signed representative of the torus element / 2^6
-                    const uint64_t r = (src[n] + (1ull << (BSK_QUANT_BITS - 1))) & ~((1ull << BSK_QUANT_BITS) - 1);
-                    const int64_t v = (int64_t)r >> BSK_QUANT_BITS;
+                    const uint64_t r = (src[n] + (1ull << (quant_bits - 1))) & ~((1ull << quant_bits) - 1);
+                    const int64_t v = (int64_t)r >> quant_bits;
                     const int64_t m = v % (int64_t)pt.p;
                     a[n] = (uint64_t)(m < 0 ? m + (int64_t)pt.p : m);
                 }

@@ -76,6 +76,20 @@ struct BlindRotateMb2Params {
     int B;
 };
 
+// Two key bits per external product in exact arithmetic (nttmb_kernels.hip, FHS_ARITH_EXACT_NTT_MB2).
+struct BlindRotateNttMb2Params {
+    const uint64_t *ks;
+    const uint32_t *lut_idx;
+    const uint64_t *luts;
+    const double *bsk_ntt_mb; // [371 pairs][K1,K2,K3][row 2][col 2][prime 2][16][64 lanes][2], pre-scaled by N^-1 (57-bit grid)
+    NttTables tw;
+    double crt_c;
+    const double *mono;       // [2 primes][4096] psi_q^k centred
+    uint64_t *out;
+    uint64_t *const *out_ptrs;
+    int B;
+};
+
 // One lincomb output: out[dst] = sum_t coef[t] * src[t] + konst * 2^59 (body only)
 struct LinDesc {
     uint32_t first_term;
@@ -98,6 +112,8 @@ hipError_t launch_blind_rotate_fft4(const BlindRotateFftParams &p, hipStream_t s
 hipError_t launch_bsk_to_fft(const uint64_t *d_bsk_std, double *d_out, const double *d_lanetab, hipStream_t s,
                              int n_polys = LWE_N * 4);
 hipError_t launch_blind_rotate_mb2(const BlindRotateMb2Params &p, hipStream_t s);    // 2 wavefronts per ciphertext
+hipError_t launch_blind_rotate_ntt_mb2(const BlindRotateNttMb2Params &p, hipStream_t s);   // 4 wavefronts per ciphertext
+hipError_t prepare_device_for_ntt_mb2();
 // the scalar twiddle literals baked into fft_kernels.hip: W[16] (index 1 and even indices used), U[3]
 void fft_uniform_consts(double *w_re, double *w_im, double *u_re, double *u_im);
 // matrix-core keyswitch (ks_kernels.hip): KSK as 8 planes of balanced signed bytes in MFMA fragment order

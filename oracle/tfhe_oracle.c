@@ -445,6 +445,7 @@ typedef struct {
     double *bsk_fft; /* [742][2 rows][2 cols][1024] complex (re,im): f64-FFT variant (mode 2) */
     double *bsk_fm;  /* [742][2 rows][2 cols][16][64][2]: mirror of the GPU FFT kernel (mode 3), lazy */
     double *bsk_mb;  /* [371][K1,K2,K3][2 rows][2 cols][16][64][2]: pair key of mode 4 (orc_server_key_set_mb2) */
+    u64 *bsk_mb_q7;  /* [371][K1,K2,K3][2 rows][2 cols][2048] std domain, rounded to multiples of 2^7: mode 5 */
 } orc_server_key;
 
 u64 orc_bsk_words(void) { return BSK_WORDS; }
@@ -585,12 +586,15 @@ void orc_server_key_set_mb2(orc_server_key *k, const u64 *bsk_mb2) {
     free(k->bsk_mb);
     k->bsk_mb = (double *)malloc(MB2_POLYS * 2 * FM * sizeof(double));
     for (size_t p = 0; p < MB2_POLYS; p++) fmirror_bsk_poly(q + p * POLY_N, k->bsk_mb + p * 2 * FM);
-    free(q);
+    /* mode 5 (exact arithmetic): the 57-bit torus grid, so that the integer result stays inside the product's CRT range */
+    for (size_t i = 0; i < MB2_POLYS * POLY_N; i++) q[i] = (bsk_mb2[i] + (1ull << 6)) & ~((1ull << 7) - 1);
+    free(k->bsk_mb_q7);
+    k->bsk_mb_q7 = q;
 }
 
 void orc_server_key_free(orc_server_key *k) {
     if (!k) return;
-    free(k->bsk); free(k->ksk); free(k->bsk_ntt); free(k->bsk_fft); free(k->bsk_fm); free(k->bsk_mb); free(k);
+    free(k->bsk); free(k->ksk); free(k->bsk_ntt); free(k->bsk_fft); free(k->bsk_fm); free(k->bsk_mb); free(k->bsk_mb_q7); free(k);
 }
 
 /* ---- client side (src/client_key.rs:85-106 via RadixClientKey) ---------- */
@@ -776,11 +780,71 @@ static void blind_rotate_mb2(const orc_server_key *k, const u32 *ms, const u64 *
     }
 }
 
+/* mode 5: the product's FHS_ARITH_EXACT_NTT_MB2 (fhestring_amd/csrc/nttmb_kernels.hip) restated with a different exact
+ * algorithm.  The kernel forms K' = K1 (X^e1 - 1) + K2 (X^e2 - 1) + K3 (X^(e1+e2) - 1) pointwise in the domain of its
+ * two-prime NTT; here K' is formed in the COEFFICIENT domain (rotate and subtract, wrapping u64 = exact, |K'| < 2^60) and
+ * multiplied with the digits of ACC through the Goldilocks NTT on two key limbs like mode 0.  Both are exact integer
+ * arithmetic mod 2^64, so the outputs must be equal bit for bit. */
+static void blind_rotate_mb2_exact(const orc_server_key *k, const u32 *ms, const u64 *lut, u64 *acc /* [2][N] */) {
+    u64 *dn = (u64 *)malloc(2 * POLY_N * sizeof(u64));
+    u64 *kc = (u64 *)malloc(POLY_N * sizeof(u64));
+    u64 *rt = (u64 *)malloc(POLY_N * sizeof(u64));
+    u64 *lim = (u64 *)malloc(2 * POLY_N * sizeof(u64));
+    u64 *tt = (u64 *)malloc(2 * POLY_N * sizeof(u64));
+    const u64 lm = (1ull << 29) - 1;
+    memset(acc, 0, POLY_N * sizeof(u64));
+    poly_rotate(lut, (2 * POLY_N - ms[LWE_N]) & (2 * POLY_N - 1), acc + POLY_N);
+    for (int p = 0; p < LWE_N / 2; p++) {
+        const unsigned e[3] = { ms[2 * p], ms[2 * p + 1], (ms[2 * p] + ms[2 * p + 1]) & (2 * POLY_N - 1) };
+        if ((e[0] | e[1]) == 0) continue;
+        for (int c = 0; c < 2; c++) {
+            for (int n = 0; n < POLY_N; n++) {
+                i64 d = pbs_digit(acc[c * POLY_N + n]);
+                dn[c * POLY_N + n] = d < 0 ? GP - (u64)(-d) : (u64)d;
+            }
+            g_ntt_fwd(dn + c * POLY_N);
+        }
+        for (int col = 0; col < 2; col++) {
+            memset(tt, 0, 2 * POLY_N * sizeof(u64));
+            for (int row = 0; row < 2; row++) {
+                memset(kc, 0, POLY_N * sizeof(u64));
+                for (int t = 0; t < 3; t++) {
+                    const u64 *K = k->bsk_mb_q7 + ((((size_t)p * 3 + t) * 2 + row) * 2 + col) * POLY_N;
+                    poly_rotate(K, e[t], rt);
+                    for (int n = 0; n < POLY_N; n++) kc[n] += rt[n] - K[n];
+                }
+                for (int n = 0; n < POLY_N; n++) {           /* signed value / 2^7 -> limb 0 in [0, 2^29), signed limb 1 */
+                    const i64 v = (i64)kc[n] >> 7;
+                    const u64 l0 = (u64)v & lm;
+                    const i64 l1 = (v - (i64)l0) >> 29;
+                    lim[n] = l0;
+                    lim[POLY_N + n] = l1 < 0 ? GP - (u64)(-l1) : (u64)l1;
+                }
+                g_ntt_fwd(lim);
+                g_ntt_fwd(lim + POLY_N);
+                for (int limb = 0; limb < 2; limb++)
+                    for (int n = 0; n < POLY_N; n++)
+                        tt[limb * POLY_N + n] = g_add(tt[limb * POLY_N + n], g_mul(dn[row * POLY_N + n], lim[limb * POLY_N + n]));
+            }
+            g_ntt_inv(tt);
+            g_ntt_inv(tt + POLY_N);
+            for (int n = 0; n < POLY_N; n++) {
+                u64 r0 = tt[n], r1 = tt[POLY_N + n];
+                u64 s0 = (r0 > GP / 2) ? r0 - GP : r0;
+                u64 s1 = (r1 > GP / 2) ? r1 - GP : r1;
+                acc[col * POLY_N + n] += (s0 + (s1 << 29)) << 7;
+            }
+        }
+    }
+    free(dn); free(kc); free(rt); free(lim); free(tt);
+}
+
 /* mode 0: Goldilocks NTT (2 x 29-bit key limbs, exact); mode 1: schoolbook (exact);
  * mode 2: f64 FFT (approximate, CPU-baseline only); mode 3: mirror of the GPU f64-FFT kernel */
 static void blind_rotate(const orc_server_key *k, const u32 *ms, const u64 *lut,
                          u64 *acc /* [2][N] */, int mode) {
     if (mode == 4) { blind_rotate_mb2(k, ms, lut, acc); return; }
+    if (mode == 5) { blind_rotate_mb2_exact(k, ms, lut, acc); return; }
     u64 *rot = (u64 *)malloc(POLY_N * sizeof(u64));
     i64 *dig = (i64 *)malloc(2 * POLY_N * sizeof(i64));
     u64 *dn = (u64 *)malloc(2 * POLY_N * sizeof(u64));
@@ -874,8 +938,8 @@ static void blind_rotate(const orc_server_key *k, const u32 *ms, const u64 *lut,
 
 static void ensure_mode(const orc_server_key *kc, int mode) {
     orc_server_key *k = (orc_server_key *)kc;
-    if (mode == 4 && !k->bsk_mb) {
-        fprintf(stderr, "oracle: mode 4 needs the pair key (orc_server_key_set_mb2)\n");
+    if ((mode == 4 || mode == 5) && !k->bsk_mb) {
+        fprintf(stderr, "oracle: modes 4 and 5 need the pair key (orc_server_key_set_mb2)\n");
         abort();
     }
     if (mode != 3) return;

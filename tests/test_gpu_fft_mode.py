@@ -220,14 +220,43 @@ def test_golden_vectors_with_two_key_bits_per_product(product_mb2, v):
     check_vector(v, run_vector(v, *env))
 
 
-def test_mb2_blind_rotation_on_chosen_masks(oracle_keys, oracle_sk):
-    """fhs_debug_blind_rotate_batch in FHS_ARITH_F64_FFT_MB2 against oracle mode 4, every output word, on chosen
+@pytest.fixture(scope="module")
+def product_exact_mb2():
+    import fhestring_amd
+    from fhestring_amd.api import MyClientKey
+    ck = MyClientKey(0xF5E57121)
+    sk = ck.get_server_key(0, arith=fhestring_amd.Context.ARITH_EXACT_NTT_MB2)
+    sk.set_mode(1)
+    yield ck, sk
+    sk.close()
+    ck.close()
+
+
+@pytest.mark.parametrize("v", _golden(), ids=[v["name"] for v in _golden()])
+def test_golden_vectors_with_two_key_bits_per_product_exact(product_exact_mb2, v):
+    """The reference's own test literals through the fused DAGs with FHS_ARITH_EXACT_NTT_MB2 (csrc/nttmb_kernels.hip)."""
+    from golden_util import run_vector, check_vector
+    ck, sk = product_exact_mb2
+    assert sk.ctx.arithmetic == sk.ctx.ARITH_EXACT_NTT_MB2
+    sk.trivial_char = sk.trivial
+    env = (sk, lambda t, pad: ck.encrypt(t, pad, None, sk), lambda t: ck.encrypt_no_padding(t, sk),
+           lambda c: ck.encrypt_char(c, sk), ck.decrypt, ck.decrypt_char)
+    if "expected_panic" in v:
+        with pytest.raises(OverflowError, match=v["expected_panic"]):
+            run_vector(v, *env)
+        return
+    check_vector(v, run_vector(v, *env))
+
+
+@pytest.mark.parametrize("arith,mode", [(2, 4), (3, 5)], ids=["f64_fft", "exact_ntt"])
+def test_mb2_blind_rotation_on_chosen_masks(oracle_keys, oracle_sk, arith, mode):
+    """fhs_debug_blind_rotate_batch in FHS_ARITH_F64_FFT_MB2 / FHS_ARITH_EXACT_NTT_MB2 against oracle mode 4 / 5, every output word, on chosen
     mod-switched masks: all zero (no product at all), one element of a pair zero, odd / even exponents (the sign of the
     odd registers' monomial), exponents >= 2048 (negated monomials), and random ones."""
     import fhestring_amd
     from oracle import radix
     ctx = fhestring_amd.Context(0)
-    ctx.set_arithmetic(ctx.ARITH_F64_FFT_MB2)
+    ctx.set_arithmetic(arith)
     ctx.load_server_key(oracle_keys.bsk, oracle_keys.ksk)
     with pytest.raises(fhestring_amd.FhsError, match="pair key"):
         ctx.blind_rotate_batch(np.zeros((1, 743), np.uint64), np.zeros(1, np.uint32), radix.lut_poly("msg")[None, :])
@@ -247,7 +276,7 @@ def test_mb2_blind_rotation_on_chosen_masks(oracle_keys, oracle_sk):
     idx = (np.arange(len(ms)) % 2).astype(np.uint32)
     got = ctx.blind_rotate_batch(ms.astype(np.uint64) << np.uint64(52), idx, luts)
     for k in range(len(ms)):
-        acc = oracle_sk.blind_rotate(ms[k], luts[idx[k]], mode=4)
+        acc = oracle_sk.blind_rotate(ms[k], luts[idx[k]], mode=mode)
         want = np.zeros(2049, np.uint64)
         want[0] = acc[0]; want[1:2048] = np.uint64(0) - acc[2047:0:-1]; want[2048] = acc[2048]
         assert np.array_equal(got[k], want), k

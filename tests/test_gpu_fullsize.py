@@ -8,13 +8,13 @@ pytestmark = pytest.mark.gpu
 SEED = 0xF5E57121
 
 
-@pytest.fixture(scope="module", params=["exact_ntt", "f64_fft", "f64_fft_mb2"])
+@pytest.fixture(scope="module", params=["exact_ntt", "f64_fft", "f64_fft_mb2", "exact_ntt_mb2"])
 def product(request):
     """The arithmetics of blind rotation (fhs_set_arithmetic): the library default, the one bench.py times, and the
     two-key-bits-per-product variant of the latter."""
     from fhestring_amd.api import MyClientKey
     ck = MyClientKey(SEED)
-    sk = ck.get_server_key(0, arith={"exact_ntt": 0, "f64_fft": 1, "f64_fft_mb2": 2}[request.param])
+    sk = ck.get_server_key(0, arith={"exact_ntt": 0, "f64_fft": 1, "f64_fft_mb2": 2, "exact_ntt_mb2": 3}[request.param])
     sk.set_mode(1)
     yield ck, sk
     sk.close()

@@ -19,7 +19,9 @@ the decoding threshold (half a LUT box = 64 units of 2^52):
   2^50.3 at base 2^24, 2^51.4 at 2^25, also with a noise-free key; 2^23 is the optimum).  The linear combinations then
   add at most 8 x 2^49.62 = 1.54 units instead of 1.0 to the ~9 units of keyswitch + modulus switch: total error at the
   design limit 9.05 instead of 8.98 units on an average key (log2 p_fail -39.2 instead of -39.8); all other bounds
-  below are the same for the three arithmetics;
+  below are the same for all arithmetics;
+* FHS_ARITH_EXACT_NTT_MB2 (the same in exact integer arithmetic) has no f64 rounding at all: only the 1.5x decomposition
+  rounding remains, sigma 2^48.8, inside the classic bound of 2^49.2;
 * the floor itself: 64 / sigma >= 6.6.  (Averaged over keys the parameter set gives 8.92 units = 7.17 sigma =
   2^-40.3; the balanced keyswitch digits [-4, 3] have mean -1/2, so a given key shifts the error by
   -1/2 * sum(ksk noise) ~ N(0, 1.5 units): the test key's floor is 9.4 units = 6.8 sigma.  tfhe-rs has the same term.)
@@ -35,14 +37,14 @@ import noise_util as nu
 pytestmark = pytest.mark.gpu
 SEED = 0xF5E57121
 NOISE_BUDGET = 64            # include/fhestring_hip.h FHS_NOISE_BUDGET_SUM_C2
-PBS_SIGMA_LOG2_BOUND = {"f64_fft": 49.2, "exact_ntt": 49.2, "f64_fft_mb2": 49.9}
+PBS_SIGMA_LOG2_BOUND = {"f64_fft": 49.2, "exact_ntt": 49.2, "f64_fft_mb2": 49.9, "exact_ntt_mb2": 49.2}
 
 
-@pytest.fixture(scope="module", params=["f64_fft", "exact_ntt", "f64_fft_mb2"])
+@pytest.fixture(scope="module", params=["f64_fft", "exact_ntt", "f64_fft_mb2", "exact_ntt_mb2"])
 def product(request):
     from fhestring_amd.api import MyClientKey
     ck = MyClientKey(SEED)
-    sk = ck.get_server_key(0, arith={"exact_ntt": 0, "f64_fft": 1, "f64_fft_mb2": 2}[request.param])
+    sk = ck.get_server_key(0, arith={"exact_ntt": 0, "f64_fft": 1, "f64_fft_mb2": 2, "exact_ntt_mb2": 3}[request.param])
     sk.set_mode(1)
     yield ck, sk, request.param
     sk.close()

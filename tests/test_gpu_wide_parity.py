@@ -138,6 +138,30 @@ def test_mb2_pbs_sampled_rows_at_bench_width(fft_ctx, oracle_keys, wide_inputs, 
         assert oracle_keys.decrypt_block(got[r]) == oracle_keys.decrypt_block(classic[k]), r
 
 
+def test_exact_mb2_pbs_sampled_rows_at_bench_width(exact_ctx, oracle_keys, wide_inputs, oracle_sk):
+    """FHS_ARITH_EXACT_NTT_MB2 (two key bits per external product in exact arithmetic, csrc/nttmb_kernels.hip) against
+    oracle mode 5 -- an independent exact algorithm (keys combined in the coefficient domain, Goldilocks NTT) -- every
+    output word of the sampled rows at B = 3968, plus a narrow batch; then back to the classic exact kernel."""
+    B = 3968
+    _, cts = wide_inputs
+    luts = _luts()
+    idx = (np.arange(B) % len(NAMES)).astype(np.uint32)
+    oracle_sk.set_mb2(oracle_keys.bsk_mb2)
+    exact_ctx.load_multibit_key(oracle_keys.bsk_mb2)          # arithmetic 0 selected: converted for the exact arithmetic
+    exact_ctx.set_arithmetic(exact_ctx.ARITH_EXACT_NTT_MB2)
+    try:
+        got = exact_ctx.pbs_batch(cts[:B], idx, luts)
+        small = exact_ctx.pbs_batch(cts[:5], idx[:5], luts)
+    finally:
+        exact_ctx.set_arithmetic(exact_ctx.ARITH_EXACT_NTT)
+    rows = _sample_rows(B, 10)[::2]                         # the exact oracle takes 0.8 s per bootstrap
+    _check_sampled(got, cts[:B], idx, luts, rows, oracle_sk, mode=5)
+    assert np.array_equal(small, got[:5])
+    classic = exact_ctx.pbs_batch(cts[rows], idx[rows], luts)
+    for k, r in enumerate(rows):
+        assert oracle_keys.decrypt_block(got[r]) == oracle_keys.decrypt_block(classic[k]), r
+
+
 def test_pbs_batch_device_sampled_rows(fft_ctx, exact_ctx, wide_inputs, oracle_sk):
     """fhs_pbs_batch_device: device-resident inputs/outputs (torch tensors), both arithmetics."""
     import torch

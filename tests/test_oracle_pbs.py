@@ -112,6 +112,29 @@ def test_two_key_bits_per_product_mode_decrypts_and_tracks_the_exact_path(oracle
         assert min(d, 2**64 - d) < 2**52
 
 
+def test_exact_two_key_bits_per_product_mode(oracle_keys, oracle_sk):
+    """mode 5 = the product's FHS_ARITH_EXACT_NTT_MB2 restated (keys combined in the coefficient domain, exact): decrypts
+    like the classic exact bootstrap, phases within 2^52, and agrees with the f64 mirror of the same algebra (mode 4)
+    to within the f64 rounding noise."""
+    oracle_sk.set_mb2(oracle_keys.bsk_mb2)
+    names = ["msg", "carry", "eq_biv", "sign"]
+    luts = np.stack([radix.lut_poly(n) for n in names])
+    rng = np.random.default_rng(43)
+    msgs = rng.integers(0, 32, 8)
+    idx = (np.arange(8) % 4).astype(np.uint32)
+    cts = np.stack([oracle_keys.encrypt_block(int(m)) for m in msgs])
+    o5 = oracle_sk.pbs_batch(cts, idx, luts, mode=5)
+    o0 = oracle_sk.pbs_batch(cts, idx, luts, mode=0)
+    o4 = oracle_sk.pbs_batch(cts, idx, luts, mode=4)
+    for b in range(8):
+        assert oracle_keys.decrypt_block(o5[b]) == oracle_keys.decrypt_block(o0[b])
+        for other in (o0, o4):
+            d = (oracle_keys.phase(o5[b]) - oracle_keys.phase(other[b])) & (2**64 - 1)
+            assert min(d, 2**64 - d) < 2**52
+    ms = np.zeros(743, np.uint32); ms[742] = 3
+    assert np.array_equal(oracle_sk.blind_rotate(ms, luts[0], mode=5), oracle_sk.blind_rotate(ms, luts[0], mode=0))
+
+
 def test_negacyclic_padding_bit_rule(oracle_keys, oracle_sk):
     # an input with the padding bit set (v+16) yields -f(v): what lt/le/gt/ge rely on
     lut = radix.lut_poly("sign")
