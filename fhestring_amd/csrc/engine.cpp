@@ -210,8 +210,7 @@ Bid Engine::pbs(Bid x, int lut) {
     // fused mode: an identical bootstrap (same LUT on the same linear combination of the same blocks) is computed once,
     // e.g. the high-nibble test of a character against pattern characters that share their high nibble
     uint64_t h1 = 0, h2 = 0;
-    static const bool no_cse = std::getenv("FHS_NO_CSE") != nullptr;      // debugging switch
-    const bool share = mode == 1 && !no_cse;
+    const bool share = mode == 1;
     if (share) {
         auto mix = [](uint64_t v, uint64_t k) {
             v = (v ^ (v >> 31)) * k;
@@ -250,8 +249,7 @@ Bid Engine::pbs(Bid x, int lut) {
     n.level = lvl;
     pending_.push_back({id, n.gen});
     if (lvl == 1) n_depth1_++;
-    static const bool no_auto = std::getenv("FHS_NO_AUTO_FLUSH") != nullptr;   // debugging switch
-    if (auto_flush_pending && !no_auto && !manual_jobs_ && !capture_max_rows && !in_auto_flush_ &&
+    if (auto_flush_pending && !manual_jobs_ && !capture_max_rows && !in_auto_flush_ &&
         sched_.empty() && !(dist_world > 1 && !level_parallel) && (planner || ctx.key_loaded)) {
         // peel the ready level when a whole batch has accumulated -- or, on a real device, as soon as a grid's worth is
         // ready and the previous launch group has finished (polled every 256 recorded bootstraps): the GPU never idles

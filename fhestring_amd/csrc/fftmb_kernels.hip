@@ -27,8 +27,6 @@
 // Same mapping as fft_kernels.hip: a workgroup of 2 wavefronts per ciphertext (persistent), wavefront j owns GLWE
 // polynomial j, 16 complex points per lane; same transform (fft_transform.h), so mode 4 of the CPU oracle mirrors
 // the kernel operation for operation and the output is checked bit for bit.
-#include <cstdlib>
-
 #include "fft_transform.h"
 
 namespace fhs {
@@ -236,11 +234,7 @@ hipError_t launch_blind_rotate_mb2(const BlindRotateMb2Params &p, hipStream_t s)
     hipError_t e = hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     const int grid = p.B < p.slots ? p.B : p.slots;
-    static const int variant = std::getenv("FHS_MB2_VARIANT") ? std::atoi(std::getenv("FHS_MB2_VARIANT")) : 0;   // experiment
-    switch (variant) {
-    case 1: hipLaunchKernelGGL((blind_rotate_mb2_kernel<2>), dim3(grid), dim3(128), lds, s, p); break;
-    default: hipLaunchKernelGGL((blind_rotate_mb2_kernel<1>), dim3(grid), dim3(128), lds, s, p); break;
-    }
+    hipLaunchKernelGGL((blind_rotate_mb2_kernel<1>), dim3(grid), dim3(128), lds, s, p);   // key rows one half step ahead
     return hipGetLastError();
 }
 

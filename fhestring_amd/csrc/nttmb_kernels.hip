@@ -58,6 +58,7 @@ __device__ __forceinline__ void mb_phase_crt(const double (&x)[32], uint64_t (&a
 
 }  // namespace
 
+template <int PF>
 __global__ __launch_bounds__(256, 2) void blind_rotate_ntt_mb2_kernel(BlindRotateNttMb2Params P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ct = blockIdx.x;
@@ -135,9 +136,12 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_ntt_mb2_kernel(BlindRotat
         const gk_t kbase = (gk_t)(P.bsk_ntt_mb + ((size_t)pr * 12 + j) * 2 * POLY_N + (size_t)q * POLY_N) + lane;
         // key t of row `row`: kbase[((t * 2 + row) * 2) * POLY_N (doubles -> double2: / 2 ... see idx()) + cpair * 64]
         auto idx = [](int t, int row, int cpair) { return ((t * 2 + row) * 2) * POLY_N + cpair * 64; };
-        double2_t ko[3], kp[3];
+        // ring over register pairs: the rows of pair cp + PF are requested while pair cp is computed
+        double2_t ko[PF + 1][3], kp[PF + 1][3];
 #pragma unroll
-        for (int t = 0; t < 3; t++) { ko[t] = kbase[idx(t, j, 0)]; kp[t] = kbase[idx(t, 1 - j, 0)]; }   // over the barrier
+        for (int h = 0; h < PF; h++)
+#pragma unroll
+            for (int t = 0; t < 3; t++) { ko[h][t] = kbase[idx(t, j, h)]; kp[h][t] = kbase[idx(t, 1 - j, h)]; }   // over the barrier
 #pragma unroll
         for (int c = 0; c < 32; c++) my[c * 64 + lane] = x[c];
         __syncthreads();
@@ -145,11 +149,15 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_ntt_mb2_kernel(BlindRotat
             const uint32_t s1 = (e1 & 1u) << 31, s2 = (e2 & 1u) << 31;      // odd register: psi^(2048 e) = (-1)^e
 #pragma unroll
             for (int cp = 0; cp < 16; cp++) {
-                double2_t no[3], np[3];
-                if (cp + 1 < 16) {
+                if (cp + PF < 16) {
 #pragma unroll
-                    for (int t = 0; t < 3; t++) { no[t] = kbase[idx(t, j, cp + 1)]; np[t] = kbase[idx(t, 1 - j, cp + 1)]; }
+                    for (int t = 0; t < 3; t++) {
+                        ko[(cp + PF) % (PF + 1)][t] = kbase[idx(t, j, cp + PF)];
+                        kp[(cp + PF) % (PF + 1)][t] = kbase[idx(t, 1 - j, cp + PF)];
+                    }
                 }
+                const double2_t (&KO)[3] = ko[cp % (PF + 1)];
+                const double2_t (&KP)[3] = kp[cp % (PF + 1)];
                 const int c = 2 * cp;
                 // wave-uniform 32nd roots psi^(128 m), m = rev5(c) e = rev4(cp) e  (mod 32)
                 const int r4 = ((cp & 1) << 3) | ((cp & 2) << 1) | ((cp & 4) >> 1) | ((cp & 8) >> 3);
@@ -161,16 +169,12 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_ntt_mb2_kernel(BlindRotat
                 const double am1 = a1 - 1.0, bm1 = b1 - 1.0, abm1 = ab1 - 1.0;
                 const double o0 = partner[c * 64 + lane], o1 = partner[(c + 1) * 64 + lane];
                 // combined key of each row at the two points, |A| <= 1.6 p
-                const double Ao0 = mulmod(ko[0].x, am0, p, pinv) + mulmod(ko[1].x, bm0, p, pinv) + mulmod(ko[2].x, abm0, p, pinv);
-                const double Ap0 = mulmod(kp[0].x, am0, p, pinv) + mulmod(kp[1].x, bm0, p, pinv) + mulmod(kp[2].x, abm0, p, pinv);
-                const double Ao1 = mulmod(ko[0].y, am1, p, pinv) + mulmod(ko[1].y, bm1, p, pinv) + mulmod(ko[2].y, abm1, p, pinv);
-                const double Ap1 = mulmod(kp[0].y, am1, p, pinv) + mulmod(kp[1].y, bm1, p, pinv) + mulmod(kp[2].y, abm1, p, pinv);
+                const double Ao0 = mulmod(KO[0].x, am0, p, pinv) + mulmod(KO[1].x, bm0, p, pinv) + mulmod(KO[2].x, abm0, p, pinv);
+                const double Ap0 = mulmod(KP[0].x, am0, p, pinv) + mulmod(KP[1].x, bm0, p, pinv) + mulmod(KP[2].x, abm0, p, pinv);
+                const double Ao1 = mulmod(KO[0].y, am1, p, pinv) + mulmod(KO[1].y, bm1, p, pinv) + mulmod(KO[2].y, abm1, p, pinv);
+                const double Ap1 = mulmod(KP[0].y, am1, p, pinv) + mulmod(KP[1].y, bm1, p, pinv) + mulmod(KP[2].y, abm1, p, pinv);
                 x[c] = mulmod(x[c], Ao0, p, pinv) + mulmod(o0, Ap0, p, pinv);
                 x[c + 1] = mulmod(x[c + 1], Ao1, p, pinv) + mulmod(o1, Ap1, p, pinv);
-                if (cp + 1 < 16) {
-#pragma unroll
-                    for (int t = 0; t < 3; t++) { ko[t] = no[t]; kp[t] = np[t]; }
-                }
             }
         }
         __syncthreads();
@@ -203,13 +207,15 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_ntt_mb2_kernel(BlindRotat
 }
 
 hipError_t prepare_device_for_ntt_mb2() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(blind_rotate_ntt_mb2_kernel),
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(blind_rotate_ntt_mb2_kernel<1>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)blind_rotate_lds_bytes());
 }
 
 hipError_t launch_blind_rotate_ntt_mb2(const BlindRotateNttMb2Params &p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(blind_rotate_ntt_mb2_kernel, dim3(p.B), dim3(256), blind_rotate_lds_bytes(), s, p);
+    // key rows are requested one register pair ahead; two or three ahead measured 84.4 / 91.6 ms per 3968 bootstraps
+    // against 82.6 (spills: the kernel is VALU-bound at 94 % busy, not waiting for the key)
+    hipLaunchKernelGGL((blind_rotate_ntt_mb2_kernel<1>), dim3(p.B), dim3(256), blind_rotate_lds_bytes(), s, p);
     return hipGetLastError();
 }
 

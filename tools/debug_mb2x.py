@@ -40,7 +40,8 @@ idx = (np.arange(8) % 2).astype(np.uint32)
 got = ctx.pbs_batch(cts, idx, luts)
 want = S.pbs_batch(cts, idx, luts, mode=5)
 print("full PBS x8 equal:", np.array_equal(got, want), [K.decrypt_block(g) for g in got], flush=True)
-for arith in (3, 0):
+import os
+for arith in ((3,) if os.environ.get('FHS_MB2X_VARIANT') else (3, 0)):
     ctx.set_arithmetic(arith)
     for B in (3968, 1024):
         c = rng.integers(0, 2**64, (B, 2049), dtype=np.uint64)
