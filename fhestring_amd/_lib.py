@@ -222,6 +222,10 @@ def _declare(L):
     L.fhs_client_ksk.restype = C.POINTER(C.c_uint64)
     L.fhs_client_bsk_mb2.argtypes = [vp]
     L.fhs_client_bsk_mb2.restype = C.POINTER(C.c_uint64)
+    L.fhs_client_save_multibit_key.argtypes = [vp, C.c_char_p]
+    L.fhs_client_save_multibit_key.restype = i
+    L.fhs_load_multibit_key_file.argtypes = [vp, C.c_char_p]
+    L.fhs_load_multibit_key_file.restype = i
     L.fhs_debug_blind_rotate_batch.argtypes = [vp, vp, vp, vp, sz, vp, sz]
     L.fhs_debug_blind_rotate_batch.restype = i
     L.fhs_load_multibit_key.argtypes = [vp, vp]

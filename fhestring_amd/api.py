@@ -168,6 +168,11 @@ class MyClientKey:
         if self._L.fhs_client_save(self._h, str(path).encode(), int(server_key_only)) != 0:
             raise FhsError("cannot write key file %s" % path)
 
+    def save_multibit_key(self, path):
+        """fhs_client_save_multibit_key: kind 3 file with the pair key of the two-key-bits-per-product arithmetics."""
+        if self._L.fhs_client_save_multibit_key(self._h, str(path).encode()) != 0:
+            raise FhsError("cannot write pair key file %s" % path)
+
     @classmethod
     def load(cls, path):
         h = C.c_void_p()
@@ -385,10 +390,12 @@ class MyServerKey:
         return FheString([self.upload_char(z) for _ in range(n)])
 
     @classmethod
-    def from_key_file(cls, path, device_id=0, arith=0):
+    def from_key_file(cls, path, device_id=0, arith=0, multibit_key_path=None):
         ctx = Context(device_id)
         ctx.set_arithmetic(arith)
         ctx._check(ctx._L.fhs_load_server_key_file(ctx._h, str(path).encode()))
+        if multibit_key_path is not None:                      # kind 3 file, needed by arithmetics 2 and 3
+            ctx._check(ctx._L.fhs_load_multibit_key_file(ctx._h, str(multibit_key_path).encode()))
         return cls(ctx)
 
     @classmethod

@@ -83,6 +83,16 @@ void fhs_fft_mono_table(double *mono /*[4096][2]*/) {
 
 int fhs_read_server_key_file(const char *path, std::vector<uint64_t> &bsk, std::vector<uint64_t> &ksk);
 
+int fhs_read_multibit_key_file(const char *path, std::vector<uint64_t> &mb);
+
+int fhs_load_multibit_key_file(fhs_ctx *ctx, const char *path) {
+    if (!ctx || !path) return FHS_ERR_ARG;
+    std::vector<uint64_t> mb;
+    if (fhs_read_multibit_key_file(path, mb) != FHS_OK)
+        return ctx->eng.ctx.fail(FHS_ERR_STATE, "cannot read pair key file (missing, truncated or wrong parameters)");
+    return fhs_load_multibit_key(ctx, mb.data());
+}
+
 int fhs_load_server_key_file(fhs_ctx *ctx, const char *path) {
     if (!ctx || !path) return FHS_ERR_ARG;
     std::vector<uint64_t> bsk, ksk;

@@ -310,7 +310,7 @@ KeyFileHeader make_header(uint64_t kind) {
 }
 bool header_ok(const KeyFileHeader &h) {
     const KeyFileHeader w = make_header(h.kind);
-    return std::memcmp(&h, &w, sizeof(h)) == 0 && (h.kind == 1 || h.kind == 2);
+    return std::memcmp(&h, &w, sizeof(h)) == 0 && (h.kind == 1 || h.kind == 2 || h.kind == 3);
 }
 bool write_all(FILE *f, const void *p, size_t n) { return std::fwrite(p, 1, n, f) == n; }
 bool read_all(FILE *f, void *p, size_t n) { return std::fread(p, 1, n, f) == n; }
@@ -328,6 +328,30 @@ int fhs_client_save(const fhs_client *ck, const char *path, int server_key_only)
     }
     ok = ok && write_all(f, ck->bsk.data(), ck->bsk.size() * 8) && write_all(f, ck->ksk.data(), ck->ksk.size() * 8);
     ok = (std::fclose(f) == 0) && ok;
+    return ok ? FHS_OK : FHS_ERR_STATE;
+}
+
+// kind 3: the pair key of the two-key-bits-per-product arithmetics alone (it accompanies a kind 1 / kind 2 file)
+int fhs_client_save_multibit_key(fhs_client *ck, const char *path) {
+    if (!ck || !path) return FHS_ERR_ARG;
+    const uint64_t *mb = fhs_client_bsk_mb2(ck);
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return FHS_ERR_STATE;
+    const KeyFileHeader h = make_header(3);
+    bool ok = write_all(f, &h, sizeof(h)) && write_all(f, mb, FHS_BSK_MB2_WORDS * 8);
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? FHS_OK : FHS_ERR_STATE;
+}
+int fhs_read_multibit_key_file(const char *path, std::vector<uint64_t> &mb) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return FHS_ERR_STATE;
+    KeyFileHeader h;
+    bool ok = read_all(f, &h, sizeof(h)) && header_ok(h) && h.kind == 3;
+    if (ok) {
+        mb.resize(FHS_BSK_MB2_WORDS);
+        ok = read_all(f, mb.data(), mb.size() * 8) && std::fgetc(f) == EOF;
+    }
+    std::fclose(f);
     return ok ? FHS_OK : FHS_ERR_STATE;
 }
 
@@ -360,7 +384,7 @@ int fhs_read_server_key_file(const char *path, std::vector<uint64_t> &bsk, std::
     FILE *f = std::fopen(path, "rb");
     if (!f) return FHS_ERR_STATE;
     KeyFileHeader h;
-    bool ok = read_all(f, &h, sizeof(h)) && header_ok(h);
+    bool ok = read_all(f, &h, sizeof(h)) && header_ok(h) && h.kind != 3;
     if (ok && h.kind == 1) ok = std::fseek(f, 8 + (LWE_N + POLY_N) * 8, SEEK_CUR) == 0;
     if (ok) {
         bsk.resize((size_t)LWE_N * 4 * POLY_N); ksk.resize((size_t)BIG_N * KS_LEVEL * SMALL_CT);

@@ -7,7 +7,7 @@
 // at psi^(2 bitrev11(idx) + 1), so X^e becomes psi^((2 k' + 1) e) there, an exact field element:
 //     (per-lane base: one table gather per monomial) x (a wave-uniform 32nd root of unity per register pair: scalar
 //     loads), the odd register of a pair differs by (-1)^e.
-// Everything is exact, so the result equals the integer computation mod 2^64 (oracle mode 5 does it with a different
+// Everything is exact, so the result equals the integer computation mod 2^64 (mode 5 of the CPU oracle does it with a different
 // algorithm: coefficient-domain combination of the keys + Goldilocks NTT) as long as the CRT range p0 p1 / 2 > 2^93
 // covers the integer result: |digit| <= 2^22, 4096 terms, |combined key| <= 6 x 2^56 -- which is why the pair key is
 // rounded to the 57-bit torus grid here (2^7 instead of the classic key's 2^6; the rounding adds 2^-59 to a key noise of

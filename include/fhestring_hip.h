@@ -361,6 +361,10 @@ int fhs_client_secret_keys(const fhs_client *ck, uint64_t *lwe_sk /*[742]*/, uin
 int fhs_client_save(const fhs_client *ck, const char *path, int server_key_only);
 int fhs_client_load(const char *path, fhs_client **out);             /* kind 1 files only */
 int fhs_load_server_key_file(fhs_ctx *ctx, const char *path);        /* kind 1 or 2 */
+/* kind 3 = the pair key of FHS_ARITH_F64_FFT_MB2 / FHS_ARITH_EXACT_NTT_MB2 alone (generated on first use): it travels
+ * beside a kind 1 / 2 file and is loaded after it, converted for the arithmetic selected at that moment */
+int fhs_client_save_multibit_key(fhs_client *ck, const char *path);
+int fhs_load_multibit_key_file(fhs_ctx *ctx, const char *path);
 
 #ifdef __cplusplus
 }

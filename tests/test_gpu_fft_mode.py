@@ -283,6 +283,24 @@ def test_mb2_blind_rotation_on_chosen_masks(oracle_keys, oracle_sk, arith, mode)
     ctx.close()
 
 
+def test_server_and_pair_key_files(tmp_path):
+    """A server built from key files alone: kind 2 (server key) + kind 3 (pair key), in the two-bit FFT arithmetic."""
+    from fhestring_amd.api import MyClientKey, MyServerKey
+    import fhestring_amd
+    ck = MyClientKey(0xF5E57121)
+    pub, pair = tmp_path / "server.key", tmp_path / "pair.key"
+    ck.save(pub, server_key_only=True)
+    ck.save_multibit_key(pair)
+    sk = MyServerKey.from_key_file(pub, arith=fhestring_amd.Context.ARITH_F64_FFT_MB2, multibit_key_path=pair)
+    sk.set_mode(1)
+    s = ck.encrypt("key files", 1, None, sk)
+    assert ck.decrypt(sk.to_upper(s)) == "KEY FILES" and ck.decrypt_char(sk.find_clear(s, "file")) == 4
+    with pytest.raises(fhestring_amd.FhsError):
+        sk.ctx._check(sk.ctx._L.fhs_load_multibit_key_file(sk.ctx._h, str(pub).encode()))   # not a pair-key file
+    sk.close()
+    ck.close()
+
+
 def test_fft_needs_key_built_for_it(oracle_keys):
     import fhestring_amd
     ctx = fhestring_amd.Context(0)
