@@ -544,6 +544,17 @@ def main():
         dt3, outs3, st3, kt3 = timed(n3)
         wl.check(outs3)
         multi_bit = {"pbs_local": float(st3["pbs_executed"]), "dt": dt3, "steps": n3, "kt": kt3}
+        if single:                                       # one op alone in this arithmetic (every level on the one kernel)
+            one = Workload(args, ck, [sks[0]], [None], 0, 1, strings=1)
+            keep = one.step(0); sks[0].flush(); sync()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                keep = one.step(0)
+                sks[0].flush()
+            sync()
+            multi_bit["single_op_latency_ms"] = (time.perf_counter() - t1) / 3 * 1e3
+            one.check(keep)
+            del keep
         set_arith("exact_mb2")
         for _ in range(P):
             step()
@@ -701,6 +712,7 @@ def main():
                 "value": multi_bit["pbs_total"] / multi_bit["dt"], "unit": "PBS/s", "steps": multi_bit["steps"],
                 "ms_per_step": multi_bit["dt"] / multi_bit["steps"] * 1e3,
                 "ms_per_op": multi_bit["dt"] / multi_bit["steps"] / wl.n_strings * 1e3,
+                "single_op_latency_ms": multi_bit.get("single_op_latency_ms"),
                 "roofline": roofline_for("blind_rotate_mb2_kernel", k3[0]["pbs"] / max(1, k3[0]["n"]), k3[0]["ms"],
                                          k3[0]["n"], counters, traffic.get("blind_rotate_mb2_kernel_hbm_bytes_per_launch"))}
             mx = multi_bit["exact"]

@@ -197,15 +197,16 @@ def main(argv=None):
     ap.add_argument("--from", dest="frm", required=True)
     ap.add_argument("--to", required=True)
     ap.add_argument("--mode", choices=["fused", "as_written"], default="fused")
-    ap.add_argument("--arith", choices=["exact", "fft"], default="exact",
-                    help="arithmetic of blind rotation: exact two-prime NTT or f64 FFT (fhs_set_arithmetic)")
+    ap.add_argument("--arith", choices=["exact", "fft", "fft_mb2", "exact_mb2"], default="exact",
+                    help="arithmetic of blind rotation (fhs_set_arithmetic): exact two-prime NTT, f64 FFT, or either with "
+                         "two key bits per external product (needs the pair key, generated by the client key)")
     ap.add_argument("--methods", default="", help="comma-separated subset (default: all non-split methods)")
     ap.add_argument("--seed", type=int, default=None,
                     help="reproducible (insecure) keys for tests; default: OS entropy, like the reference")
     a = ap.parse_args(argv)
     assert a.n <= MAX_REPETITIONS, "n must be <= MAX_REPETITIONS"  # src/main.rs:37-40
     ck = MyClientKey.from_params(seed=a.seed)                     # src/main.rs:43
-    sk = ck.get_server_key(0, arith=1 if a.arith == "fft" else 0)
+    sk = ck.get_server_key(0, arith={"exact": 0, "fft": 1, "fft_mb2": 2, "exact_mb2": 3}[a.arith])
     sk.set_mode(1 if a.mode == "fused" else 0)
     methods = [m for m in a.methods.split(",") if m] or METHODS
     failed = 0

@@ -133,6 +133,9 @@ void Context::shutdown() {
 int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
     if (!bsk || !ksk) return fail(-1, "null key pointer");
     HIP_TRY(hipSetDevice(device), "hipSetDevice");
+    // a pair key belongs to the server key it was generated with: a new server key invalidates it
+    if (d_bsk_mb) { (void)hipFree(d_bsk_mb); d_bsk_mb = nullptr; }
+    if (d_bsk_ntt_mb) { (void)hipFree(d_bsk_ntt_mb); d_bsk_ntt_mb = nullptr; }
     const size_t ksk_bytes = (size_t)BIG_N * KS_LEVEL * SMALL_CT * sizeof(uint64_t);
     const size_t bsk_ntt_doubles = (size_t)LWE_N * 4 * 2 * POLY_N;
     if (!d_bsk_ntt) HIP_TRY(hipMalloc(&d_bsk_ntt, bsk_ntt_doubles * sizeof(double)), "hipMalloc bsk");

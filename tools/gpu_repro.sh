@@ -1,8 +1,2 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/repro
-timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/repro/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/repro/smoke.log
-timeout -k 10 400 python bench.py > gpurun_out/repro/bench_default.json 2> gpurun_out/repro/bench_default.err; echo "bench rc=$?"
-python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/repro/bench_default.json").read().strip().split("\n")[-1])
-print("value %.0f"%d["value"], "mb %.0f"%d["multi_bit"]["value"], "mb exact %.0f"%d["multi_bit"]["exact"]["value"], d["multi_bit"]["exact"]["roofline"]["frac"], "other %.0f"%d["other_arithmetic"]["value"])
-PY
+timeout -k 10 600 python -m pytest tests/test_gpu_fft_mode.py tests/test_gpu_bench_contract.py -x -q -k "key_files or two_key_bits or json_line" > gpurun_out/repro/t.log 2>&1; echo "rc=$?"; tail -4 gpurun_out/repro/t.log
