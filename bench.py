@@ -665,7 +665,8 @@ def main():
                        "scheduling": ("level-skewed batching: one context, fhs_submit + fhs_pump per step, the narrow "
                                       "levels of step k ride in the wide launch of step k+1" if SKEW else
                                       "%d independent context(s), step k on context k mod %d" % (P, P)),
-                       "parallelism": wl.parallelism()},
+                       "parallelism": wl.parallelism(),
+                       "transport": dists[0].transport if dists and dists[0] is not None else "single GPU"},
             "ms_per_op": dt / args.steps / wl.n_strings * 1e3,
             "median_ms_per_step": statistics.median(rep_ms) if rep_ms else None,
             "repeat_ms_per_step": rep_ms,

@@ -54,6 +54,7 @@ class Dist:
     def __init__(self, sk, rank, world):
         self.sk, self.rank, self.world = sk, rank, world
         self._cb = None
+        self.transport = "none"
 
     # ---- set-up ---------------------------------------------------------------------------------------
     @classmethod
@@ -67,16 +68,38 @@ class Dist:
         if world == 1 and dist is None:
             return self
         if dist.get_backend() == "nccl":
-            box = [unique_id() if rank == 0 else None]
+            # the library's own communicator (ncclCommInitRank on this context's device).  The id travels through
+            # torch.distributed; whether EVERY rank came up is agreed on the same way, and if one did not, all of them
+            # fall back to a host transport carried by torch.distributed (slower: the gathered blocks take a detour
+            # through host memory; `transport` says which one runs)
+            ok = 1
+            try:
+                box = [unique_id() if rank == 0 else None]
+            except RuntimeError:
+                box, ok = [None], 0
             dist.broadcast_object_list(box, src=0)
-            sk.ctx._check(sk.ctx._L.fhs_dist_init(sk.ctx._h, rank, world, box[0]))
+            if box[0] is None:
+                ok = 0
+            elif ok:
+                ok = int(sk.ctx._L.fhs_dist_init(sk.ctx._h, rank, world, box[0]) == 0)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                self.transport = "rccl"
+            else:
+                if ok:
+                    self.shutdown()
+                self.init_host_transport(lambda send: _torch_device_all_gather(dist, torch, send, world))
+                self.transport = "torch.distributed (fallback: the library's RCCL communicator did not come up)"
         else:
             self.init_host_transport(lambda send: _gloo_all_gather(dist, torch, send, world))
+            self.transport = "host transport over torch.distributed/%s" % dist.get_backend()
         return self
 
     def init_single(self):
         """world = 1 with a real RCCL communicator (exercises the stream-ordered path on one GPU)."""
         self.sk.ctx._check(self.sk.ctx._L.fhs_dist_init(self.sk.ctx._h, 0, 1, unique_id()))
+        self.transport = "rccl"
         return self
 
     def init_host_transport(self, all_gather_bytes):
@@ -94,6 +117,8 @@ class Dist:
                 return 1
 
         self._cb = CB(cb)                       # keep the trampoline alive as long as the context uses it
+        if self.transport == "none":
+            self.transport = "host transport (caller's all-gather)"
         self.sk.ctx._check(self.sk.ctx._L.fhs_dist_init_host_transport(self.sk.ctx._h, self.rank, self.world,
                                                                        self._cb, None))
         return self
@@ -201,6 +226,13 @@ class Dist:
         return [sk.flags_or([parts[r][i] for r in range(self.world)]) for i in range(len(local))]
 
     _force = False
+
+
+def _torch_device_all_gather(dist, torch, send, world):
+    t = torch.frombuffer(bytearray(send), dtype=torch.uint8).cuda()
+    out = torch.empty(world * t.numel(), dtype=torch.uint8, device="cuda")
+    dist.all_gather_into_tensor(out, t)
+    return out.cpu().numpy().tobytes()
 
 
 def _gloo_all_gather(dist, torch, send, world):
