@@ -1,4 +1,5 @@
-"""GPU exact two-bits-per-product blind rotation vs oracle mode 5, and its timing vs the classic exact kernel (GPU box)."""
+"""Two-key-bits-per-product blind rotation on the GPU against its oracle mode on chosen masks and a few full bootstraps,
+and its kernel time beside the classic kernel of the same arithmetic:  python tools/check_mb2.py [fft|exact]  (GPU box)."""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -8,8 +9,10 @@ from oracle import core, radix
 
 K = core.Keys(0xF5E57121)
 S = core.ServerKey(K).set_mb2(K.bsk_mb2)
+EXACT = "fft" not in sys.argv[1:]
+ARITH, MODE, CLASSIC = (3, 5, 0) if EXACT else (2, 4, 1)
 ctx = fhestring_amd.Context(0)
-ctx.set_arithmetic(3)
+ctx.set_arithmetic(ARITH)
 t = time.time(); ctx.load_server_key(K.bsk, K.ksk); ctx.load_multibit_key(K.bsk_mb2); print("key load %.2fs" % (time.time() - t), flush=True)
 luts = np.stack([radix.lut_poly(n) for n in ("msg", "carry")])
 rng = np.random.default_rng(1)
@@ -26,7 +29,7 @@ idx = (np.arange(len(ms)) % 2).astype(np.uint32)
 got = ctx.blind_rotate_batch(ms.astype(np.uint64) << np.uint64(52), idx, luts)
 bad = 0
 for k in range(len(ms)):
-    acc = S.blind_rotate(ms[k], luts[idx[k]], mode=5)
+    acc = S.blind_rotate(ms[k], luts[idx[k]], mode=MODE)
     want = np.zeros(2049, np.uint64)
     want[0] = acc[0]; want[1:2048] = np.uint64(0) - acc[2047:0:-1]; want[2048] = acc[2048]
     ok = np.array_equal(got[k], want)
@@ -38,10 +41,9 @@ print("chosen masks: %d of %d equal" % (len(ms) - bad, len(ms)), flush=True)
 cts = np.stack([K.encrypt_block(int(v)) for v in rng.integers(0, 32, 8)])
 idx = (np.arange(8) % 2).astype(np.uint32)
 got = ctx.pbs_batch(cts, idx, luts)
-want = S.pbs_batch(cts, idx, luts, mode=5)
+want = S.pbs_batch(cts, idx, luts, mode=MODE)
 print("full PBS x8 equal:", np.array_equal(got, want), [K.decrypt_block(g) for g in got], flush=True)
-import os
-for arith in ((3,) if os.environ.get('FHS_MB2X_VARIANT') else (3, 0)):
+for arith in (ARITH, CLASSIC):
     ctx.set_arithmetic(arith)
     for B in (3968, 1024):
         c = rng.integers(0, 2**64, (B, 2049), dtype=np.uint64)
