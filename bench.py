@@ -68,6 +68,8 @@ def parse():
                          "scratch, block pool, communicator), step k on pipeline k mod P (default 1 for the other ops)")
     ap.add_argument("--repeats", type=int, default=5, help="extra repeats for the median (0 = skip)")
     ap.add_argument("--skip-secondary", action="store_true", help="do not time the other arithmetic")
+    ap.add_argument("--no-balance", action="store_true",
+                    help="level-skewed batching without round alignment of the launch groups (fhs_set_tick_balance off)")
     ap.add_argument("--skip-single-op", action="store_true", help="skip single-op latency / end-to-end / as-written")
     ap.add_argument("--skip-extras", action="store_true", help="skip the configs 3-5 section of the default run")
     a = ap.parse_args()
@@ -388,6 +390,9 @@ def main():
         x.ctx.set_arithmetic(ARITH[args.arith])
         x.set_mode(1 if args.mode == "fused" else 0)
         dists.append(Dist.from_torch(x, dist, torch, rank, world) if world > 1 else None)
+    if SKEW and not args.no_balance:
+        for x in sks:
+            x.set_tick_balance()                         # launch groups in whole rounds of the persistent kernel
     wl = Workload(args, ck, sks, dists, rank, world)
     if wl.op == "replace" and world > 1:
         for D in dists:
@@ -412,7 +417,8 @@ def main():
             sk = sks[0]
             local = [sk.contains_clear(sh, wl.pattern) if len(sh) >= wl.m else sk.trivial(0)
                      for sh, _, _ in wl.inputs[0]["shards"]]
-            if len(inflight) >= 4:           # step j-4 finished its 4th level in tick j-1
+            if len(inflight) >= (4 if args.no_balance else 5):   # step j-4 finished its 4th level in tick j-1 (one tick
+                # later when round alignment moved part of its first level)
                 exchange_oldest()
             sk.submit()
             sk.pump(1)
@@ -449,6 +455,8 @@ def main():
     def set_arith(a):
         for x in sks:
             x.ctx.set_arithmetic(ARITH[a])
+            if SKEW and not args.no_balance:
+                x.set_tick_balance()                     # resident slots of the kernel of THIS arithmetic
 
     def sync():
         if SKEW:
@@ -662,8 +670,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s, %s DAG, %s arithmetic" % (wl.describe(), args.mode, ARITH_NAME[args.arith]),
                        "pipelines": args.pipelines,
-                       "scheduling": ("level-skewed batching: one context, fhs_submit + fhs_pump per step, the narrow "
-                                      "levels of step k ride in the wide launch of step k+1" if SKEW else
+                       "scheduling": (("level-skewed batching: one context, fhs_submit + fhs_pump per step, the narrow "
+                                       "levels of step k ride in the wide launch of step k+1" +
+                                       ("" if args.no_balance else "; launch groups aligned to whole rounds of the "
+                                        "persistent kernel (fhs_set_tick_balance: the excess of a step's first level, "
+                                        "less than one round, runs with the next step)")) if SKEW else
                                       "%d independent context(s), step k on context k mod %d" % (P, P)),
                        "parallelism": wl.parallelism(),
                        "transport": dists[0].transport if dists and dists[0] is not None else "single GPU"},

@@ -196,6 +196,10 @@ def _declare(L):
     L.fhs_debug_capture_pbs_inputs.restype = i
     L.fhs_debug_capture_read.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.fhs_debug_capture_read.restype = i
+    L.fhs_set_tick_balance.argtypes = [vp, sz]
+    L.fhs_set_tick_balance.restype = i
+    L.fhs_resident_slots.argtypes = [vp]
+    L.fhs_resident_slots.restype = i
     L.fhs_set_auto_flush.argtypes = [vp, sz]
     L.fhs_set_auto_flush.restype = i
     L.fhs_submit.argtypes = [vp]

@@ -454,6 +454,14 @@ class MyServerKey:
         """fhs_pump: enqueue the next n ticks (one launch group each over every job's level scheduled for it)."""
         self.ctx._check(self.ctx._L.fhs_pump(self.ctx._h, int(n_ticks)))
 
+    def set_tick_balance(self, slots=None):
+        """fhs_set_tick_balance: round-align the launch groups of fhs_submit scheduling (None = the selected kernel's
+        resident slots, 0 = off)."""
+        if slots is None:
+            slots = self.ctx._L.fhs_resident_slots(self.ctx._h)
+        self.ctx._check(self.ctx._L.fhs_set_tick_balance(self.ctx._h, int(slots)))
+        return int(slots)
+
     def set_auto_flush(self, n_depth1):
         """fhs_set_auto_flush: peel the ready level once n_depth1 bootstraps of it are recorded (0 = off)."""
         self.ctx._check(self.ctx._L.fhs_set_auto_flush(self.ctx._h, int(n_depth1)))

@@ -132,6 +132,19 @@ int fhs_set_auto_flush(fhs_ctx *c, size_t n_pending) {
     c->eng.auto_flush_pending = n_pending;
     return FHS_OK;
 }
+int fhs_set_tick_balance(fhs_ctx *c, size_t slots) {
+    if (!c) return FHS_ERR_ARG;
+    c->eng.balance_slots = slots;
+    return FHS_OK;
+}
+int fhs_resident_slots(const fhs_ctx *c) {
+    if (!c) return FHS_ERR_ARG;
+    // ciphertexts the selected blind-rotation kernel works on at a time: 4 workgroups of 2 wavefronts per CU for the
+    // f64-FFT kernels (persistent), 2 workgroups of 4 wavefronts per CU for the exact ones
+    const int a = c->eng.ctx.arith;
+    return (a == 1 || a == 2) ? c->eng.ctx.wg_slots : c->eng.ctx.wg_slots / 2;
+}
+
 int fhs_submit(fhs_ctx *c) {
     if (!c) return FHS_ERR_ARG;
     return c->eng.submit();

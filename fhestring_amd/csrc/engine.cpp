@@ -379,7 +379,18 @@ int Engine::plan_job(bool run_now, bool first_level_only) {
             continue;
         }
         tick = std::max(tick + 1, need + 1);
-        last_sched_tick_ = std::max(last_sched_tick_, tick);  // before the releases below: their frees wait for this tick
+        // round alignment: with `cur` rows already scheduled for this tick, keep only as many of this level's rows as
+        // fill whole rounds of the persistent kernel; at most one round's worth moves to the next tick
+        size_t keep = lv.size();
+        if (balance_slots && lv.size() >= balance_slots) {
+            size_t cur = 0;
+            auto it = sched_.find(tick);
+            if (it != sched_.end())
+                for (const TickLevel &l : it->second) cur += l.descs.size();
+            const size_t rem = (cur + lv.size()) % balance_slots;
+            if (rem && rem < lv.size()) keep = lv.size() - rem;
+        }
+        last_sched_tick_ = std::max(last_sched_tick_, keep < lv.size() ? tick + 1 : tick);  // before the releases below
         for (size_t k = 0; k < lv.size(); k++) {
             BlockNode &n = nodes_[lv[k]];
             const Bid src = n.src;
@@ -387,8 +398,19 @@ int Engine::plan_job(bool run_now, bool first_level_only) {
             n.dev = tl.out[k];
             n.src = 0;
             n.level = 0;
-            n.ready_tick = tick;
+            n.ready_tick = k < keep ? tick : tick + 1;
             release(src);
+        }
+        if (keep < lv.size()) {                               // split: rows [keep, n) form their own level one tick later
+            TickLevel late;
+            const uint32_t t0 = tl.descs[keep].first_term;
+            late.descs.assign(tl.descs.begin() + keep, tl.descs.end());
+            for (LinDesc &d : late.descs) d.first_term -= t0;
+            late.terms.assign(tl.terms.begin() + t0, tl.terms.end());
+            late.lut.assign(tl.lut.begin() + keep, tl.lut.end());
+            late.out.assign(tl.out.begin() + keep, tl.out.end());
+            tl.descs.resize(keep); tl.terms.resize(t0); tl.lut.resize(keep); tl.out.resize(keep);
+            sched_[tick + 1].push_back(std::move(late));
         }
         sched_[tick].push_back(std::move(tl));
     }

@@ -86,6 +86,10 @@ class Engine {
     // 256 k bootstraps in ~0.25 s of host time: without this the GPU idles through all of it, and with 8 GPUs that is as
     // long as the computation.  0 = off.  Not used while jobs are scheduled by hand (submit / pump) or inputs are captured.
     size_t auto_flush_pending = 8192;
+    // fhs_submit scheduling: a job level that would leave the launch group of its tick with a partly filled last round
+    // of the persistent blind-rotation kernel (width not a multiple of the resident workgroup slots) sends the excess
+    // rows to the next tick instead (their consumers move with them).  0 = off.
+    size_t balance_slots = 0;
     int submit() { manual_jobs_ = true; return plan_job(false); }
     int pump(size_t n_ticks);
     bool has_scheduled() const { return !sched_.empty(); }

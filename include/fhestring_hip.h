@@ -164,6 +164,14 @@ int fhs_submit(fhs_ctx *ctx);
  * flush on their own. */
 int fhs_set_auto_flush(fhs_ctx *ctx, size_t n_pending);
 int fhs_pump(fhs_ctx *ctx, size_t n_ticks);
+/* Round alignment of the launch groups (fhs_submit scheduling): the persistent blind-rotation kernel works on `slots`
+ * ciphertexts at a time (fhs_resident_slots: 1024 on an MI355X for the f64-FFT kernels), so a launch group of 3.5 x slots
+ * rows leaves half the chip idle during its last round.  With balancing on, a job level that would leave its tick's
+ * group with a partly filled last round keeps only the rows that fill whole rounds; the excess (less than one round)
+ * runs one tick later together with everything that consumes it.  Results are unchanged; a few results of a request are
+ * complete one tick later.  0 = off (default). */
+int fhs_set_tick_balance(fhs_ctx *ctx, size_t slots);
+int fhs_resident_slots(const fhs_ctx *ctx);
 int fhs_download(fhs_ctx *ctx, fhs_char_t a, uint64_t *blocks /*[4][2049]*/);
 /* device-to-device import/export of one char (multi-GPU gather of partial results) */
 int fhs_export_device(fhs_ctx *ctx, fhs_char_t a, uint64_t *d_blocks /*[4][2049] device*/);

@@ -43,6 +43,35 @@ def test_skewed_requests_decrypt_correctly(product):
     assert sk.stats()["max_input_sum_c2"] <= 64
 
 
+def test_round_aligned_launch_groups_decrypt_correctly(product):
+    """fhs_set_tick_balance: launch groups cut to whole rounds of the blind-rotation kernel (the excess of a first level
+    runs one tick later with its consumers).  Small slot count here so that every step is split."""
+    ck, sk = product
+    sk.set_tick_balance(96)
+    try:
+        rnd = random.Random(13)
+        texts = ["".join(chr(rnd.randint(0x20, 0x7E)) for _ in range(40)) for _ in range(6)]
+        pats = [t[5:9] if i % 2 == 0 else "\x7f\x7f\x7f" for i, t in enumerate(texts)]
+        sk.stats(reset=True)
+        results, seen, groups = [], 0, []
+        for t, p in zip(texts, pats):
+            es = ck.encrypt(t, 1, None, sk)
+            results.append((sk.contains_clear(es, p), sk.find_clear(es, p), sk.to_lower(es)))
+            sk.submit()
+            sk.pump(1)
+            w = sk.level_widths()
+            groups.append(sum(w[seen:]))
+            seen = len(w)
+        assert any(g % 96 == 0 for g in groups[1:]), groups
+        sk.flush()
+        for (c, f, u), t, p in zip(results, texts, pats):
+            assert ck.decrypt_char(c) == int(p in t)
+            assert ck.decrypt_char(f) == (t.find(p) if p in t else 255)
+            assert ck.decrypt(u) == t.lower()
+    finally:
+        sk.set_tick_balance(0)
+
+
 def test_job_consuming_an_unfinished_job(product):
     ck, sk = product
     a, b = ck.encrypt("hello world", 1, None, sk), ck.encrypt("HELLO WORLD", 1, None, sk)

@@ -150,3 +150,42 @@ def test_automatic_partial_flush_plans_the_same_bootstraps(sk):
     assert one_shot[0] > 10_000 and one_shot[0] <= peeled[0] <= 1.1 * one_shot[0]
     assert peeled[2] > one_shot[2]                     # more, narrower launches: it really did peel
     sk.set_auto_flush(8192)
+
+
+def test_round_aligned_launch_groups(sk):
+    """fhs_set_tick_balance: with 8 x 64-char contains per step (4 512 bootstraps, widths 3968 / 496 / 40 / 8) and 512
+    resident slots (exact kernels; 1024 for the f64-FFT ones), every launch group of the steady state is a whole number
+    of rounds: the excess of a step's first level runs one tick later together with everything that consumes it.
+    Nothing is lost or duplicated."""
+    sk.set_mode(1)
+    slots = sk.set_tick_balance()
+    assert slots == 512
+    try:
+        strings = [sk.dummy_string(65) for _ in range(8)]
+        sk.stats(reset=True)
+        keep, seen, groups = [], 0, []
+        for _ in range(9):
+            keep.append([sk.contains_clear(s, "a2S$") for s in strings])
+            sk.submit()
+            sk.pump(1)
+            w = sk.level_widths()
+            groups.append(sum(w[seen:]))
+            seen = len(w)
+        assert all(g % slots == 0 and g >= 3584 for g in groups), groups
+        sk.flush()
+        assert sk.stats()["pbs_executed"] == 9 * 4512
+        # without balancing the same schedule has ragged groups
+        sk.set_tick_balance(0)
+        sk.stats(reset=True)
+        seen, ragged = 0, []
+        for _ in range(5):
+            keep.append([sk.contains_clear(s, "a2S$") for s in strings])
+            sk.submit()
+            sk.pump(1)
+            w = sk.level_widths()
+            ragged.append(sum(w[seen:]))
+            seen = len(w)
+        assert ragged[-1] == 4512 and ragged[-1] % slots != 0
+        sk.flush()
+    finally:
+        sk.set_tick_balance(0)
