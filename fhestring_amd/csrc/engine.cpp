@@ -387,8 +387,11 @@ int Engine::plan_job(bool run_now, bool first_level_only) {
             auto it = sched_.find(tick);
             if (it != sched_.end())
                 for (const TickLevel &l : it->second) cur += l.descs.size();
-            const size_t rem = (cur + lv.size()) % balance_slots;
-            if (rem && rem < lv.size()) keep = lv.size() - rem;
+            const size_t total = cur + lv.size(), rem = total % balance_slots;
+            const size_t rounds = (total + balance_slots - 1) / balance_slots;
+            // only when the last round would be less than ~2/3 full overall: a group that already fills 95 % of its rounds
+            // is left alone (the split costs its consumers one tick)
+            if (rem && rem < lv.size() && total * 100 < rounds * balance_slots * 95) keep = lv.size() - rem;
         }
         last_sched_tick_ = std::max(last_sched_tick_, keep < lv.size() ? tick + 1 : tick);  // before the releases below
         for (size_t k = 0; k < lv.size(); k++) {
