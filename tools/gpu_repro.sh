@@ -1,9 +1,5 @@
-cd "$GRAFT_REPO_ROOT"; O=gpurun_out/repro/skewstats; mkdir -p $O; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 bench.py --steps 20 --warmup 3 --cpu-pbs 0 --skip-single-op --skip-secondary --skip-extras --repeats 0 > $O/line.json 2> $O/line.err; echo "rc=$?"
-find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
-head -4 $(find $O -name "*kernel_stats.csv") | cut -c1-150
-python3 - <<'PY'
-import json
-l=json.loads(open("gpurun_out/repro/skewstats/line.json").read().strip().splitlines()[-1]); r=l["roofline"]
-print(l["value"], l["ms_per_step"], r["avg_launch_ms"], r["avg_pbs_per_launch"], r["launches"], r["frac"])
-PY
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/repro
+timeout -k 10 200 python tools/time_mb2.py --arith=2 3968 > gpurun_out/repro/p_base.log 2>&1; echo "base"; grep "B=" gpurun_out/repro/p_base.log
+for v in noprio prio_0_1_0 prio_2_3_0; do
+FHS_LIB_PATH=$PWD/tools/ablate_build/libfhs_mb2_$v.so timeout -k 10 200 python tools/time_mb2.py --arith=2 3968 > gpurun_out/repro/p_$v.log 2>&1; echo "$v"; grep "B=" gpurun_out/repro/p_$v.log
+done
