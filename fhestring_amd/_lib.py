@@ -196,6 +196,8 @@ def _declare(L):
     L.fhs_debug_capture_pbs_inputs.restype = i
     L.fhs_debug_capture_read.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.fhs_debug_capture_read.restype = i
+    L.fhs_set_launch_chunk.argtypes = [vp, i, sz]
+    L.fhs_set_launch_chunk.restype = i
     L.fhs_set_tick_balance.argtypes = [vp, sz]
     L.fhs_set_tick_balance.restype = i
     L.fhs_resident_slots.argtypes = [vp]

@@ -58,6 +58,10 @@ class Context:
         load_server_key; mode 2 also needs load_multibit_key)."""
         self._check(self._L.fhs_set_arithmetic(self._h, int(arith)))
 
+    def set_launch_chunk(self, arith, n):
+        """fhs_set_launch_chunk: ciphertexts per blind-rotation launch of that arithmetic (0 = whole batch)."""
+        self._check(self._L.fhs_set_launch_chunk(self._h, int(arith), int(n)))
+
     def set_fft4_max_batch(self, n):
         """fhs_set_fft4_max_batch: batches <= n use the 4-wavefront FFT kernel (default 512)."""
         self._check(self._L.fhs_set_fft4_max_batch(self._h, int(n)))

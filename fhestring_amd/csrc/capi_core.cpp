@@ -58,6 +58,11 @@ int fhs_set_arithmetic(fhs_ctx *ctx, int arith) {
     return ctx->eng.ctx.set_arithmetic(arith);
 }
 int fhs_get_arithmetic(const fhs_ctx *ctx) { return ctx ? ctx->eng.ctx.arith : FHS_ERR_ARG; }
+int fhs_set_launch_chunk(fhs_ctx *ctx, int arith, size_t n_ciphertexts) {
+    if (!ctx || arith < 0 || arith > 3) return FHS_ERR_ARG;
+    ctx->eng.ctx.launch_chunk[arith] = n_ciphertexts;
+    return FHS_OK;
+}
 int fhs_set_fft4_max_batch(fhs_ctx *ctx, int max_batch) {
     if (!ctx || max_batch < 0) return FHS_ERR_ARG;
     if (int rc = ctx->eng.flush()) return rc;

@@ -93,6 +93,10 @@ int Context::init(int device_id) {
     HIP_TRY(prepare_device_for_kernels(), "hipFuncSetAttribute (dynamic LDS)");
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
     wg_slots = 4 * prop.multiProcessorCount;
+    // two-bit f64 kernel: one round of resident workgroups per launch (its 73 MB key only stays inside the L2 window
+    // while the workgroups walk it together; consecutive launches overlap at the seams): 202 k instead of 183 k PBS/s at
+    // 4096 rows, 214 k instead of 152 k at 14 336.  The classic f64 kernel (48 MB key) does not care below 4096 rows.
+    launch_chunk[2] = (size_t)wg_slots;
     HIP_TRY(hipMalloc(&d_work_counter, 64), "hipMalloc counter");
     return 0;
 }
@@ -276,45 +280,56 @@ int Context::load_multibit_key(const uint64_t *bsk_mb2) {
 
 int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const uint64_t *d_luts, uint64_t *d_out,
                           uint64_t *const *d_out_ptrs, size_t B, hipStream_t s) {
-    hipError_t e;
+    hipError_t e = hipSuccess;
     const bool four = arith == 1 && B <= (size_t)fft4_max_batch;
     if (arith == 2 && !d_bsk_mb) return fail(-3, "pair key not loaded (fhs_load_multibit_key)");
     if (arith == 3 && !d_bsk_ntt_mb) return fail(-3, "pair key not loaded in the exact arithmetic (fhs_load_multibit_key)");
     if (arith == 1 && !d_bsk_fft) return fail(-3, "Fourier-domain key not loaded");
     timer.begin(four ? 2 : 0, B, s);
-    if (arith == 3) {
-        BlindRotateNttMb2Params p{};
-        p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;
-        p.bsk_ntt_mb = d_bsk_ntt_mb; p.tw = tw; p.crt_c = crt_c; p.mono = d_ntt_mono;
-        p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
-        e = launch_blind_rotate_ntt_mb2(p, s);
-    } else if (arith == 2) {
-        BlindRotateMb2Params p{};
-        p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;
-        p.bsk_mb = d_bsk_mb;
-        p.lanetab = d_fft_tables;
-        p.mono = d_fft_tables + 12 * 64 + 2 * 1024;
-        p.r16 = p.mono + 2 * 4096;
-        p.work_counter = d_work_counter;
-        p.slots = wg_slots;
-        p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
-        e = launch_blind_rotate_mb2(p, s);
-    } else if (arith == 1) {
-        BlindRotateFftParams p{};
-        p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;
-        p.bsk_fft = d_bsk_fft;
-        p.lanetab = d_fft_tables;
-        p.weff = d_fft_tables + 12 * 64;
-        p.work_counter = d_work_counter;
-        p.slots = wg_slots;
-        p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
-        e = four ? launch_blind_rotate_fft4(p, s) : launch_blind_rotate_fft(p, s);
-    } else {
-        BlindRotateParams p{};
-        p.ks = d_ks; p.lut_idx = d_lut_idx; p.luts = d_luts;
-        p.bsk_ntt = d_bsk_ntt; p.tw = tw; p.crt_c = crt_c;
-        p.out = d_out; p.out_ptrs = d_out_ptrs; p.B = (int)B;
-        e = launch_blind_rotate(p, s);
+    // A launch is cut into chunks of launch_chunk[arith] ciphertexts (0 = whole batch): every chunk starts all workgroups on
+    // the first key element together again.  The kernels whose key does not fit the L2 window of a drifting launch need
+    // that (two-bit f64 kernel: 185 k PBS/s in launches of 3 072 - 4 096 rows, 144 k in one launch of 13 400).
+    const size_t chunk = launch_chunk[arith] ? launch_chunk[arith] : B;
+    for (size_t off = 0; off < B && e == hipSuccess; off += chunk) {
+        const size_t n = std::min(chunk, B - off);
+        const uint64_t *ks = d_ks + off * SMALL_CT;
+        const uint32_t *li = d_lut_idx + off;
+        uint64_t *out = d_out ? d_out + off * BIG_CT : nullptr;
+        uint64_t *const *outp = d_out_ptrs ? d_out_ptrs + off : nullptr;
+        if (arith == 3) {
+            BlindRotateNttMb2Params p{};
+            p.ks = ks; p.lut_idx = li; p.luts = d_luts;
+            p.bsk_ntt_mb = d_bsk_ntt_mb; p.tw = tw; p.crt_c = crt_c; p.mono = d_ntt_mono;
+            p.out = out; p.out_ptrs = outp; p.B = (int)n;
+            e = launch_blind_rotate_ntt_mb2(p, s);
+        } else if (arith == 2) {
+            BlindRotateMb2Params p{};
+            p.ks = ks; p.lut_idx = li; p.luts = d_luts;
+            p.bsk_mb = d_bsk_mb;
+            p.lanetab = d_fft_tables;
+            p.mono = d_fft_tables + 12 * 64 + 2 * 1024;
+            p.r16 = p.mono + 2 * 4096;
+            p.work_counter = d_work_counter;
+            p.slots = wg_slots;
+            p.out = out; p.out_ptrs = outp; p.B = (int)n;
+            e = launch_blind_rotate_mb2(p, s);
+        } else if (arith == 1) {
+            BlindRotateFftParams p{};
+            p.ks = ks; p.lut_idx = li; p.luts = d_luts;
+            p.bsk_fft = d_bsk_fft;
+            p.lanetab = d_fft_tables;
+            p.weff = d_fft_tables + 12 * 64;
+            p.work_counter = d_work_counter;
+            p.slots = wg_slots;
+            p.out = out; p.out_ptrs = outp; p.B = (int)n;
+            e = four ? launch_blind_rotate_fft4(p, s) : launch_blind_rotate_fft(p, s);
+        } else {
+            BlindRotateParams p{};
+            p.ks = ks; p.lut_idx = li; p.luts = d_luts;
+            p.bsk_ntt = d_bsk_ntt; p.tw = tw; p.crt_c = crt_c;
+            p.out = out; p.out_ptrs = outp; p.B = (int)n;
+            e = launch_blind_rotate(p, s);
+        }
     }
     timer.end(s);
     if (e != hipSuccess) return hip_fail(e, "blind_rotate launch");

@@ -67,7 +67,8 @@ class Context {
     double *d_bsk_ntt_mb = nullptr;   // arith 3 (FHS_ARITH_EXACT_NTT_MB2): [371][K1,K2,K3][4][2 primes][2048] residues
     const double *d_ntt_mono = nullptr;   // [2][4096] inside d_tables
     int load_multibit_key(const uint64_t *bsk_mb2);   // [371][K1,K2,K3][4][2048] u64 standard domain (fhs_client_bsk_mb2)
-    int fft4_max_batch = 512;         // batches up to this size use the 4-wavefront kernel (lower latency)
+    int fft4_max_batch = 512;
+    size_t launch_chunk[4] = {0, 0, 0, 0};   // per arithmetic: ciphertexts per blind-rotation launch (0 = whole batch)         // batches up to this size use the 4-wavefront kernel (lower latency)
     int set_arithmetic(int mode);
     // keyswitch of a dense batch into ks_buf (timed as kernel kind 1); ks_buf must hold B rows
     int keyswitch(const uint64_t *d_in, size_t B, hipStream_t s);

@@ -91,6 +91,10 @@ int fhs_get_arithmetic(const fhs_ctx *ctx);
  * (lower latency), larger ones on the 2-wavefront kernel (higher throughput).  Default 512; 0 = never, a huge value
  * = always.  Both kernels produce identical bits. */
 int fhs_set_fft4_max_batch(fhs_ctx *ctx, int max_batch);
+/* Tuning knob: a blind-rotation launch of arithmetic `arith` is cut into chunks of n_ciphertexts (0 = the whole batch in
+ * one launch).  Every chunk starts all workgroups on the first key element together again, which keeps the key stream
+ * inside the L2 for the kernels whose key does not fit it otherwise.  Results are identical. */
+int fhs_set_launch_chunk(fhs_ctx *ctx, int arith, size_t n_ciphertexts);
 /* Diagnostic: the host-derived twiddle tables of the F64_FFT mode (W[1024] re/im; U[16] re/im, 3 used). */
 void fhs_fft_tables(double *w_re, double *w_im, double *u_re, double *u_im);
 /* ... and the monomial evaluation table of the F64_FFT_MB2 mode: exp(i*pi*k/2048), k < 4096, (re, im) pairs. */

@@ -1,11 +1,11 @@
 #!/bin/bash
-# counters of blind_rotate_mb2_kernel on 3968-wide launches only (tools/time_mb2.py --profile): per-PBS figures
+# counters of blind_rotate_mb2_kernel on 4096-row batches = 4 launches of 1024 (one round each, the default launch chunk): per-PBS figures with tools/pmc_to_json.py --pbs=1024
 set -o pipefail
 O=gpurun_out/profile_mb2b
 mkdir -p $O
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-PB="python3 tools/time_mb2.py --profile 3968"
+PB="python3 tools/time_mb2.py --profile 4096"
 run() { name=$1; shift; timeout -k 10 240 "$@" > $O/$name.log 2> $O/$name.err; echo "$name rc=$?" | tee -a $O/status.txt; }
 run stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $PB
 run pmc1 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS -d $O/pmc1 -- $PB

@@ -11,6 +11,7 @@ ck = MyClientKey(0xF5E57121)
 sizes = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [3968]
 PROFILE = "--profile" in sys.argv          # under rocprofv3: only 3968-wide launches of the two-bit kernel
 ARITHS = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--arith=")]
+CHUNK = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--chunk=")]
 for arith in (ARITHS or ((2,) if PROFILE else (1, 2))):
     t = time.time()
     sk = ck.get_server_key(0, arith=arith)
@@ -23,6 +24,8 @@ for arith in (ARITHS or ((2,) if PROFILE else (1, 2))):
       sk.flush()
       print("   to_upper %r contains %d find %d" % (ck.decrypt(up), ck.decrypt_char(found), ck.decrypt_char(pos)), flush=True)
     ctx = sk.ctx
+    if CHUNK:
+        ctx.set_launch_chunk(arith, CHUNK[0])
     rng = np.random.default_rng(0)
     luts = rng.integers(0, 2**64, (2, 2048), dtype=np.uint64)
     for B in sizes:
