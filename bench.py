@@ -611,6 +611,16 @@ def main():
                 dists[0].level_parallel(False)
             extras[op] = {"ms_local": d * 1e3, "pbs_local": float(s2["pbs_executed"]), "levels": s2["levels"],
                           "workload": w.describe(), "parallelism": w.parallelism()}
+            if multi_bit is not None:                     # the same op once more in the two-bit f64 arithmetic
+                set_arith("mb2")
+                keep = w.step(0); sks[0].flush(); sync()
+                t0 = time.perf_counter()
+                keep = w.step(0)
+                sks[0].flush()
+                sync()
+                extras[op]["ms_two_bit"] = (time.perf_counter() - t0) * 1e3
+                w.check(keep)
+                set_arith(args.arith)
             del keep, w
 
     pbs_local = st["pbs_executed"]
@@ -746,6 +756,8 @@ def main():
                 line["configs"][names[op]] = {"ms_per_op": e["ms"], "pbs": e["pbs"], "levels": e["levels"],
                                               "pbs_per_s": e["pbs"] / (e["ms"] * 1e-3), "scaling": "strong",
                                               "workload": e["workload"], "parallelism": e["parallelism"]}
+                if "ms_two_bit" in e:
+                    line["configs"][names[op]]["ms_per_op_multi_bit"] = e["ms_two_bit"]
         if args.cpu_pbs != 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_pbs, single["level_widths"] if single else None)
         print(json.dumps(line))

@@ -60,6 +60,7 @@ def test_bench_json_line_contract():
     # BASELINE configs 3-5 at their fixed sizes in the same run
     for k in ("cfg3_find_encrypted_256", "cfg4_replace_1024", "cfg5_eq_ignore_case_4096", "cfg5_le_4096"):
         assert d["configs"][k]["ms_per_op"] > 0 and d["configs"][k]["pbs"] > 1000
+        assert 0 < d["configs"][k]["ms_per_op_multi_bit"] < d["configs"][k]["ms_per_op"]     # two-bit f64 arithmetic
 
 
 @pytest.mark.parametrize("op", ["find_enc", "eq_ignore_case"])
