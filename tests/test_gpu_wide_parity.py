@@ -162,6 +162,24 @@ def test_exact_mb2_pbs_sampled_rows_at_bench_width(exact_ctx, oracle_keys, wide_
         assert oracle_keys.decrypt_block(got[r]) == oracle_keys.decrypt_block(classic[k]), r
 
 
+@pytest.mark.parametrize("arith", [0, 1])
+def test_launch_chunking_changes_nothing(fft_ctx, exact_ctx, wide_inputs, arith):
+    """fhs_set_launch_chunk: a batch cut into launches of 1000 rows (not a multiple of anything) gives the same words as
+    one launch (the two-bit f64 kernel runs chunked by default and is compared with its oracle above)."""
+    ctx = fft_ctx if arith == 1 else exact_ctx
+    _, cts = wide_inputs
+    B = 2500
+    luts = _luts()
+    idx = (np.arange(B) % len(NAMES)).astype(np.uint32)
+    whole = ctx.pbs_batch(cts[:B], idx, luts)
+    ctx.set_launch_chunk(arith, 1000)
+    try:
+        cut = ctx.pbs_batch(cts[:B], idx, luts)
+    finally:
+        ctx.set_launch_chunk(arith, 0)
+    assert np.array_equal(whole, cut)
+
+
 def test_pbs_batch_device_sampled_rows(fft_ctx, exact_ctx, wide_inputs, oracle_sk):
     """fhs_pbs_batch_device: device-resident inputs/outputs (torch tensors), both arithmetics."""
     import torch
