@@ -289,6 +289,8 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
     // A launch is cut into chunks of launch_chunk[arith] ciphertexts (0 = whole batch): every chunk starts all workgroups on
     // the first key element together again.  The kernels whose key does not fit the L2 window of a drifting launch need
     // that (two-bit f64 kernel: 185 k PBS/s in launches of 3 072 - 4 096 rows, 144 k in one launch of 13 400).
+    // (the classic f64 kernel with its 48 MB key gains 2-3 % from 1024-row launches at 14 336 rows but loses 5-8 % at widths
+    // like 8194 = 8 rounds + 2 rows, where the remainder becomes a launch of its own: left unchunked)
     const size_t chunk = launch_chunk[arith] ? launch_chunk[arith] : B;
     for (size_t off = 0; off < B && e == hipSuccess; off += chunk) {
         const size_t n = std::min(chunk, B - off);
