@@ -106,6 +106,8 @@ int main() {
     }
     {   // level-skewed batching: jobs on ticks, dependent jobs, handles released while their levels are still scheduled
         CHECK(fhs_set_mode(c, 1) == FHS_OK);
+        CHECK(fhs_resident_slots(c) == 512 && fhs_set_tick_balance(c, 64) == FHS_OK);   // levels get split across ticks
+        CHECK(fhs_set_launch_chunk(c, 0, 100) == FHS_OK && fhs_set_launch_chunk(c, 7, 1) == FHS_ERR_ARG);
         std::vector<fhs_char_t> keep;
         for (int k = 0; k < 6; k++) {
             auto s = dummy(c, 30);
@@ -127,6 +129,7 @@ int main() {
         size_t nl = 0;
         CHECK(fhs_level_widths(c, nullptr, 0, &nl) == FHS_OK && nl > 20);
         for (fhs_char_t h : keep) CHECK(fhs_release(c, h) == FHS_OK);
+        CHECK(fhs_set_tick_balance(c, 0) == FHS_OK);
     }
     fhs_stats st;
     CHECK(fhs_get_stats(c, &st) == FHS_OK && st.pbs_executed > 1000 && st.max_input_sum_c2 <= FHS_NOISE_BUDGET_SUM_C2);
