@@ -598,13 +598,15 @@ def main():
             lp = op == "replace" and world > 1
             if lp:
                 dists[0].level_parallel(True)
-            keep = w.step(0); sks[0].flush(); sync()
-            sks[0].stats(reset=True)
-            t0 = time.perf_counter()
-            keep = w.step(0)
-            sks[0].flush()
-            sync()
-            d = time.perf_counter() - t0
+            def once():
+                sks[0].stats(reset=True)
+                t0 = time.perf_counter()
+                out = w.step(0)
+                sks[0].flush()
+                sync()
+                return time.perf_counter() - t0, out
+            keep = w.step(0); sks[0].flush(); sync()         # warm-up, then the better of two runs
+            d, keep = min((once() for _ in range(2)), key=lambda r: r[0])
             s2 = sks[0].stats()
             w.check(keep)
             if lp:
@@ -614,11 +616,8 @@ def main():
             if multi_bit is not None:                     # the same op once more in the two-bit f64 arithmetic
                 set_arith("mb2")
                 keep = w.step(0); sks[0].flush(); sync()
-                t0 = time.perf_counter()
-                keep = w.step(0)
-                sks[0].flush()
-                sync()
-                extras[op]["ms_two_bit"] = (time.perf_counter() - t0) * 1e3
+                d2, keep = min((once() for _ in range(2)), key=lambda r: r[0])
+                extras[op]["ms_two_bit"] = d2 * 1e3
                 w.check(keep)
                 set_arith(args.arith)
             del keep, w
