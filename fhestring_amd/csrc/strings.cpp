@@ -1262,6 +1262,9 @@ std::vector<Strings::Num> Strings::flag_prefix_counts(const std::vector<Ref> &z,
 // them.  Shifts are prefix counts (base-4 numbers), routed LSB first through log2(n) conditional
 // moves by 2^k -- collision-free for monotone compaction.  Same result as the reference's n-pass
 // bubble (utils.rs:28-46) in O(n log n) PBS and O(log n) wide levels instead of O(n^2) / O(n).
+// The not-yet-used part of every shift travels with its character as base-4 DIGITS (2 bootstraps per digit and stage,
+// like a data block) and the bit a stage needs is extracted from its digit where it is used (1 bootstrap): 177 instead
+// of 209 bootstraps per position for n = 1025 (routing the 11 bits separately cost 2 per remaining bit and stage).
 FStr Strings::f_compact(const FStr &s) {
     const size_t n = s.size();
     if (n <= 1) return s;
@@ -1271,44 +1274,48 @@ FStr Strings::f_compact(const FStr &s) {
     const FChar zero = t(0);
     std::vector<Ref> z(n);
     for (size_t i = 0; i < n; i++) z[i] = and_tree(block_eq_flags(s[i], zero));
-    // per-position shift = number of NULs before it
+    // per-position shift = number of NULs before it; NUL positions get shift 0 (they stay and contribute zeros)
     std::vector<Num> shifts = flag_prefix_counts(z, D);
-    std::vector<std::vector<Ref>> bits(n, std::vector<Ref>(K));
-    for (size_t i = 0; i < n; i++) {
-        const Num &sh = shifts[i];
-        for (int b = 0; b < K; b++) {
-            if (((size_t)1 << b) > i) { bits[i][b] = trivial_block(e_, 0); continue; }   // shift <= i
-            bits[i][b] = pbs(lin(e_, {{1, &sh[b / 2]}, {4, &z[i]}}), (b & 1) ? LUT_BIT1_UNLESS : LUT_BIT0_UNLESS);
+    std::vector<std::vector<Ref>> dg(n, std::vector<Ref>(D));
+    for (size_t i = 0; i < n; i++)
+        for (size_t q = 0; q < D; q++) {
+            if (((size_t)1 << (2 * q)) > i) { dg[i][q] = trivial_block(e_, 0); continue; }   // shift <= i < 4^q
+            dg[i][q] = pbs(lin(e_, {{1, &shifts[i][q]}, {4, &z[i]}}), LUT_SEL_F);               // digit unless NUL
         }
-    }
     FStr cur = s;
     for (int k = 0; k < K; k++) {
-        const size_t d = (size_t)1 << k;
-        FStr nxt(n);
-        std::vector<std::vector<Ref>> nb(n, std::vector<Ref>(K));
+        const size_t d = (size_t)1 << k, q = (size_t)k / 2;
+        const bool hi = k & 1;
+        // the stage's move flag: bit k of the shift, from its digit; statically 0 where the shift cannot reach 2^k
+        std::vector<Ref> mv(n);
         for (size_t p = 0; p < n; p++) {
-            const Ref &bs = bits[p][k];
-            // statically known bits (shift <= position) need no PBS
+            if (d > p || (e_->is_triv(dg[p][q].id()) && ((e_->triv_val(dg[p][q].id()) >> (hi ? 1 : 0)) & 1) == 0))
+                mv[p] = trivial_block(e_, 0);
+            else mv[p] = pbs(dg[p][q], hi ? LUT_BIT1_UNLESS : LUT_BIT0_UNLESS);
+        }
+        const size_t q0 = hi ? q + 1 : q;                    // digits still needed after this stage
+        FStr nxt(n);
+        std::vector<std::vector<Ref>> nd(n, std::vector<Ref>(D));
+        for (size_t p = 0; p < n; p++) {
+            const Ref &bs = mv[p];
             const bool stays = e_->is_triv(bs.id()) && e_->triv_val(bs.id()) == 0;
-            const bool has_src = p + d < n && !(e_->is_triv(bits[p + d][k].id()) && e_->triv_val(bits[p + d][k].id()) == 0);
-            for (int blk = 0; blk < 4; blk++) {
-                Ref st = stays ? cur[p].b[blk] : pbs(lin(e_, {{4, &bs}, {1, &cur[p].b[blk]}}), LUT_SEL_F);
+            const bool has_src = p + d < n && !(e_->is_triv(mv[p + d].id()) && e_->triv_val(mv[p + d].id()) == 0);
+            auto route = [&](const Ref &here, const Ref *there) {
+                Ref st = stays ? here : pbs(lin(e_, {{4, &bs}, {1, &here}}), LUT_SEL_F);
                 if (stays && has_src && e_->sum_c2(st.id()) > 1) st = pbs(st, LUT_MSG);   // keep outputs at <= 2 terms
-                if (has_src) {
-                    Ref in = pbs(lin(e_, {{4, &bits[p + d][k]}, {1, &cur[p + d].b[blk]}}), LUT_SEL_T);
-                    nxt[p].b[blk] = lin(e_, {{1, &in}, {1, &st}});
-                } else nxt[p].b[blk] = st;
-            }
-            for (int jb = k + 1; jb < K; jb++) {
-                Ref st = stays ? bits[p][jb] : pbs(lin(e_, {{2, &bs}, {1, &bits[p][jb]}}), LUT_IS1);   // stays and bit set
-                if (has_src) {
-                    Ref in = pbs(lin(e_, {{2, &bits[p + d][k]}, {1, &bits[p + d][jb]}}), LUT_IS3);
-                    nb[p][jb] = lin(e_, {{1, &in}, {1, &st}});
-                } else nb[p][jb] = st;
+                if (!has_src) return st;
+                Ref in = pbs(lin(e_, {{4, &mv[p + d]}, {1, there}}), LUT_SEL_T);
+                return lin(e_, {{1, &in}, {1, &st}});
+            };
+            for (int blk = 0; blk < 4; blk++)
+                nxt[p].b[blk] = route(cur[p].b[blk], has_src ? &cur[p + d].b[blk] : nullptr);
+            for (size_t jq = 0; jq < D; jq++) {
+                if (jq < q0) { nd[p][jq] = trivial_block(e_, 0); continue; }
+                nd[p][jq] = route(dg[p][jq], has_src ? &dg[p + d][jq] : nullptr);
             }
         }
         cur.swap(nxt);
-        bits.swap(nb);
+        dg.swap(nd);
     }
     return cur;
 }
