@@ -1262,9 +1262,13 @@ std::vector<Strings::Num> Strings::flag_prefix_counts(const std::vector<Ref> &z,
 // them.  Shifts are prefix counts (base-4 numbers), routed LSB first through log2(n) conditional
 // moves by 2^k -- collision-free for monotone compaction.  Same result as the reference's n-pass
 // bubble (utils.rs:28-46) in O(n log n) PBS and O(log n) wide levels instead of O(n^2) / O(n).
-// The not-yet-used part of every shift travels with its character as base-4 DIGITS (2 bootstraps per digit and stage,
-// like a data block) and the bit a stage needs is extracted from its digit where it is used (1 bootstrap): 177 instead
-// of 209 bootstraps per position for n = 1025 (routing the 11 bits separately cost 2 per remaining bit and stage).
+// The not-yet-used part of every shift travels with its character as base-4 DIGITS, and the bit a stage needs is
+// extracted from its digit where it is used (1 bootstrap).  A stage costs ONE bootstrap per block or digit: the part
+// that moves is m = (bit ? x : 0), and what stays is x - m -- linear, exact (m is x or 0) -- so
+//     next[p] = cur[p] - m[p] + m[p + 2^k].
+// The blocks are sums of 1 + 2k bootstrap outputs by then (sum c^2 <= 23, the select's input 16 + 21), inside the noise
+// budget; the result is refreshed once at the end.  101 bootstraps per position for n = 1025 instead of 209 (bits
+// routed separately, stay and move selected separately).
 FStr Strings::f_compact(const FStr &s) {
     const size_t n = s.size();
     if (n <= 1) return s;
@@ -1288,35 +1292,49 @@ FStr Strings::f_compact(const FStr &s) {
         const bool hi = k & 1;
         // the stage's move flag: bit k of the shift, from its digit; statically 0 where the shift cannot reach 2^k
         std::vector<Ref> mv(n);
+        std::vector<bool> moves(n);
         for (size_t p = 0; p < n; p++) {
             if (d > p || (e_->is_triv(dg[p][q].id()) && ((e_->triv_val(dg[p][q].id()) >> (hi ? 1 : 0)) & 1) == 0))
                 mv[p] = trivial_block(e_, 0);
             else mv[p] = pbs(dg[p][q], hi ? LUT_BIT1_UNLESS : LUT_BIT0_UNLESS);
+            moves[p] = !(e_->is_triv(mv[p].id()) && e_->triv_val(mv[p].id()) == 0);
         }
-        const size_t q0 = hi ? q + 1 : q;                    // digits still needed after this stage
+        // digits still needed after this stage: those holding a bit above k that exists (bits 0 .. K-1)
+        size_t q0 = hi ? q + 1 : q;
+        if ((size_t)k + 1 >= (size_t)K) q0 = D;              // last stage: nothing travels on
+        // the moving part of every block and digit
+        FStr md(n);
+        std::vector<std::vector<Ref>> mdg(n, std::vector<Ref>(D));
+        for (size_t p = 0; p < n; p++) {
+            if (!moves[p]) continue;
+            for (int blk = 0; blk < 4; blk++) md[p].b[blk] = pbs(lin(e_, {{4, &mv[p]}, {1, &cur[p].b[blk]}}), LUT_SEL_T);
+            for (size_t jq = q0; jq < D; jq++) mdg[p][jq] = pbs(lin(e_, {{4, &mv[p]}, {1, &dg[p][jq]}}), LUT_SEL_T);
+        }
         FStr nxt(n);
         std::vector<std::vector<Ref>> nd(n, std::vector<Ref>(D));
         for (size_t p = 0; p < n; p++) {
-            const Ref &bs = mv[p];
-            const bool stays = e_->is_triv(bs.id()) && e_->triv_val(bs.id()) == 0;
-            const bool has_src = p + d < n && !(e_->is_triv(mv[p + d].id()) && e_->triv_val(mv[p + d].id()) == 0);
-            auto route = [&](const Ref &here, const Ref *there) {
-                Ref st = stays ? here : pbs(lin(e_, {{4, &bs}, {1, &here}}), LUT_SEL_F);
-                if (stays && has_src && e_->sum_c2(st.id()) > 1) st = pbs(st, LUT_MSG);   // keep outputs at <= 2 terms
-                if (!has_src) return st;
-                Ref in = pbs(lin(e_, {{4, &mv[p + d]}, {1, there}}), LUT_SEL_T);
-                return lin(e_, {{1, &in}, {1, &st}});
+            const bool in = p + d < n && moves[p + d];
+            auto combine = [&](const Ref &here, const Ref *out, const Ref *inc) {
+                Term tt[3];
+                size_t m = 0;
+                tt[m++] = {1, here.id()};
+                if (out) tt[m++] = {-1, out->id()};
+                if (inc) tt[m++] = {1, inc->id()};
+                return m == 1 ? here : Ref(e_, e_->lin(tt, m, 0));
             };
             for (int blk = 0; blk < 4; blk++)
-                nxt[p].b[blk] = route(cur[p].b[blk], has_src ? &cur[p + d].b[blk] : nullptr);
+                nxt[p].b[blk] = combine(cur[p].b[blk], moves[p] ? &md[p].b[blk] : nullptr, in ? &md[p + d].b[blk] : nullptr);
             for (size_t jq = 0; jq < D; jq++) {
                 if (jq < q0) { nd[p][jq] = trivial_block(e_, 0); continue; }
-                nd[p][jq] = route(dg[p][jq], has_src ? &dg[p + d][jq] : nullptr);
+                nd[p][jq] = combine(dg[p][jq], moves[p] ? &mdg[p][jq] : nullptr, in ? &mdg[p + d][jq] : nullptr);
             }
         }
         cur.swap(nxt);
         dg.swap(nd);
     }
+    for (size_t p = 0; p < n; p++)                           // hand fresh ciphertexts to whatever comes next
+        for (int blk = 0; blk < 4; blk++)
+            if (e_->sum_c2(cur[p].b[blk].id()) > 1) cur[p].b[blk] = pbs(cur[p].b[blk], LUT_MSG);
     return cur;
 }
 

@@ -147,7 +147,7 @@ def test_automatic_partial_flush_plans_the_same_bootstraps(sk):
         return st["pbs_executed"], st["pbs_shared"], st["levels"]
     one_shot = run(0)
     peeled = run(64)
-    assert one_shot[0] > 10_000 and one_shot[0] <= peeled[0] <= 1.1 * one_shot[0]
+    assert one_shot[0] > 10_000 and one_shot[0] <= peeled[0] <= 1.15 * one_shot[0]
     assert peeled[2] > one_shot[2]                     # more, narrower launches: it really did peel
     sk.set_auto_flush(8192)
 
