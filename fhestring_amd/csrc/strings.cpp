@@ -148,6 +148,45 @@ FStr Strings::longer_from(const FStr &s, const FStr &from, FStr to, const FChar 
     while (to.size() < from.size()) to.push_back(zero);     // :847-849
     FChar counter = t(0);
     FStr result = data;
+    if (fused() && !use_counter && !from.empty() && from.size() <= 10 && from.size() <= result.size()) {
+        // The loop below writes `to` over every matching window in ascending order, flags taken on the ORIGINAL data: the
+        // LAST matching window that covers a position wins.  Re-associated per position p: sel_k = window p-k matches and
+        // none of p-k+1 .. p does (one bootstrap each on 5 * match[p-k] + the later flags: equals 5 exactly then), none =
+        // no window covers p; result[p] = none ? data[p] : to[the k that is set] -- (m + 1) selects per block instead of
+        // 2 m, two levels deep instead of m chained ones.
+        const size_t m = from.size(), end = adjust_end_of_pattern(result.size() - from.size());
+        std::vector<Ref> match(end);
+        for (size_t i = 0; i < end; i++) match[i] = window_match(data, i, from);
+        for (size_t p = 0; p < result.size(); p++) {
+            std::vector<Ref> later;                          // match flags of windows p-j, j < k, that exist
+            std::vector<std::pair<size_t, Ref>> sel;         // (k, flag)
+            for (size_t k = 0; k < m && k <= p; k++) {
+                const size_t i = p - k;
+                if (i >= end) continue;
+                if (later.empty()) sel.push_back({k, match[i]});
+                else {
+                    Term tt[12];
+                    size_t c = 0;
+                    tt[c++] = {5, match[i].id()};
+                    for (const Ref &l : later) tt[c++] = {1, l.id()};
+                    sel.push_back({k, pbs(Ref(e_, e_->lin(tt, c, 0)), lut_is_k(5))});
+                }
+                later.push_back(match[i]);
+            }
+            if (sel.empty()) continue;                       // no window reaches this position
+            Ref none = pbs(sum_refs(e_, later.data(), later.size()), lut_is_k(0));
+            for (int b = 0; b < 4; b++) {
+                Term tt[12];
+                size_t c = 0;
+                Ref keepv = pbs(lin(e_, {{4, &none}, {1, &data[p].b[b]}}), LUT_SEL_T);
+                std::vector<Ref> parts{keepv};
+                for (auto &kv : sel) parts.push_back(pbs(lin(e_, {{4, &kv.second}, {1, &to[kv.first].b[b]}}), LUT_SEL_T));
+                for (const Ref &x : parts) tt[c++] = {1, x.id()};
+                result[p].b[b] = Ref(e_, e_->lin(tt, c, 0));
+            }
+        }
+        return bubble_zeroes_right(result);                 // :881
+    }
     if (from.size() <= result.size()) {
         const size_t end = adjust_end_of_pattern(result.size() - from.size());
         for (size_t i = 0; i < end; i++) {
