@@ -112,6 +112,6 @@ def test_automatic_partial_flush_decrypts_correctly(product):
         from fhestring_amd.api import FheSplit
         bufs, found = FheSplit.decrypt(parts, ck)
         assert found == 1 and bufs[:4] == ["a", "b", "", "c"] and all(b == "" for b in bufs[4:])
-        assert st["max_input_sum_c2"] <= 64 and st["levels"] > 200
+        assert st["max_input_sum_c2"] <= 64 and st["levels"] > 100
     finally:
         sk.close()
