@@ -867,6 +867,9 @@ std::vector<Ref> Strings::prefix_or(const std::vector<Ref> &f) {
         size_t m = 0;
         for (size_t u = 0; u < k; u++) tt[m++] = {1, f[15 * j + u].id()};
         tt[m++] = {1, q[j].id()};
+        const bool q0 = e_->is_triv(q[j].id()) && e_->triv_val(q[j].id()) == 0;
+        if (k == 0) { p[i] = q[j]; continue; }               // nothing of this chunk yet: the flag itself, no bootstrap
+        if (k == 1 && q0) { p[i] = f[15 * j]; continue; }    // OR of one 0/1 flag
         Ref sm(e_, e_->lin(tt, m, 0));       // <= 14 + 1
         p[i] = pbs(sm, LUT_NZ);              // folds to a constant when everything is trivial
     }
@@ -880,12 +883,60 @@ FChar Strings::f_find(const FStr &s, const FStr &pat) {
     std::vector<Ref> f(W);
     for (size_t i = 0; i < W; i++) f[i] = pat.empty() ? trivial_block(e_, 1) : window_match(s, i, pat);
     std::vector<Ref> p = prefix_or(f);
+    Ref found = or_tree(f);
+    if (W <= 256) return first_index(p, found);              // 255 = 3,3,3,3 when absent (:1023)
     std::vector<Ref> first(W);
     for (size_t i = 0; i < W; i++) first[i] = pbs(lin(e_, {{2, &f[i]}, {1, &p[i]}}), LUT_IS2);
-    Ref found = or_tree(f);
     Ref one = trivial_block(e_, 1);
     Ref nf = lin(e_, {{1, &one}, {-1, &found}});
-    return position_of(first, 0, &nf, 255);                  // 255 = 3,3,3,3 when absent (:1023)
+    return position_of(first, 0, &nf, 255);
+}
+
+// Index of the first set flag from the exclusive prefix ORs before[j] = OR(f[0 .. j-1]) (before[W] = found): the flags
+// g[j] = found - before[j] = [the first match sits at index >= j] form a thermometer, so floor(index / 4^d) = sum_r
+// g[r 4^d] and every base-4 digit is LINEAR in the prefix ORs,
+//     digit_d = sum_q L_q,   L_q = g[(4q+1) S] + g[(4q+2) S] + g[(4q+3) S] - 3 g[(4q+4) S],   S = 4^d,
+// with at most one block q non-zero (`found` cancels inside a block).  The two high digits are used as they are, the
+// low ones refresh their blocks first (noise budget); 255 when nothing is set.  ~90 bootstraps in 1-3 levels instead of
+// the one-hot route (first = f & !before, weighted sums: ~560 in 6) -- find on 256 characters: 8 levels instead of 11.
+FChar Strings::first_index(const std::vector<Ref> &before, const Ref &found) {
+    const size_t W = before.size();                          // index in [0, W), W <= 256
+    Ref one = trivial_block(e_, 1);
+    Ref nf = lin(e_, {{1, &one}, {-1, &found}});
+    auto g_terms = [&](size_t j, int64_t coef, std::vector<Term> &tt) {       // coef * g[j], j >= 1
+        if (j > W) return;                                   // index >= j is impossible
+        tt.push_back({coef, found.id()});
+        tt.push_back({-coef, j == W ? found.id() : before[j].id()});
+    };
+    FChar r;
+    for (int d = 0; d < 4; d++) {
+        const size_t S = (size_t)1 << (2 * d);
+        std::vector<Ref> blocks;                             // L_q, values 0..3, at most one non-zero
+        for (size_t q = 0; (4 * q + 1) * S <= W; q++) {
+            std::vector<Term> tt;
+            for (size_t i = 1; i <= 3; i++) g_terms((4 * q + i) * S, 1, tt);
+            g_terms((4 * q + 4) * S, -3, tt);
+            blocks.push_back(Ref(e_, e_->lin(tt.data(), tt.size(), 0)));
+        }
+        // add the blocks up within the noise budget: refresh (LUT_MSG) before a sum would pass ~40
+        while (blocks.size() > 1) {
+            int64_t c2 = 0;
+            for (const Ref &b : blocks) c2 += e_->sum_c2(b.id());
+            if (c2 + 9 <= 48) break;
+            std::vector<Ref> nxt;
+            if (e_->sum_c2(blocks[0].id()) > 1) {            // first pass: refresh every block
+                for (Ref &b : blocks) nxt.push_back(pbs(b, LUT_MSG));
+            } else {                                         // later passes: fresh partial sums of 15
+                for (size_t i = 0; i < blocks.size(); i += 15)
+                    nxt.push_back(pbs(sum_refs(e_, &blocks[i], std::min<size_t>(15, blocks.size() - i)), LUT_MSG));
+            }
+            blocks.swap(nxt);
+        }
+        Ref digit = blocks.empty() ? trivial_block(e_, 0) : (blocks.size() == 1 ? blocks[0] : sum_refs(e_, blocks.data(), blocks.size()));
+        digit = lin(e_, {{1, &digit}, {3, &nf}});            // 255 = 3,3,3,3 when absent
+        r.b[d] = pbs(digit, LUT_MSG);
+    }
+    return r;
 }
 
 // Window-sharded find: the same DAG as f_find on one rank's slice, with the global window index baked into the
