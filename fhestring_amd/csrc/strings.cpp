@@ -303,7 +303,40 @@ FChar Strings::ne(const FStr &a, const FStr &b) {            // mod.rs:1178-1186
     return ch_flip(r);
 }
 FChar Strings::eq_ignore_case(const FStr &a, const FStr &b) {   // mod.rs:1221-1231
+    if (fused()) return f_eq_ignore_case(a, b);
     return eq(to_lower(a), to_lower(b));
+}
+
+// eq(to_lower(a), to_lower(b)) without folding either string: two characters are equal ignoring case iff their low
+// nibbles are equal and their high nibbles are equal, or differ in the case bit 0x20 only with both characters letters
+// (top two bits 01, and the low nibble in 1..15 on the rows 0x4_ / 0x6_, in 0..10 on the rows 0x5_ / 0x7_: with equal
+// low nibbles one range test serves both).  7 bootstraps per position in 3 levels instead of 12 (case flags and folds
+// of both strings, then the nibble tests); the length condition of eq is the tail test of f_eq (NUL has no case).
+FChar Strings::f_eq_ignore_case(const FStr &a, const FStr &b) {
+    std::vector<Ref> f;
+    const size_t common = std::min(a.size(), b.size());
+    auto clean = [&](FChar c) {                              // operands that are sums of bootstrap outputs (a select,
+        for (int k = 0; k < 4; k++)                          // a case shift) are refreshed: the packings below weigh
+            if (e_->sum_c2(c.b[k].id()) > 1) c.b[k] = pbs(c.b[k], LUT_MSG);   // them with up to 4
+        return c;
+    };
+    for (size_t i = 0; i < common; i++) {
+        const FChar x = clean(a[i]), y = clean(b[i]);
+        Ref e_lo = pbs(lin(e_, {{1, &x.b[0]}, {4, &x.b[1]}, {-1, &y.b[0]}, {-4, &y.b[1]}}), LUT_IS0);
+        Ref b3 = pbs(lin(e_, {{1, &x.b[3]}, {4, &y.b[3]}}), LUT_EQIC_B3);
+        Ref b2 = pbs(lin(e_, {{1, &x.b[2]}, {4, &y.b[2]}}), LUT_EQIC_B2);
+        Ref lo = pbs(lin(e_, {{1, &x.b[0]}, {4, &x.b[1]}}), LUT_EQIC_LO);
+        Ref ok = pbs(lin(e_, {{1, &lo}, {4, &x.b[2]}}), LUT_EQIC_OK);
+        Ref c1 = pbs(lin(e_, {{1, &b2}, {3, &b3}}), LUT_EQIC_C1);
+        f.push_back(pbs(lin(e_, {{1, &c1}, {3, &ok}, {6, &e_lo}}), LUT_EQIC_FIN));
+    }
+    const FStr &longer = a.size() > b.size() ? a : b;
+    for (size_t i = common; i < longer.size(); i++) {
+        const FChar &c = longer[i];
+        f.push_back(pbs(lin(e_, {{1, &c.b[0]}, {4, &c.b[1]}}), lut_is_k(0)));
+        f.push_back(pbs(lin(e_, {{1, &c.b[2]}, {4, &c.b[3]}}), lut_is_k(0)));
+    }
+    return ch_flag(e_, and_tree(f));
 }
 
 FStr Strings::strip_prefix(const FStr &s, const FStr &pat, FChar *found) {   // mod.rs:1261-1307

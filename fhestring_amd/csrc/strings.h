@@ -102,7 +102,8 @@ class Strings {
     Ref char_nonzero(const FChar &c);                                 // 1 block: c != 0
     Ref char_significant(const FChar &c);                             // 1 block: c is neither NUL nor whitespace
     FChar position_of(const std::vector<Ref> &pick, size_t index_offset, const Ref *absent_flag, int absent_value);
-    FChar first_index(const std::vector<Ref> &before, const Ref &found);   // index of the first set flag, 255 if none
+    FChar first_index(const std::vector<Ref> &before, const Ref &found);
+    FChar f_eq_ignore_case(const FStr &a, const FStr &b);   // index of the first set flag, 255 if none
     FChar f_rfind(const FStr &s, const FStr &pat);
     FChar f_ends_with(const FStr &s, const FStr &needle, std::vector<Ref> *pick_out);
     FStr f_trim(const FStr &s, bool from_end);

@@ -248,3 +248,38 @@ def test_compare_partial_and_first_decides_single_gpu(product):
                            for k in range(3)])
             got = ck.decrypt_char(sk.flags_first_decides(list(ds), list(vs), 1 if name in ("le", "ge") else 0))
             assert got == int(f(a, b)) == ck.decrypt_char(getattr(sk, name)(ea, eb)), (a, b, name)
+
+
+def test_eq_ignore_case_on_byte_pairs(product):
+    """Fused eq_ignore_case compares the two strings without folding either (Strings::f_eq_ignore_case: nibble tests on
+    the pair, 7 bootstraps per position).  Checked per character against eq(to_lower, to_lower) semantics
+    (mod.rs:1221-1231; ASCII letters only change) on boundary bytes around both letter ranges, every letter in both
+    cases, digits / punctuation that differ by 0x20, bytes above 127, and random pairs -- also after another op
+    (operands that are sums of bootstrap outputs)."""
+    import random
+    ck, sk = product
+    sk.set_mode(1)
+    sk.stats(reset=True)
+    lower = lambda x: x + 32 if 0x41 <= x <= 0x5A else x
+    rnd = random.Random(20)
+    edge = [0x40, 0x41, 0x4A, 0x4F, 0x50, 0x5A, 0x5B, 0x60, 0x61, 0x6A, 0x6F, 0x70, 0x7A, 0x7B, 0x20, 0x00, 0x10, 0x30,
+            0x1F, 0x3F, 0x5F, 0x7F, 0xC1, 0xE1, 0x80]
+    pairs = [(a, b) for a in edge for b in edge if a == b or (a ^ b) in (0x20, 0x10, 0x01, 0x40)]
+    pairs += [(c, c ^ 0x20) for c in range(0x41, 0x5B)] + [(c ^ 0x20, c) for c in range(0x41, 0x5B)]
+    pairs += [(rnd.randrange(256), rnd.randrange(256)) for _ in range(60)]
+    pairs += [(c, c) for c in rnd.sample(range(1, 256), 30)]
+    out = []
+    for a, b in pairs:
+        ea = [ck.encrypt_char(a, sk)]
+        eb = [ck.encrypt_char(b, sk)]
+        out.append(sk.eq_ignore_case(ea, eb))
+    # through operands that are not fresh: upper-cased on the fly, and strings of different buffer lengths
+    s1 = ck.encrypt("Hello, World [x]{y}`@", 2, None, sk)
+    s2 = ck.encrypt("hELLO, wORLD [X]{Y}`@", 5, None, sk)
+    s3 = ck.encrypt("hELLO, wORLD {X}[Y]`@", 5, None, sk)
+    extra = [sk.eq_ignore_case(sk.to_upper(s1), s2), sk.eq_ignore_case(s1, sk.to_lower(s2)), sk.eq_ignore_case(s1, s3)]
+    sk.flush()
+    for (a, b), o in zip(pairs, out):
+        assert ck.decrypt_char(o) == int(lower(a) == lower(b)), (hex(a), hex(b))
+    assert [ck.decrypt_char(x) for x in extra] == [1, 1, 0]
+    assert sk.stats()["max_input_sum_c2"] <= 64
