@@ -1021,6 +1021,28 @@ FChar Strings::find_first_decides(const std::vector<Ref> &found, const std::vect
 // and `ge` equals `gt`, so: pick_i = X_i & !prefix_or(differs)_i with X = lt (lt, le) or gt (gt, ge),
 // ret = OR pick_i.  When no position differs (the reference's 255 sentinel, :1483,1518) the result is
 // the length-based comparison (:1520-1538).
+// One character pair of a comparison: the two sign bootstraps of blk_cmp_flag (nibble differences through the padding
+// bit: lt / eq / gt per nibble) already say whether the characters are equal, so the equality flag is a second look-up
+// on the same packed pair (4 s_hi + s_lo == 5) instead of two nibble tests and an AND: 4 bootstraps per pair, not 6.
+void Strings::cmp_pair(const FChar &a_in, const FChar &b_in, int cmp_lut, Ref *eq, Ref *x) {
+    FChar a = a_in, b = b_in;
+    Ref s[2];
+    for (int p = 0; p < 2; p++) {
+        Ref *blk[4] = {&a.b[2 * p], &a.b[2 * p + 1], &b.b[2 * p], &b.b[2 * p + 1]};
+        Ref d = lin(e_, {{1, blk[0]}, {4, blk[1]}, {-1, blk[2]}, {-4, blk[3]}});
+        if (e_->sum_c2(d.id()) > FHS_NOISE_BUDGET_SUM_C2) {  // operands that are sums of bootstrap outputs: refresh
+            for (int k = 0; k < 4; k++)
+                if (e_->sum_c2(blk[k]->id()) > 1) *blk[k] = pbs(*blk[k], LUT_MSG);
+            d = lin(e_, {{1, blk[0]}, {4, blk[1]}, {-1, blk[2]}, {-4, blk[3]}});
+        }
+        Ref sg = pbs(d, LUT_SIGN);
+        s[p] = lin(e_, {{1, &sg}}, 1);                       // {0: lt, 1: eq, 2: gt}
+    }
+    Ref v = lin(e_, {{4, &s[1]}, {1, &s[0]}});
+    *x = pbs(v, cmp_lut);
+    *eq = pbs(v, lut_is_k(5));
+}
+
 FChar Strings::f_comparison(const FStr &a_in, const FStr &b_in, int cmp) {
     FStr a = a_in, b = b_in;
     size_t min_len = std::min(a.size(), b.size());
@@ -1033,9 +1055,9 @@ FChar Strings::f_comparison(const FStr &a_in, const FStr &b_in, int cmp) {
     std::vector<Ref> differs(min_len), x(min_len);
     const int xl = (cmp == 0 || cmp == 1) ? LUT_CMP_LT : LUT_CMP_GT;
     for (size_t i = 0; i < min_len; i++) {
-        Ref eq = and_tree(block_eq_flags(a[i], b[i]));
+        Ref eq;
+        cmp_pair(a[i], b[i], xl, &eq, &x[i]);
         differs[i] = lin(e_, {{1, &one}, {-1, &eq}});
-        x[i] = blk_cmp_flag(a[i], b[i], xl);
     }
     std::vector<Ref> before = prefix_or(differs);
     std::vector<Ref> pick(min_len);
@@ -1086,9 +1108,9 @@ void Strings::f_cmp_partial(const FStr &a, const FStr &b, int cmp, FChar *any_di
     std::vector<Ref> differs(n), x(n);
     const int xl = (cmp == 0 || cmp == 1) ? LUT_CMP_LT : LUT_CMP_GT;
     for (size_t i = 0; i < n; i++) {
-        Ref eq = and_tree(block_eq_flags(a[i], b[i]));
+        Ref eq;
+        cmp_pair(a[i], b[i], xl, &eq, &x[i]);
         differs[i] = lin(e_, {{1, &one}, {-1, &eq}});
-        x[i] = blk_cmp_flag(a[i], b[i], xl);
     }
     std::vector<Ref> before = prefix_or(differs);
     std::vector<Ref> pick(n);

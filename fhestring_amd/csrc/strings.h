@@ -103,7 +103,8 @@ class Strings {
     Ref char_significant(const FChar &c);                             // 1 block: c is neither NUL nor whitespace
     FChar position_of(const std::vector<Ref> &pick, size_t index_offset, const Ref *absent_flag, int absent_value);
     FChar first_index(const std::vector<Ref> &before, const Ref &found);
-    FChar f_eq_ignore_case(const FStr &a, const FStr &b);   // index of the first set flag, 255 if none
+    FChar f_eq_ignore_case(const FStr &a, const FStr &b);
+    void cmp_pair(const FChar &a, const FChar &b, int cmp_lut, Ref *eq, Ref *x);   // index of the first set flag, 255 if none
     FChar f_rfind(const FStr &s, const FStr &pat);
     FChar f_ends_with(const FStr &s, const FStr &needle, std::vector<Ref> *pick_out);
     FStr f_trim(const FStr &s, bool from_end);
