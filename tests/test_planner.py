@@ -64,16 +64,19 @@ def test_config_dag_shapes(sk):
     assert (st["pbs_executed"], st["levels"]) == (564, 4) and w == [496, 62, 5, 1]
     st, w = run(lambda: sk.contains_clear(s65, "abcd"))               # one shared high nibble: tested once per position
     assert st["pbs_executed"] + st["pbs_shared"] == 564 and w == [313, 62, 5, 1]
+    # the fused DAGs of configs 3-5 as they are now (round 2: thermometer index for find, one bootstrap per block and
+    # stage in the compaction, tail tests instead of popcounts in eq / comparisons, eq_ignore_case on the pair): a
+    # change of these numbers is a change of the measured configs
     st, w = run(lambda: sk.find(s257, p4))
-    assert st["pbs_executed"] < 3200 and st["levels"] <= 12
+    assert (st["pbs_executed"], st["levels"]) == (2649, 9)          # 2 911 / 11 at the start of the round
     s1025, f5, t5 = sk.dummy_string(1025), sk.dummy_string(5), sk.dummy_string(5)
     st, w = run(lambda: sk.replace(s1025, f5, t5))
-    assert st["pbs_executed"] < 400_000 and st["levels"] < 60      # as written: 36.9 M PBS, 16 413 levels
+    assert (st["pbs_executed"], st["levels"]) == (137_539, 40)      # 255 795 / 35; as written: 36.9 M PBS, 16 413 levels
     a, b = sk.dummy_string(4097), sk.dummy_string(4097)
     st, w = run(lambda: sk.eq_ignore_case(a, b))
-    assert st["pbs_executed"] < 90_000 and st["levels"] < 30       # as written: 418 k + 258 k PBS, 16 396 levels
+    assert (st["pbs_executed"], st["levels"]) == (28_975, 7)        # 68 541 / 19; as written: 418 k + 258 k PBS
     st, w = run(lambda: sk.le(a, b))
-    assert st["pbs_executed"] < 70_000 and st["levels"] < 30       # as written: 344 k PBS, 24 591 levels
+    assert (st["pbs_executed"], st["levels"]) == (25_169, 13)       # 60 641 / 14; as written: 344 k PBS, 24 591 levels
     sk.set_mode(0)
     st, w = run(lambda: sk.contains_clear(s65, "abcd"))
     assert st["pbs_executed"] + st["pbs_folded"] == 2480 and st["levels"] == 68
