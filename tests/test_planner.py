@@ -64,6 +64,7 @@ def test_config_dag_shapes(sk):
     assert (st["pbs_executed"], st["levels"]) == (564, 4) and w == [496, 62, 5, 1]
     st, w = run(lambda: sk.contains_clear(s65, "abcd"))               # one shared high nibble: tested once per position
     assert st["pbs_executed"] + st["pbs_shared"] == 564 and w == [313, 62, 5, 1]
+    sk.set_auto_flush(0)                                             # whole DAGs: no levels peeled while recording
     # the fused DAGs of configs 3-5 as they are now (round 2: thermometer index for find, one bootstrap per block and
     # stage in the compaction, tail tests instead of popcounts in eq / comparisons, eq_ignore_case on the pair): a
     # change of these numbers is a change of the measured configs
@@ -77,6 +78,7 @@ def test_config_dag_shapes(sk):
     assert (st["pbs_executed"], st["levels"]) == (28_975, 7)        # 68 541 / 19; as written: 418 k + 258 k PBS
     st, w = run(lambda: sk.le(a, b))
     assert (st["pbs_executed"], st["levels"]) == (25_169, 13)       # 60 641 / 14; as written: 344 k PBS, 24 591 levels
+    sk.set_auto_flush(8192)
     sk.set_mode(0)
     st, w = run(lambda: sk.contains_clear(s65, "abcd"))
     assert st["pbs_executed"] + st["pbs_folded"] == 2480 and st["levels"] == 68
