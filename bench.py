@@ -548,7 +548,7 @@ def main():
         set_arith("mb2")
         for _ in range(P):
             step()
-        n3 = max(6, min(args.steps, 12)) if SKEW else max(1, min(args.steps, 2 * P))
+        n3 = args.steps if SKEW else max(1, min(args.steps, 2 * P))     # same protocol as the headline leg
         dt3, outs3, st3, kt3 = timed(n3)
         wl.check(outs3)
         multi_bit = {"pbs_local": float(st3["pbs_executed"]), "dt": dt3, "steps": n3, "kt": kt3}
