@@ -1422,7 +1422,17 @@ FStr Strings::f_compact(const FStr &s) {
     const size_t D = (size_t)(K + 1) / 2;
     const FChar zero = t(0);
     std::vector<Ref> z(n);
-    for (size_t i = 0; i < n; i++) z[i] = and_tree(block_eq_flags(s[i], zero));
+    for (size_t i = 0; i < n; i++) {
+        // is-NUL flag: two nibble tests -- unless the blocks are sums of bootstrap outputs whose packing (weights 1, 4) would
+        // leave the noise budget: then four single-block tests (5 bootstraps) instead of refreshing all four blocks first (7)
+        bool heavy = false;
+        for (int h = 0; h < 2; h++)
+            heavy = heavy || e_->sum_c2(s[i].b[2 * h].id()) + 16 * e_->sum_c2(s[i].b[2 * h + 1].id()) > FHS_NOISE_BUDGET_SUM_C2;
+        if (!heavy) { z[i] = and_tree(block_eq_flags(s[i], zero)); continue; }
+        std::vector<Ref> f;
+        for (int k = 0; k < 4; k++) f.push_back(pbs(s[i].b[k], LUT_IS0));
+        z[i] = and_tree(f);
+    }
     // per-position shift = number of NULs before it; NUL positions get shift 0 (they stay and contribute zeros)
     std::vector<Num> shifts = flag_prefix_counts(z, D);
     std::vector<std::vector<Ref>> dg(n, std::vector<Ref>(D));

@@ -72,7 +72,7 @@ def test_config_dag_shapes(sk):
     assert (st["pbs_executed"], st["levels"]) == (2649, 9)          # 2 911 / 11 at the start of the round
     s1025, f5, t5 = sk.dummy_string(1025), sk.dummy_string(5), sk.dummy_string(5)
     st, w = run(lambda: sk.replace(s1025, f5, t5))
-    assert (st["pbs_executed"], st["levels"]) == (137_539, 40)      # 255 795 / 35; as written: 36.9 M PBS, 16 413 levels
+    assert (st["pbs_executed"], st["levels"]) == (135_497, 39)      # 255 795 / 35; as written: 36.9 M PBS, 16 413 levels
     a, b = sk.dummy_string(4097), sk.dummy_string(4097)
     st, w = run(lambda: sk.eq_ignore_case(a, b))
     assert (st["pbs_executed"], st["levels"]) == (28_975, 7)        # 68 541 / 19; as written: 418 k + 258 k PBS
