@@ -951,18 +951,27 @@ FChar Strings::first_index(const std::vector<Ref> &before, const Ref &found) {
             g_terms((4 * q + 4) * S, -3, tt);
             blocks.push_back(Ref(e_, e_->lin(tt.data(), tt.size(), 0)));
         }
-        // add the blocks up within the noise budget: refresh (LUT_MSG) before a sum would pass ~40
-        while (blocks.size() > 1) {
+        // add the blocks up within the noise budget: while the whole sum (+ the `absent` term) would pass it, merge
+        // neighbours up to sum c^2 <= 60 and refresh each merged group (one value in 0..3: at most one block is non-zero)
+        for (;;) {
             int64_t c2 = 0;
             for (const Ref &b : blocks) c2 += e_->sum_c2(b.id());
-            if (c2 + 9 <= 48) break;
-            std::vector<Ref> nxt;
-            if (e_->sum_c2(blocks[0].id()) > 1) {            // first pass: refresh every block
-                for (Ref &b : blocks) nxt.push_back(pbs(b, LUT_MSG));
-            } else {                                         // later passes: fresh partial sums of 15
-                for (size_t i = 0; i < blocks.size(); i += 15)
-                    nxt.push_back(pbs(sum_refs(e_, &blocks[i], std::min<size_t>(15, blocks.size() - i)), LUT_MSG));
+            if (blocks.size() <= 1 || c2 + 9 <= 48) break;
+            std::vector<Ref> nxt, grp;
+            int64_t g2 = 0;
+            auto close = [&] {
+                if (grp.empty()) return;
+                nxt.push_back(pbs(grp.size() == 1 ? grp[0] : sum_refs(e_, grp.data(), grp.size()), LUT_MSG));
+                grp.clear();
+                g2 = 0;
+            };
+            for (const Ref &b : blocks) {
+                const int64_t w = e_->sum_c2(b.id());
+                if (g2 + w > 60) close();
+                grp.push_back(b);
+                g2 += w;
             }
+            close();
             blocks.swap(nxt);
         }
         Ref digit = blocks.empty() ? trivial_block(e_, 0) : (blocks.size() == 1 ? blocks[0] : sum_refs(e_, blocks.data(), blocks.size()));
