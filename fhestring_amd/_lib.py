@@ -5,7 +5,10 @@ entry point fails loudly when no MI355X is visible (fhs_ctx_create returns an
 error that FhsError carries).
 """
 import ctypes as C
+import importlib
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FHS_LIB_PATH: load another build of the same library (kernel experiments: tools/ablate_fft.py); never a fallback
@@ -18,6 +21,35 @@ class FhsError(RuntimeError):
     pass
 
 
+def hip_runtimes():
+    """Paths of the HIP runtimes (libamdhip64) mapped into this process."""
+    seen = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1]
+                if os.path.basename(path).startswith("libamdhip64") and path not in seen:
+                    seen.append(path)
+    except OSError:
+        pass
+    return seen
+
+
+def check_single_hip_runtime():
+    """Raise FhsError when two HIP runtimes are mapped into the process.
+
+    PyTorch ships its own libamdhip64 / libhsa-runtime64 next to /opt/rocm's.  The dynamic loader shares ONE copy only
+    when torch's is already there (this library's DT_NEEDED then resolves to it by SONAME); loaded in the other order,
+    torch's RPATH maps a second runtime beside /opt/rocm's and the first GPU call of either side can crash the process
+    (the segmentation faults of round 2's `call_b.log`: two pytest processes that loaded this library, then torch).
+    """
+    rts = hip_runtimes()
+    if len(rts) > 1:
+        raise FhsError(
+            "two HIP runtimes are mapped into this process (%s): `import torch` BEFORE fhestring_amd "
+            "(or not at all) so that both sides share one; refusing to touch the GPU" % ", ".join(rts))
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -25,7 +57,14 @@ def lib():
             raise FhsError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        # Load order (see check_single_hip_runtime): if torch is installed but not imported yet, import it first so
+        # that a later `import torch` of the host program cannot map a second runtime.  FHS_SKIP_TORCH_PRELOAD=1
+        # opts out (hosts that never use torch); the check below and in Context() still guards the process.
+        if (not hip_runtimes() and "torch" not in sys.modules and not os.environ.get("FHS_SKIP_TORCH_PRELOAD")
+                and importlib.util.find_spec("torch") is not None):
+            importlib.import_module("torch")
         _lib = C.CDLL(LIB_PATH)
+        check_single_hip_runtime()
         _declare(_lib)
     return _lib
 
@@ -147,6 +186,10 @@ def _declare(L):
     L.fhs_str_split_dim.restype = sz
     L.fhs_str_split.argtypes = [vp, i, hp, sz, hp, sz, h, hp, sz, C.POINTER(sz), hp]
     L.fhs_str_split.restype = i
+    L.fhs_dist_available.argtypes = []
+    L.fhs_dist_available.restype = i
+    L.fhs_dist_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(i)]
+    L.fhs_dist_stats.restype = i
     L.fhs_dist_config.argtypes = [vp, i, i]
     L.fhs_dist_config.restype = i
     L.fhs_flush_plan.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]

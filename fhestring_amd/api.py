@@ -3,7 +3,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import FhsError, lib
+from ._lib import FhsError, lib, check_single_hip_runtime
 
 BIG_CT = 2049
 SMALL_CT = 743
@@ -20,6 +20,8 @@ class Context:
 
     def __init__(self, device_id=0, planner=False):
         self._L = lib()
+        if not planner:
+            check_single_hip_runtime()     # a second HIP runtime mapped since the library was loaded: refuse, do not crash
         h = C.c_void_p()
         if planner:        # fhs_ctx_create_planner: records and levelises DAGs (statistics only), computes nothing
             rc = self._L.fhs_ctx_create_planner(C.byref(h))

@@ -70,6 +70,20 @@ int fhs_dist_unique_id(void *id) {
     return Dist::unique_id(id, err);
 }
 
+int fhs_dist_available(void) {
+    std::string err;
+    return Dist::available(err) ? 1 : 0;
+}
+
+int fhs_dist_stats(const fhs_ctx *c, uint64_t *n_allgather, uint64_t *bytes_sent, int *transport) {
+    if (!c) return FHS_ERR_ARG;
+    const Dist &d = c->eng.ctx.dist;
+    if (n_allgather) *n_allgather = d.n_gathers;
+    if (bytes_sent) *bytes_sent = d.bytes_sent;
+    if (transport) *transport = d.stream_ordered() ? FHS_TRANSPORT_RCCL : (d.active() ? FHS_TRANSPORT_HOST : FHS_TRANSPORT_NONE);
+    return FHS_OK;
+}
+
 int fhs_dist_init(fhs_ctx *c, int rank, int world, const void *nccl_unique_id) {
     if (!c || world < 1 || rank < 0 || rank >= world || !nccl_unique_id) return bad(c);
     if (hipSetDevice(c->eng.ctx.device) != hipSuccess) return c->eng.ctx.fail(FHS_ERR_HIP, "hipSetDevice failed");
@@ -181,6 +195,11 @@ static int dist_find(fhs_ctx *c, const fhs_char_t *s, size_t n, const FStr &pat,
         return e.ctx.fail(FHS_ERR_LIMIT, "Maximum supported size for find reached");
     FusedScope fs(e);
     Strings S(&e);
+    if (total_chars == 0 && pat.empty()) {                          // mod.rs:1017-1019: "" in "" is found at position 0
+        FChar zero = ch_trivial(&e, 0);
+        *out = store(e, zero);
+        return FHS_OK;
+    }
     Ref found;
     FChar pos;
     S.f_find_partial(load_str(e, s, n), pat, first_window, &found, &pos);

@@ -48,6 +48,12 @@ std::string rccl_err(const char *what, int rc) {
 }
 }  // namespace
 
+bool Dist::available(std::string &err) {
+    Rccl &r = rccl();
+    if (!r.load_error.empty()) { err = r.load_error; return false; }
+    return true;
+}
+
 int Dist::unique_id(void *out128, std::string &err) {
     Rccl &r = rccl();
     if (!r.load_error.empty()) { err = r.load_error; return -3; }
@@ -82,6 +88,8 @@ int Dist::init_host(int rk, int wd, HostAllGatherFn fn, void *user, std::string 
 
 int Dist::all_gather(const void *d_send, void *d_recv, size_t bytes, hipStream_t s, std::string &err) {
     if (bytes == 0) return 0;
+    n_gathers++;
+    bytes_sent += bytes;
     if (comm_) {
         if (int rc = rccl().AllGather(d_send, d_recv, bytes, /*ncclUint8*/ 1, comm_, s)) {
             err = rccl_err("ncclAllGather", rc);
@@ -125,6 +133,7 @@ void Dist::shutdown() {
     h_cap_ = 0;
     rank = 0;
     world = 1;
+    n_gathers = bytes_sent = 0;
 }
 
 }  // namespace fhs

@@ -19,6 +19,8 @@ class Dist {
     bool active() const { return comm_ != nullptr || host_fn_ != nullptr; }
     bool stream_ordered() const { return comm_ != nullptr; }
 
+    // librccl.so.1 loadable with every entry point used here (dlopen + dlsym only: no communicator, no GPU call)
+    static bool available(std::string &err);
     static int unique_id(void *out128, std::string &err);
     int init_rccl(int rank, int world, const void *id128, std::string &err);   // the caller has made the device current
     int init_host(int rank, int world, HostAllGatherFn fn, void *user, std::string &err);
@@ -26,6 +28,8 @@ class Dist {
     // host transport: synchronises `s`, stages through pinned host memory, calls back, uploads.
     int all_gather(const void *d_send, void *d_recv, size_t bytes_per_rank, hipStream_t s, std::string &err);
     void shutdown();
+    // exchange counters since init: calls of all_gather with a non-empty payload, bytes this rank contributed
+    unsigned long long n_gathers = 0, bytes_sent = 0;
 
   private:
     void *comm_ = nullptr;            // ncclComm_t

@@ -1193,8 +1193,10 @@ FChar Strings::position_of(const std::vector<Ref> &pick, size_t off, const Ref *
             for (size_t i = 0; i < W; i++) {
                 const int dig = (int)(((i + off) >> (2 * blk)) & 3);
                 if (!dig || e_->is_triv(pick[i].id())) {
-                    if (dig && e_->triv_val(pick[i].id())) { tt[m++] = {dig, pick[i].id()}; }   // folds into the constant
-                    if (m == 64) close();
+                    if (dig && e_->triv_val(pick[i].id())) {                                    // folds into the constant
+                        if (m == 64) close();               // tt is full: never write tt[64] (either branch may fill it)
+                        tt[m++] = {dig, pick[i].id()};
+                    }
                     continue;
                 }
                 if (c2 + dig * dig > limit || m == 64) close();

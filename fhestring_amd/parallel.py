@@ -68,26 +68,30 @@ class Dist:
         if world == 1 and dist is None:
             return self
         if dist.get_backend() == "nccl":
-            # the library's own communicator (ncclCommInitRank on this context's device).  The id travels through
-            # torch.distributed; whether EVERY rank came up is agreed on the same way, and if one did not, all of them
-            # fall back to a host transport carried by torch.distributed (slower: the gathered blocks take a detour
-            # through host memory; `transport` says which one runs)
-            ok = 1
-            try:
-                box = [unique_id() if rank == 0 else None]
-            except RuntimeError:
-                box, ok = [None], 0
-            dist.broadcast_object_list(box, src=0)
-            if box[0] is None:
-                ok = 0
-            elif ok:
-                ok = int(sk.ctx._L.fhs_dist_init(sk.ctx._h, rank, world, box[0]) == 0)
+            # the library's own communicator (ncclCommInitRank on this context's device).  ncclCommInitRank is
+            # collective, so the ranks first agree -- through torch.distributed -- that EVERY one of them can load
+            # librccl (fhs_dist_available: dlopen + dlsym only) and that rank 0 produced an id; only then do all of them
+            # enter it.  If one cannot, all of them fall back to a host transport carried by torch.distributed
+            # (slower: the gathered blocks take a detour through host memory; `transport` says which one runs, and
+            # bench.py refuses to report a multi-GPU number measured on the fallback).
+            ok = int(sk.ctx._L.fhs_dist_available() == 1)
+            box = [None]
+            if ok and rank == 0:
+                try:
+                    box = [unique_id()]
+                except RuntimeError:
+                    ok = 0
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
+                dist.broadcast_object_list(box, src=0)
+                ok = int(sk.ctx._L.fhs_dist_init(sk.ctx._h, rank, world, box[0]) == 0)
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
                 self.transport = "rccl"
             else:
-                if ok:
+                if ok and sk.ctx._L.fhs_dist_world(sk.ctx._h) > 1:
                     self.shutdown()
                 self.init_host_transport(lambda send: _torch_device_all_gather(dist, torch, send, world))
                 self.transport = "torch.distributed (fallback: the library's RCCL communicator did not come up)"
@@ -125,6 +129,13 @@ class Dist:
 
     def shutdown(self):
         self.sk.ctx._check(self.sk.ctx._L.fhs_dist_shutdown(self.sk.ctx._h))
+
+    def stats(self):
+        """fhs_dist_stats: all-gathers issued by this context, bytes this rank contributed, the transport in use."""
+        n, b, tr = C.c_uint64(), C.c_uint64(), C.c_int()
+        self.sk.ctx._check(self.sk.ctx._L.fhs_dist_stats(self.sk.ctx._h, C.byref(n), C.byref(b), C.byref(tr)))
+        return {"allgather_calls": int(n.value), "bytes_sent": int(b.value),
+                "transport": {0: "none", 1: "rccl", 2: "host"}[int(tr.value)]}
 
     def level_parallel(self, on=True):
         self.sk.ctx._check(self.sk.ctx._L.fhs_dist_level_parallel(self.sk.ctx._h, int(bool(on))))

@@ -259,6 +259,16 @@ int fhs_dist_init(fhs_ctx *ctx, int rank, int world, const void *nccl_unique_id 
 typedef int (*fhs_allgather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
 int fhs_dist_init_host_transport(fhs_ctx *ctx, int rank, int world, fhs_allgather_fn fn, void *user);
 int fhs_dist_shutdown(fhs_ctx *ctx);
+/* 1 if librccl.so.1 can be loaded with every entry point used here (dlopen + dlsym only: no communicator is made, no
+ * GPU is touched).  ncclCommInitRank is collective: agree on this among ALL ranks before any of them calls
+ * fhs_dist_init, or the ranks that could load it block forever waiting for the one that could not. */
+int fhs_dist_available(void);
+/* Exchange counters of this context since fhs_dist_init*: all-gathers issued (ncclAllGather calls, or host-transport
+ * callbacks), bytes THIS rank contributed, and which transport carries them. */
+#define FHS_TRANSPORT_NONE 0
+#define FHS_TRANSPORT_RCCL 1
+#define FHS_TRANSPORT_HOST 2
+int fhs_dist_stats(const fhs_ctx *ctx, uint64_t *n_allgather, uint64_t *bytes_sent, int *transport);
 int fhs_dist_rank(const fhs_ctx *ctx);
 int fhs_dist_world(const fhs_ctx *ctx);
 /* Partition helpers (pure host logic).  Windows 0..n_chars-m of contains/find split into `world` contiguous ranges:

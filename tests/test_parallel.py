@@ -121,3 +121,74 @@ def test_sharded_design_world2_gloo(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
     rcs = [p.wait(timeout=240) for p in procs]
     assert rcs == [0, 0]
+
+
+LEVEL_WORKER = r'''
+import ctypes as C, os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["FHS_ROOT"])
+from fhestring_amd.api import MyServerKey
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+
+# Level-parallel replace (BASELINE config 4's multi-GPU form): every rank records the SAME DAG through a planner
+# context (the product's DAG construction and levelisation; nothing is computed) and takes slice
+# [rank * cap, (rank + 1) * cap) of every dependency level -- the protocol of fhs_dist_config / fhs_flush_plan /
+# fhs_flush_level_exec / fhs_flush_level_commit that fhs_dist_level_parallel drives on the GPU.
+sk = MyServerKey.planner()
+sk.set_mode(1)
+sk.set_auto_flush(0)
+L, h = sk.ctx._L, sk.ctx._h
+sk.ctx._check(L.fhs_dist_config(h, rank, world))
+s, f, t = sk.dummy_string(257), sk.dummy_string(3), sk.dummy_string(2)
+out = sk.replace(s, f, t)
+n_levels, max_w = C.c_uint64(), C.c_uint64()
+sk.ctx._check(L.fhs_flush_plan(h, C.byref(n_levels), C.byref(max_w)))
+dummy = (C.c_uint64 * 1)()
+ok = n_levels.value > 10
+mine_total = 0
+for k in range(n_levels.value):
+    sk.stats(reset=True)
+    width, cap = C.c_uint64(), C.c_uint64()
+    sk.ctx._check(L.fhs_flush_level_exec(h, k, dummy, C.byref(width), C.byref(cap)))
+    mine = sk.stats()["pbs_executed"]
+    mine_total += mine
+    got = torch.zeros(world, 3, dtype=torch.int64)
+    parts = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(parts, torch.tensor([mine, width.value, cap.value], dtype=torch.int64))
+    widths = {int(p[1]) for p in parts}
+    caps = {int(p[2]) for p in parts}
+    ok &= len(widths) == 1 and len(caps) == 1                       # same DAG, same level on every rank
+    w, c = width.value, cap.value
+    ok &= c == (w + world - 1) // world                             # slice capacity
+    ok &= sum(int(p[0]) for p in parts) == w                        # the slices cover the level exactly once
+    ok &= all(int(parts[r][0]) == max(0, min(w, (r + 1) * c) - min(w, r * c)) for r in range(world))
+    sk.ctx._check(L.fhs_flush_level_commit(h, k, dummy))
+tot = torch.tensor([mine_total], dtype=torch.int64)
+dist.all_reduce(tot)
+# the same DAG in one piece
+sk2 = MyServerKey.planner()
+sk2.set_mode(1)
+sk2.set_auto_flush(0)
+s2, f2, t2 = sk2.dummy_string(257), sk2.dummy_string(3), sk2.dummy_string(2)
+o2 = sk2.replace(s2, f2, t2)
+sk2.stats(reset=True)
+sk2.flush()
+st = sk2.stats()
+ok &= int(tot.item()) == st["pbs_executed"] and st["levels"] == n_levels.value
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+'''
+
+
+def test_level_parallel_slices_world2_gloo(tmp_path):
+    """fhs_dist_level_parallel's partition off the GPU: two gloo ranks, each with a planner context, walk the
+    level-exec / commit protocol over the replace DAG; the slices of every level cover it exactly once."""
+    script = tmp_path / "level_worker.py"
+    script.write_text(LEVEL_WORKER)
+    env = dict(os.environ, FHS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
+    rcs = [p.wait(timeout=240) for p in procs]
+    assert rcs == [0, 0]

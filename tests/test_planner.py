@@ -190,3 +190,20 @@ def test_round_aligned_launch_groups(sk):
         assert run(3, 5)[-1] == 1692                       # off: ragged groups
     finally:
         sk.set_tick_balance(0)
+
+
+def test_position_sums_over_mixed_trivial_and_encrypted_strings(sk):
+    """position_of groups at most 64 terms per linear combination.  64 consecutive encrypted picks with digit 1
+    (characters 63..126 for block 3 with offset 1) followed by a pick that folded to a trivial 1 with a non-zero digit
+    used to write one Term past the group buffer: rfind("") on >= 127 encrypted characters followed by
+    trivial non-NUL ones takes exactly that path, and so does the sharded find's partial position."""
+    from fhestring_amd.api import FheString
+    sk.set_mode(1)
+    for n_enc, n_triv in ((127, 3), (130, 1), (191, 2), (64, 70)):
+        s = FheString(list(sk.dummy_string(n_enc).chars) + [sk.trivial(ord("x")) for _ in range(n_triv)])
+        sk.stats(reset=True)
+        r = sk.rfind(s, FheString([]))
+        sk.flush()
+        st = sk.stats()
+        assert st["pbs_executed"] > 0 and st["max_input_sum_c2"] <= BUDGET, (n_enc, n_triv, st)
+        del r

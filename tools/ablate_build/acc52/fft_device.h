@@ -1,0 +1,67 @@
+// Device helpers shared by the f64-FFT blind-rotation kernels (fft_kernels.hip: 2 wavefronts per ciphertext,
+// fft4_kernels.hip: 4 wavefronts per ciphertext).  Both kernels perform the same butterflies on the same values in
+// the same order, so one CPU mirror (mode 3 of the CPU oracle) checks either bit for bit.
+#pragma once
+#include "pbs_kernels.h"
+
+namespace fhs {
+namespace fftdev {
+
+#pragma clang fp contract(off)
+
+#include "fft_consts.inc"
+
+constexpr int FM = 1024;                       // complex points
+constexpr int FFT_LDS_DOUBLES = 2176;          // per wave: 1088 complex slots (same 17 408 B as the NTT path)
+
+struct cplx { double r, i; };
+__device__ __forceinline__ cplx cmul(cplx a, double wr, double wi) {
+    cplx t;
+    t.r = __builtin_fma(-a.i, wi, a.r * wr);
+    t.i = __builtin_fma(a.i, wr, a.r * wi);
+    return t;
+}
+__device__ __forceinline__ uint32_t fft_mod_switch(uint64_t x) { return (uint32_t)(((x + (1ull << 51)) >> 52) & 4095u); }
+
+// Cooley-Tukey butterfly (forward): (a, b) <- (a + w' b, a - w' b), w' = w or i*w (ROT), in 6 fused
+// operations: the sum is accumulated straight onto a, the difference is 2a - sum
+template <bool ROT> __device__ __forceinline__ void bf_fwd(cplx &a, cplx &b, double wr, double wi) {
+    const cplx u = a;
+    if (!ROT) {
+        a.r = __builtin_fma(-b.i, wi, __builtin_fma(b.r, wr, u.r));
+        a.i = __builtin_fma(b.i, wr, __builtin_fma(b.r, wi, u.i));
+    } else {
+        a.r = __builtin_fma(-b.i, wr, __builtin_fma(-b.r, wi, u.r));
+        a.i = __builtin_fma(-b.i, wi, __builtin_fma(b.r, wr, u.i));
+    }
+    b.r = __builtin_fma(2.0, u.r, -a.r);
+    b.i = __builtin_fma(2.0, u.i, -a.i);
+}
+// Gentleman-Sande butterfly (inverse): (a, b) <- (a + b, (a - b) conj(w')), w' = w or i*w (ROT)
+template <bool ROT> __device__ __forceinline__ void bf_inv(cplx &a, cplx &b, double wr, double wi) {
+    const cplx u = a, v = b;
+    a.r = u.r + v.r; a.i = u.i + v.i;
+    cplx d; d.r = u.r - v.r; d.i = u.i - v.i;
+    const cplx q = cmul(d, wr, -wi);
+    if (!ROT) b = q;
+    else { b.r = q.i; b.i = -q.r; }
+}
+
+// Torus value (mod 2^64) of t * 2^64, where t is the inverse transform's output: the Fourier-domain key carries
+// the factor 2^-64 (beside 1/1024), so the accumulator increment is the fractional part of t.  fract is exact;
+// 1 + f puts that fraction into the 52 mantissa bits of a double in [1, 2] (one rounding at 2^-52, i.e. 2^12 torus
+// units, far below the noise), which two 32-bit shifts move to the top of the 64-bit word.
+__device__ __forceinline__ uint64_t to_torus(double t) {
+    const double g = 1.0 + __builtin_amdgcn_fract(t);
+    const uint64_t b = __builtin_bit_cast(uint64_t, g);
+    return b;
+    typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+    const u32x2 w = __builtin_bit_cast(u32x2, b);
+    u32x2 o;
+    o.x = w.x << 12;
+    o.y = __builtin_amdgcn_alignbit(w.y, w.x, 20);
+    return __builtin_bit_cast(uint64_t, o);                    // (b << 12) mod 2^64
+}
+
+}  // namespace fftdev
+}  // namespace fhs

@@ -138,8 +138,11 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
             const uint64_t v = vq[r % RW];
             if (r + RW < 32) vq[r % RW] = vbase[64 * ((r + RW - sh) & 31)];
             const uint64_t wrapmask = __builtin_amdgcn_ballot_w64(64 * r < thr);
-            const uint32_t dhi = rot_sub_hi(v, acc[r], wrapmask ^ negmask);
-            const int32_t dig = (int32_t)(dhi + 0x100u) >> 9;
+            uint32_t mm;
+            asm("v_cndmask_b32 %0, -1, 0, %1" : "=v"(mm) : "s"(wrapmask ^ negmask));
+            const uint64_t e = (v ^ (((uint64_t)mm << 32) | mm)) + acc[r];
+            const uint32_t al = __builtin_amdgcn_alignbit((uint32_t)(e >> 32), (uint32_t)e, 28) + 1u;
+            const int32_t dig = __builtin_amdgcn_sbfe(al, 1, 23);
             if (r < 16) z[r].r = (double)dig; else z[r - 16].i = (double)dig;
             __builtin_amdgcn_sched_barrier(0);        // keep the read of row r + RW behind the use of row r, RW in flight
         }

@@ -93,13 +93,8 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
 #pragma unroll
     for (int r = 0; r < 32; r++) my_u[64 + lane + 64 * r] = acc[r];
     my_u[lane] = acc[31];                             // row 31 again in front of row 0 (see the rotated read)
-    // the mask element of the NEXT iteration is requested one iteration ahead (ks[LWE_N], the body, is a valid address):
-    // read at the top of its own iteration it cost one exposed global-memory round trip per iteration
-    uint64_t ks_next = ks[0];
     for (int i = 0; i < LWE_N; i++) {
-        const uint32_t a = __builtin_amdgcn_readfirstlane(fft_mod_switch(ks_next));
-        __builtin_amdgcn_sched_barrier(0);            // use the value requested an iteration ago BEFORE the next request
-        ks_next = ks[i + 1];
+        const uint32_t a = fft_mod_switch(ks[i]);
         if (a == 0) continue;
         const uint32_t s = a & (POLY_N - 1);
         const bool neg = a >= POLY_N;
@@ -122,26 +117,17 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
         // lower, which for row 0 is the copy of row 31 kept in front of it.  The sign flips where the index wrapped.
         const uint32_t sl = s & 63, sh = s >> 6;
         const bool borrow = (uint32_t)lane < sl;
-        const uint64_t negmask = neg ? ~0ull : 0ull;
+        const uint64_t borrowmask = __builtin_amdgcn_ballot_w64(borrow), negmask = neg ? ~0ull : 0ull;
         const uint64_t *vbase = my_u + (((uint32_t)lane - sl) & 63) + (borrow ? 0 : 64);
-        // the index wrapped (sign flip) where n = lane + 64 r < s, i.e. 64 r < s - lane: one vector compare per row
-        // against a per-lane threshold instead of ~7 scalar operations per row building the same lane mask
-        const int32_t thr = (int32_t)s - lane;
-        // the reads run RW rows ahead of their use: issued one at a time right before its use, every row paid a full
-        // LDS round trip (32 exposed round trips per iteration)
-        constexpr int RW = 8;
-        uint64_t vq[RW];
-#pragma unroll
-        for (int k = 0; k < RW; k++) vq[k] = vbase[64 * ((k - sh) & 31)];
 #pragma unroll
         for (int r = 0; r < 32; r++) {
-            const uint64_t v = vq[r % RW];
-            if (r + RW < 32) vq[r % RW] = vbase[64 * ((r + RW - sh) & 31)];
-            const uint64_t wrapmask = __builtin_amdgcn_ballot_w64(64 * r < thr);
+            const uint64_t v = vbase[64 * ((r - sh) & 31)];
+            // lane mask of the sign flips, built from scalars: all lanes if the row index wrapped, the borrowing lanes
+            // in the row where it wraps, none above; inverted when the monomial carries a minus sign
+            const uint64_t wrapmask = (uint32_t)r < sh ? ~0ull : ((uint32_t)r == sh ? borrowmask : 0ull);
             const uint32_t dhi = rot_sub_hi(v, acc[r], wrapmask ^ negmask);
             const int32_t dig = (int32_t)(dhi + 0x100u) >> 9;
             if (r < 16) z[r].r = (double)dig; else z[r - 16].i = (double)dig;
-            __builtin_amdgcn_sched_barrier(0);        // keep the read of row r + RW behind the use of row r, RW in flight
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -163,15 +149,9 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
         __builtin_amdgcn_s_setprio(2);
         {   // partner row: z[c] += g[c] * kb (the second half of the pointwise product, same operation order as before)
             const cplx *par = reinterpret_cast<const cplx *>(partner) + lane;
-            // PW reads in flight ahead of their use (one at a time, each point waited for its own LDS round trip)
-            constexpr int PW = 4;
-            cplx gq[PW];
-#pragma unroll
-            for (int c = 0; c < PW; c++) gq[c] = par[c * 64];
 #pragma unroll
             for (int c = 0; c < 16; c++) {
-                const cplx g = gq[c % PW];
-                if (c + PW < 16) gq[c % PW] = par[(c + PW) * 64];
+                const cplx g = par[c * 64];
                 const double2_t k = kb[c & 7];
                 double rr = __builtin_fma(g.r, k.x, z[c].r); rr = __builtin_fma(-g.i, k.y, rr);
                 double ii = __builtin_fma(g.r, k.y, z[c].i); ii = __builtin_fma(g.i, k.x, ii);

@@ -58,6 +58,12 @@ KERNEL64(k_pk_fma_f32,  "v_pk_fma_f32 %0, %0, %3, %3")
 KERNEL64(k_pk_add_f32,  "v_pk_add_f32 %0, %0, %3")
 KERNEL64(k_pk_mul_f32,  "v_pk_mul_f32 %0, %0, %3")
 KERNEL64(k_rndne_f64,   "v_rndne_f64 %0, %0")
+KERNEL64(k_fract_f64,   "v_fract_f64 %0, %0")
+KERNEL64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %3")
+KERNEL64(k_cvt_f64_i32,  "v_cvt_f64_i32 %0, %1")
+KERNEL32(k_bfe_i32,     "v_bfe_i32 %0, %0, 1, 23")
+KERNEL32(k_subb,        "v_subb_co_u32 %0, vcc, %0, %1, vcc")
+KERNEL32(k_cndmask_s,   "v_cndmask_b32 %0, %0, %1, s[10:11]")
 KERNEL32(k_mov_dpp,     "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
 KERNEL32(k_permlane32,  "v_permlane32_swap_b32 %0, %1")
 
@@ -77,9 +83,10 @@ int main() {
         {"v_mad_u64_u32", k_mad_u64_u32}, {"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64},
         {"v_lshlrev_b64", k_lshl_b64}, {"v_lshrrev_b64", k_lshr_b64}, {"v_pk_fma_f32", k_pk_fma_f32},
         {"v_pk_add_f32", k_pk_add_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_rndne_f64", k_rndne_f64},
+        {"v_fract_f64", k_fract_f64}, {"v_lshl_add_u64", k_lshl_add_u64}, {"v_cvt_f64_i32", k_cvt_f64_i32}, {"v_bfe_i32", k_bfe_i32}, {"v_subb_co_u32", k_subb}, {"v_cndmask_b32_sgpr", k_cndmask_s},
         {"v_mov_b32_dpp", k_mov_dpp}, {"v_permlane32_swap", k_permlane32},
     };
-    for (int wpc : {1, 2, 4}) {          // workgroups (4 waves each) per CU -> waves per SIMD
+    for (int wpc : {2}) {          // workgroups (4 waves each) per CU -> waves per SIMD
         const int blocks = prop.multiProcessorCount * wpc;
         uint32_t* out; CK(hipMalloc(&out, (size_t)blocks * threads * 4));
         printf("--- %d waves/SIMD (blocks=%d x %d threads) : cycles per wave-instruction per SIMD\n", wpc, blocks, threads);
