@@ -252,21 +252,27 @@ def cpu_baseline(n_pbs, level_widths):
         ok = all(K.decrypt_block(out[i]) == radix.LUTS[names[idx[i]]](int(msgs[i])) for i in range(min(n, 16)))
         return n / dt, dt, ok
 
-    n_fft = n_pbs if n_pbs > 0 else 32 * cores
-    n_exact = max(cores, n_fft // 16)
-    fft_rate, fft_dt, fft_ok = run(2, n_fft)        # textbook radix-2 f64 FFT
-    mir_rate, mir_dt, mir_ok = run(3, n_fft)        # merged-twist f64 FFT (the GPU kernel's formulation)
+    n_vec = n_pbs if n_pbs > 0 else 64 * cores
+    n_fft = max(cores, n_vec // 4)
+    n_exact = max(cores, n_vec // 32)
+    vec_rate, vec_dt, vec_ok = run(6, n_vec)        # AVX2 + FMA f64 FFT (merged twist, radix-4 passes), vector keyswitch
+    fft_rate, fft_dt, fft_ok = run(2, n_fft)        # textbook scalar radix-2 f64 FFT
+    mir_rate, mir_dt, mir_ok = run(3, n_fft)        # the GPU kernel's lane-for-lane mirror (scalar)
     ex_rate, ex_dt, ex_ok = run(0, n_exact)
-    assert fft_ok and mir_ok and ex_ok, "CPU baseline produced wrong plaintexts"
-    best_mode, best = max(((3, mir_rate), (2, fft_rate), (0, ex_rate)), key=lambda t: t[1])
+    assert vec_ok and fft_ok and mir_ok and ex_ok, "CPU baseline produced wrong plaintexts"
+    best_mode, best = max(((6, vec_rate), (3, mir_rate), (2, fft_rate), (0, ex_rate)), key=lambda t: t[1])
+    per_thread_ms = 1e3 * cores / best
     out = {"value": best, "unit": "PBS/s", "cores": cores, "kind": "port",
-           "ms_per_pbs_per_thread": 1e3 * cores / best,
-           "sample": "oracle/tfhe_oracle.c (a scalar C port, NOT tfhe-rs: published tfhe-rs is ~10-20 ms/PBS/core, "
-                     "i.e. this port is ~%.1fx slower per core) on %d host threads, KS+MS+blind rotation+extract per PBS: "
-                     "merged-twist f64 FFT %d PBS in %.1f s = %.1f PBS/s; textbook f64 FFT %d PBS in %.1f s = %.1f PBS/s; "
-                     "exact NTT (parity oracle) %d PBS in %.1f s = %.1f PBS/s; fastest variant reported"
-                     % ((1e3 * cores / best) / 15.0, cores, n_fft, mir_dt, mir_rate, n_fft, fft_dt, fft_rate, n_exact,
-                        ex_dt, ex_rate)}
+           "ms_per_pbs_per_thread": per_thread_ms,
+           "variants_pbs_per_s": {"f64_fft_avx2_fma": vec_rate, "f64_fft_scalar_textbook": fft_rate,
+                                  "f64_fft_scalar_mirror_of_gpu_kernel": mir_rate, "exact_ntt_parity_oracle": ex_rate},
+           "sample": "oracle/tfhe_oracle.c mode 6 (a C port of the reference's algorithm class -- folded 1024-point "
+                     "f64 FFT external product with AVX2 + FMA, shift-and-add vector keyswitch -- NOT tfhe-rs itself, "
+                     "which cannot be built here) on %d host threads, keyswitch + modulus switch + blind rotation + "
+                     "extract per PBS: %d PBS in %.1f s = %.1f PBS/s = %.1f ms/PBS/thread (published tfhe-rs: ~10-20 "
+                     "ms/PBS/core); scalar variants: textbook f64 FFT %.1f PBS/s, GPU-kernel mirror %.1f PBS/s, exact "
+                     "NTT (the parity oracle) %.1f PBS/s; fastest variant reported"
+                     % (cores, n_vec, vec_dt, vec_rate, 1e3 * cores / vec_rate, fft_rate, mir_rate, ex_rate)}
     # (2) the same levelized batches as ONE op of the timed workload (widths from fhs_level_widths)
     if level_widths and sum(level_widths) <= 4096:
         t0 = time.perf_counter()
@@ -390,7 +396,14 @@ def main():
         x.ctx.set_arithmetic(ARITH[args.arith])
         x.set_mode(1 if args.mode == "fused" else 0)
         dists.append(Dist.from_torch(x, dist, torch, rank, world) if world > 1 else None)
-    if SKEW and not args.no_balance:
+    if world > 1 and os.environ.get("FHS_BENCH_BACKEND", "nccl") == "nccl":
+        # one rank per GPU: a multi-GPU figure must be measured on the library's own RCCL communicator (xGMI), never on
+        # the host-staged fallback that Dist.from_torch agrees on when librccl did not come up on some rank
+        bad = sorted({D.transport for D in dists if D.transport != "rccl"})
+        if bad:
+            raise SystemExit("bench.py --gpus %d: the exchange transport is %r, not the library's RCCL communicator; "
+                             "refusing to report a multi-GPU number measured through host memory" % (world, bad))
+    if not args.no_balance:
         for x in sks:
             x.set_tick_balance()                         # launch groups in whole rounds of the persistent kernel
     wl = Workload(args, ck, sks, dists, rank, world)
@@ -455,7 +468,7 @@ def main():
     def set_arith(a):
         for x in sks:
             x.ctx.set_arithmetic(ARITH[a])
-            if SKEW and not args.no_balance:
+            if not args.no_balance:
                 x.set_tick_balance()                     # resident slots of the kernel of THIS arithmetic
 
     def sync():
@@ -482,8 +495,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    ex0 = [D.stats() for D in dists if D is not None]
     dt, outs, st, kt = timed(args.steps)
+    ex1 = [D.stats() for D in dists if D is not None]
     wl.check(outs)
+    exchange = None
+    if ex1:
+        exchange = {"transport": ex1[0]["transport"],
+                    "allgather_calls_per_step": sum(b["allgather_calls"] - a["allgather_calls"] for a, b in zip(ex0, ex1)) / args.steps,
+                    "bytes_sent_per_rank_per_step": sum(b["bytes_sent"] - a["bytes_sent"] for a, b in zip(ex0, ex1)) / args.steps,
+                    "note": "fhs_dist_stats of this rank over the timed region: ncclAllGather calls issued by the library "
+                            "on the context's stream and the bytes this rank contributed"}
 
     # median of >= 5 repeats of a shorter run (SURVEY 8d timing protocol), outside the contract's timed region
     rep_ms = []
@@ -528,6 +550,47 @@ def main():
             single["as_written"] = {"levels": stw["levels"], "pbs": stw["pbs_executed"], "ms": aw_ms,
                                     "note": "the reference's own op order (FHS_MODE_AS_WRITTEN), same kernels"}
         del keep
+        if args.op == "contains" and args.mode == "fused":
+            # host timers split the way the reference's own timer brackets them together (src/main.rs:103-114,
+            # src/utils.rs:135-145): client encryption, upload, server op, download, decryption (median of 5)
+            text, pat = one.plain[0], one.pattern
+            parts = {k: [] for k in ("encrypt_ms", "upload_ms", "op_ms", "download_ms", "decrypt_ms")}
+            for _ in range(5):
+                ta = time.perf_counter(); raw = ck.encrypt_str_raw(text, 1)
+                tb = time.perf_counter(); s_up = sk.upload_string(raw); sync()
+                tc = time.perf_counter(); r_op = sk.contains_clear(s_up, pat); sk.flush(); sync()
+                td = time.perf_counter(); got = r_op.download()
+                te = time.perf_counter(); val = ck.decrypt_char_raw(got)
+                tf = time.perf_counter()
+                assert val == int(pat in text)
+                for k, v in zip(parts, (tb - ta, tc - tb, td - tc, te - td, tf - te)):
+                    parts[k].append(v * 1e3)
+                del s_up, r_op
+            single["host_timers"] = {k: statistics.median(v) for k, v in parts.items()}
+            single["host_timers"]["note"] = ("one contains_clear on one 64-char string: client encrypt (host CPU, like the "
+                                             "reference), upload, server op (record + plan + 4 levels on the GPU), "
+                                             "download, decrypt; the reference times all five together")
+            # BASELINE config 2's other cases: m = 8 and a miss
+            variants = {}
+            miss = next(c * 4 for c in "~^`|" if c * 4 not in text)
+            off8 = one.rnd.randint(0, len(text) - 8)
+            for name, p in (("m8_hit", text[off8:off8 + 8]), ("m4_miss", miss), ("m8_miss", miss * 2)):
+                s_in = ck.encrypt(text, 1, None, sk)
+                sk.flush(); sync()
+                r_op = sk.contains_clear(s_in, p); sk.flush(); sync()          # warm-up
+                sk.stats(reset=True)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    r_op = sk.contains_clear(s_in, p)
+                    sk.flush()
+                sync()
+                lat_v = (time.perf_counter() - t1) / 3 * 1e3
+                stv = sk.stats()
+                assert ck.decrypt_char(r_op) == int(p in text)
+                variants[name] = {"pattern_len": len(p), "found": int(p in text), "latency_ms": lat_v,
+                                  "pbs": stv["pbs_executed"] / 3, "levels": stv["levels"] / 3}
+                del s_in, r_op
+            single["cfg2_variants"] = variants
 
     # the other arithmetic on the same workload (secondary figure, fewer steps)
     secondary = None
@@ -622,6 +685,53 @@ def main():
                 set_arith(args.arith)
             del keep, w
 
+    # config 4 at n = 128 / 256 / 512 (the as-written op grows as n^2, the compaction as n log n) -- one GPU
+    cfg4_scaling = None
+    if extras is not None and world == 1:
+        cfg4_scaling = {}
+        for n in (128, 256, 512):
+            w = Workload(args, ck, sks[:1], dists[:1], rank, world, op="replace", chars=n, strings=1)
+            keep = w.step(0); sks[0].flush(); sync()
+            best = None
+            for _ in range(2):
+                sks[0].stats(reset=True)
+                t0 = time.perf_counter()
+                keep = w.step(0); sks[0].flush(); sync()
+                d = time.perf_counter() - t0
+                if best is None or d < best[0]:
+                    best = (d, sks[0].stats())
+            w.check(keep)
+            cfg4_scaling[str(n)] = {"ms_per_op": best[0] * 1e3, "pbs": best[1]["pbs_executed"], "levels": best[1]["levels"]}
+            del keep, w
+
+    # the as-written (reference op order) DAGs of configs 3-5: recorded and levelised by a planner context, nothing runs
+    as_written_shapes = None
+    if extras is not None and rank == 0:
+        pk = MyServerKey.planner()
+        pk.set_mode(0)
+        pk.set_auto_flush(0)
+        as_written_shapes = {}
+        def shape(name, fn):
+            pk.stats(reset=True)
+            r = fn(); pk.flush()
+            s = pk.stats()
+            as_written_shapes[name] = {"pbs": s["pbs_executed"], "pbs_constant_folded": s["pbs_folded"], "levels": s["levels"]}
+            del r
+        shape("cfg3_find_encrypted_256", lambda: pk.find(pk.dummy_string(257), pk.dummy_string(4)))
+        shape("cfg5_eq_ignore_case_4096", lambda: pk.eq_ignore_case(pk.dummy_string(4097), pk.dummy_string(4097)))
+        shape("cfg5_le_4096", lambda: pk.le(pk.dummy_string(4097), pk.dummy_string(4097)))
+        shape("cfg4_replace_128", lambda: pk.replace(pk.dummy_string(129), pk.dummy_string(5), pk.dummy_string(5)))
+        shape("cfg4_replace_256", lambda: pk.replace(pk.dummy_string(257), pk.dummy_string(5), pk.dummy_string(5)))
+        a, b = as_written_shapes["cfg4_replace_128"], as_written_shapes["cfg4_replace_256"]
+        as_written_shapes["cfg4_replace_1024_extrapolated"] = {
+            "pbs": b["pbs"] * 16.0, "levels": b["levels"] * 4.0,
+            "note": "n^2 law from the recorded n = 256 DAG (n = 128 -> 256 grows %.2fx in PBS, %.2fx in levels); the "
+                    "reference's own cost model gives 36.9 M PBS / 16 413 levels (SURVEY 8a: its radix ops cost 13-15 "
+                    "PBS where this build's cost 7-11)" % (b["pbs"] / a["pbs"], b["levels"] / a["levels"])}
+        as_written_shapes["note"] = ("FHS_MODE_AS_WRITTEN through fhs_ctx_create_planner: the reference's op order with "
+                                     "this build's radix decompositions; executed + constant-folded = the op count")
+        pk.close()
+
     pbs_local = st["pbs_executed"]
     if dist is not None:
         vec = [dt, float(pbs_local)] + ([secondary["dt"], secondary["pbs_local"]] if secondary else [0.0, 0.0])
@@ -686,7 +796,8 @@ def main():
                                         "less than one round, runs with the next step)")) if SKEW else
                                       "%d independent context(s), step k on context k mod %d" % (P, P)),
                        "parallelism": wl.parallelism(),
-                       "transport": dists[0].transport if dists and dists[0] is not None else "single GPU"},
+                       "transport": dists[0].transport if dists and dists[0] is not None else "single GPU",
+                       "exchange": exchange},
             "ms_per_op": dt / args.steps / wl.n_strings * 1e3,
             "median_ms_per_step": statistics.median(rep_ms) if rep_ms else None,
             "repeat_ms_per_step": rep_ms,
@@ -745,8 +856,21 @@ def main():
                 "ms_per_step": mx["dt"] / mx["steps"] * 1e3,
                 "roofline": roofline_for("blind_rotate_ntt_mb2_kernel", k4[0]["pbs"] / max(1, k4[0]["n"]), k4[0]["ms"],
                                          k4[0]["n"], counters, None)}
+        # both roofline figures, labelled: `frac` = hardware-counted FP64 flop / FP64 vector peak (<= 1);
+        # `survey_8d_frac` = SURVEY 8(d)'s contract figure PBS/s x 109 559 824 B / 8 TB/s, which charges one whole key to
+        # every PBS and therefore exceeds 1 as soon as one key sweep serves a batched launch
+        if line["roofline"].get("hbm"):
+            line["roofline"]["survey_8d_frac"] = line["roofline"]["hbm"]["survey_8d_figure_gbs"] / HBM_PEAK_GBS
+            line["roofline"]["survey_8d_frac_note"] = (
+                "contract definition (BASELINE.md 3): algorithmic bytes per PBS (whole BSK + KSK per PBS) x PBS per launch "
+                "/ launch time / 8 TB/s; > 1 because one key sweep out of L2 / Infinity Cache serves the whole launch -- the "
+                "kernel is FP64-issue-bound, see frac")
         if larger:
             line["larger_batch"] = larger
+        if cfg4_scaling:
+            line["cfg4_replace_scaling"] = cfg4_scaling
+        if as_written_shapes:
+            line["as_written_dag_shapes"] = as_written_shapes
         if extras:
             line["configs"] = {}
             names = {"find_enc": "cfg3_find_encrypted_256", "replace": "cfg4_replace_1024",
@@ -759,6 +883,18 @@ def main():
                     line["configs"][names[op]]["ms_per_op_multi_bit"] = e["ms_two_bit"]
         if args.cpu_pbs != 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_pbs, single["level_widths"] if single else None)
+            if extras:
+                rate = line["cpu_baseline"]["value"]
+                line["cpu_baseline"]["extrapolated"] = {
+                    k: {"fused_dag_s": v["pbs"] / rate,
+                        "as_written_dag_s": (as_written_shapes or {}).get(k, {}).get("pbs", 0) / rate or None}
+                    for k, v in line["configs"].items()}
+                if as_written_shapes:
+                    line["cpu_baseline"]["extrapolated"]["cfg4_replace_1024"]["as_written_dag_s"] = \
+                        as_written_shapes["cfg4_replace_1024_extrapolated"]["pbs"] / rate
+                line["cpu_baseline"]["extrapolated"]["note"] = (
+                    "configs 3-5 on the CPU port: PBS count / measured CPU PBS/s on %d threads (SURVEY 8d, BASELINE.md "
+                    "4.4: 'extrapolated'); fused = the DAG the GPU runs, as_written = the reference's op order" % line["cpu_baseline"]["cores"])
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

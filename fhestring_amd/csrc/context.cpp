@@ -236,10 +236,12 @@ int Context::set_arithmetic(int mode) {
     if ((mode == 1 || mode == 2) && key_loaded && !d_bsk_fft)
         return fail(-3, "select the f64-FFT arithmetic before loading the server key");
     if (mode == 2 && key_loaded && !d_bsk_mb)
-        return fail(-3, "the two-bits-per-product arithmetic needs the pair key (fhs_load_multibit_key)");
+        return fail(-3, "the two-bits-per-product arithmetic needs the pair key in the Fourier domain: call "
+                        "fhs_load_multibit_key while arithmetic 1 (f64 FFT) is selected, then fhs_set_arithmetic 2");
     if (mode == 3 && key_loaded && !d_bsk_ntt_mb)
-        return fail(-3, "the exact two-bits-per-product arithmetic needs the pair key, loaded in that arithmetic "
-                        "(fhs_set_arithmetic 3, then fhs_load_multibit_key)");
+        return fail(-3, "the exact two-bits-per-product arithmetic needs the pair key converted to residues: call "
+                        "fhs_load_multibit_key while the EXACT arithmetic (fhs_set_arithmetic 0) is selected, then "
+                        "fhs_set_arithmetic 3");
     arith = mode;
     return 0;
 }

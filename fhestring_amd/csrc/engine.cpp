@@ -260,7 +260,9 @@ Bid Engine::pbs(Bid x, int lut) {
             go = hipEventQuery(last_group_done_) == hipSuccess;
         if (go) {
             in_auto_flush_ = true;
-            (void)plan_job(true, true);                       // an error here resurfaces at the caller's flush
+            if (int rc = plan_job(true, true)) {              // kept: the caller's next flush reports THIS cause
+                if (!auto_flush_rc_) { auto_flush_rc_ = rc; auto_flush_err_ = ctx.err; }
+            }
             in_auto_flush_ = false;
         }
     }
@@ -276,6 +278,11 @@ Bid Engine::pbs(Bid x, int lut) {
 // flush: plan every level on the host, upload the plan once, enqueue all launches
 // ------------------------------------------------------------------------------------------
 int Engine::flush() {
+    if (auto_flush_rc_) {                                     // an automatic partial flush failed while the DAG was recorded
+        const int rc = auto_flush_rc_;
+        auto_flush_rc_ = 0;
+        return ctx.fail(rc, "automatic partial flush failed: " + auto_flush_err_);
+    }
     while (!sched_.empty())                                   // drain the scheduled ticks of submitted jobs first
         if (int rc = pump(1)) return rc;
     if (level_parallel && ctx.dist.active()) {                // world 1 too: same stream-ordered path
@@ -284,6 +291,15 @@ int Engine::flush() {
     }
     if (dist_world > 1 && !pending_.empty())
         return ctx.fail(-3, "distributed context: pending PBS must be run with fhs_flush_plan/level_exec/level_commit");
+    manual_jobs_ = false;                                     // every scheduled tick is in the stream: automatic partial flushes may resume
+    if (!capture_max_rows && balance_slots) {
+        // round-aligned launch groups inside ONE operation as well: the levels go through the tick scheduler at row
+        // granularity (plan_job), every tick is enqueued as soon as it is complete
+        if (int rc = plan_job(false, false, true)) return rc;
+        while (!sched_.empty())
+            if (int rc = pump(1)) return rc;
+        return 0;
+    }
     if (!capture_max_rows) return plan_job(true);             // level by level: planning overlaps execution
     int rc = plan_flush();                                    // capture mode: the all-at-once plan keeps the records
     if (rc) return rc;
@@ -296,7 +312,7 @@ int Engine::flush() {
 // ------------------------------------------------------------------------------------------
 // level-skewed batching: jobs, ticks
 // ------------------------------------------------------------------------------------------
-int Engine::plan_job(bool run_now, bool first_level_only) {
+int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
     if (pending_.empty()) return 0;
     if (!run_now && level_parallel && ctx.dist.active())
         return ctx.fail(-3, "fhs_submit is not available in level-parallel mode");
@@ -323,16 +339,21 @@ int Engine::plan_job(bool run_now, bool first_level_only) {
         n_depth1_ = 0;
     }
     uint64_t tick = next_tick_ - 1;                           // the job's first level goes to next_tick_ at the earliest
-    for (auto &kv : by_level) {
-        std::vector<Bid> &lv = kv.second;
+    const uint64_t job = ++job_counter_;
+    std::vector<uint64_t> row_need;                           // per row: latest tick that produces one of its inputs
+    for (auto lvit = by_level.begin(); lvit != by_level.end(); ++lvit) {
+        std::vector<Bid> &lv = lvit->second;
         TickLevel tl;
-        uint64_t need = 0;                                    // latest tick that produces one of this level's inputs
+        tl.job = job;
+        row_need.assign(lv.size(), 0);
+        size_t row_i = 0;
         for (Bid b : lv) {
             BlockNode &n = nodes_[b];
             const BlockNode &s = nodes_[n.src];
             LinDesc d{};
             d.first_term = (uint32_t)tl.terms.size();
             int64_t c2 = 0;
+            uint64_t &need = row_need[row_i++];
             if (s.kind == BlockNode::MAT) {
                 tl.terms.push_back({s.dev, 1});
                 d.n_terms = 1;
@@ -378,22 +399,50 @@ int Engine::plan_job(bool run_now, bool first_level_only) {
             }
             continue;
         }
-        tick = std::max(tick + 1, need + 1);
-        // round alignment: with `cur` rows already scheduled for this tick, keep only as many of this level's rows as
-        // fill whole rounds of the persistent kernel; at most one round's worth moves to the next tick
-        size_t keep = lv.size();
-        if (balance_slots && lv.size() >= balance_slots) {
+        // ---- list scheduling at ROW granularity ------------------------------------------------------------------
+        // A row runs at the first tick after the one that produces its last input (and not before the tick after the
+        // previous level's).  Rows of one level may therefore sit on different ticks: the rows that consume a result
+        // which was itself sent one tick later (round alignment below, or a dependent job) follow it, the others stay.
+        const uint64_t t0 = tick + 1;
+        uint64_t base = ~0ull, last = 0;
+        for (size_t k = 0; k < lv.size(); k++) {
+            row_need[k] = std::max(t0, row_need[k] + 1);      // now: the row's own tick
+            base = std::min(base, row_need[k]);
+            last = std::max(last, row_need[k]);
+        }
+        tick = base;
+        // round alignment: with `cur` rows already scheduled for the base tick, keep only as many of this level's on-time
+        // rows as fill whole rounds of the persistent kernel; the excess (less than one round) runs one tick later with
+        // whatever is scheduled there -- only ITS consumers follow it, the rest of the next level does not wait
+        size_t n_base = 0;
+        for (size_t k = 0; k < lv.size(); k++) n_base += row_need[k] == base;
+        if (balance_slots) {
             size_t cur = 0;
-            auto it = sched_.find(tick);
+            auto it = sched_.find(base);
             if (it != sched_.end())
                 for (const TickLevel &l : it->second) cur += l.descs.size();
-            const size_t total = cur + lv.size(), rem = total % balance_slots;
+            const size_t total = cur + n_base, rem = total % balance_slots;
             const size_t rounds = (total + balance_slots - 1) / balance_slots;
+            size_t defer = 0;
             // only when the last round would be less than ~2/3 full overall: a group that already fills 95 % of its rounds
             // is left alone (the split costs its consumers one tick)
-            if (rem && rem < lv.size() && total * 100 < rounds * balance_slots * 95) keep = lv.size() - rem;
+            // (jobs scheduled by hand share their ticks with jobs still to come: there only a level that is at least one
+            // round wide by itself is split; a streaming flush knows the whole population of the tick)
+            if ((stream_pump ? total : n_base) >= balance_slots && rem && rem < n_base &&
+                total * 100 < rounds * balance_slots * 95)
+                defer = rem;
+            // a sliver in front of a wide level (what an automatic partial flush leaves of a level: 16 388 = 2 x 8192 + 4)
+            // would pay one whole bootstrap alone: it joins the next tick, where the rows of the next level that do not
+            // consume it run anyway
+            auto nx = std::next(lvit);
+            if (stream_pump && !defer && total * 8 < balance_slots && nx != by_level.end() &&
+                nx->second.size() >= 2 * balance_slots)
+                defer = n_base;
+            for (size_t k = lv.size(); k-- > 0 && defer;)
+                if (row_need[k] == base) { row_need[k] = base + 1; defer--; }
+            for (size_t k = 0; k < lv.size(); k++) last = std::max(last, row_need[k]);
         }
-        last_sched_tick_ = std::max(last_sched_tick_, keep < lv.size() ? tick + 1 : tick);  // before the releases below
+        last_sched_tick_ = std::max(last_sched_tick_, last);  // before the releases below
         for (size_t k = 0; k < lv.size(); k++) {
             BlockNode &n = nodes_[lv[k]];
             const Bid src = n.src;
@@ -401,21 +450,44 @@ int Engine::plan_job(bool run_now, bool first_level_only) {
             n.dev = tl.out[k];
             n.src = 0;
             n.level = 0;
-            n.ready_tick = k < keep ? tick : tick + 1;
+            n.ready_tick = row_need[k];
             release(src);
         }
-        if (keep < lv.size()) {                               // split: rows [keep, n) form their own level one tick later
-            TickLevel late;
-            const uint32_t t0 = tl.descs[keep].first_term;
-            late.descs.assign(tl.descs.begin() + keep, tl.descs.end());
-            for (LinDesc &d : late.descs) d.first_term -= t0;
-            late.terms.assign(tl.terms.begin() + t0, tl.terms.end());
-            late.lut.assign(tl.lut.begin() + keep, tl.lut.end());
-            late.out.assign(tl.out.begin() + keep, tl.out.end());
-            tl.descs.resize(keep); tl.terms.resize(t0); tl.lut.resize(keep); tl.out.resize(keep);
-            sched_[tick + 1].push_back(std::move(late));
+        // hand the rows to their ticks (ascending): one TickLevel per job and tick, rows of several levels merged
+        std::vector<uint64_t> ticks(row_need.begin(), row_need.begin() + lv.size());
+        std::sort(ticks.begin(), ticks.end());
+        ticks.erase(std::unique(ticks.begin(), ticks.end()), ticks.end());
+        for (uint64_t tk : ticks) {
+            std::vector<TickLevel> &slot = sched_[tk];
+            TickLevel *dst = nullptr;
+            for (TickLevel &l : slot)
+                if (l.job == job) dst = &l;
+            if (!dst) {
+                slot.emplace_back();
+                dst = &slot.back();
+                dst->job = job;
+            }
+            if (ticks.size() == 1 && dst->descs.empty()) {    // the common case: the whole level on one tick
+                tl.job = job;
+                *dst = std::move(tl);
+                break;
+            }
+            for (size_t k = 0; k < lv.size(); k++) {
+                if (row_need[k] != tk) continue;
+                LinDesc d = tl.descs[k];
+                const uint32_t f = d.first_term;
+                d.first_term = (uint32_t)dst->terms.size();
+                dst->terms.insert(dst->terms.end(), tl.terms.begin() + f, tl.terms.begin() + f + d.n_terms);
+                dst->descs.push_back(d);
+                dst->lut.push_back(tl.lut[k]);
+                dst->out.push_back(tl.out[k]);
+            }
         }
-        sched_[tick].push_back(std::move(tl));
+        // streaming flush: every tick up to `base` is complete now (later levels cannot reach back) -- enqueue them while
+        // the host plans the next level
+        if (stream_pump)
+            while (!sched_.empty() && sched_.begin()->first <= base)
+                if (int rc = pump(1)) return rc;
     }
     return 0;
 }

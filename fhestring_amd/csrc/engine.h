@@ -161,19 +161,24 @@ class Engine {
         std::vector<LinTerm> terms;
         std::vector<uint32_t> lut;
         std::vector<uint64_t *> out;
+        uint64_t job = 0;                 // rows of one job that land on the same tick share one TickLevel
     };
     std::map<uint64_t, std::vector<TickLevel>> sched_;            // tick -> job levels to run in that launch group
     std::map<uint64_t, std::vector<uint64_t *>> free_after_;      // blocks reusable once that tick has been enqueued
     uint64_t next_tick_ = 1, last_sched_tick_ = 0;
     bool manual_jobs_ = false;           // the caller schedules jobs itself (fhs_submit): no automatic partial flushes
     bool in_auto_flush_ = false;
+    int auto_flush_rc_ = 0;              // first error of an automatic partial flush, reported by the next flush()
+    std::string auto_flush_err_;
     DevBuf tick_buf_;
     // sharded: level-parallel mode -- this rank runs slice [rank*cap, (rank+1)*cap) of the group into the exchange buffer,
     // the slices are all-gathered on the stream and scattered into the nodes' blocks
     int run_tick(std::vector<TickLevel> &levels, bool sharded = false);
     // plans the pending PBS level by level; run_now: every level is enqueued as soon as it is planned (the host plans level
     // k + 1 while the GPU runs level k), otherwise the levels are scheduled on ticks (submit)
-    int plan_job(bool run_now, bool first_level_only = false);
+    // stream_pump (scheduled path only): enqueue every tick as soon as no later level can add rows to it
+    int plan_job(bool run_now, bool first_level_only = false, bool stream_pump = false);
+    uint64_t job_counter_ = 0;
     size_t n_depth1_ = 0;                // pending bootstraps whose inputs are all available
     hipEvent_t last_group_done_ = nullptr;   // recorded behind every launch group: tells whether the GPU has run dry
     uint32_t idle_poll_ = 0;

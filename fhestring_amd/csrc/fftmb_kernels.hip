@@ -105,8 +105,15 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_mb2_kernel(BlindRotateMb2
         }
     }
 
+    // the pair of mask elements of the NEXT iteration is requested one iteration ahead (see fft_kernels.hip)
+    uint64_t kn0 = ks[0], kn1 = ks[1];
     for (int p = 0; p < LWE_N / 2; p++) {
-        const uint32_t e1 = fft_mod_switch(ks[2 * p]), e2 = fft_mod_switch(ks[2 * p + 1]);
+        asm volatile("" : "+v"(kn0), "+v"(kn1));          // opaque until here: nothing of the next iteration is computed early
+        const uint32_t e1 = __builtin_amdgcn_readfirstlane(fft_mod_switch(kn0));
+        const uint32_t e2 = __builtin_amdgcn_readfirstlane(fft_mod_switch(kn1));
+        __builtin_amdgcn_sched_barrier(0);
+        kn0 = ks[2 * p + 2];                              // p = 370: the body, a valid address
+        kn1 = ks[2 * p + 3 < SMALL_CT ? 2 * p + 3 : SMALL_CT - 1];
         if ((e1 | e2) == 0) continue;                     // both monomials are 1: the product is exactly zero
         __builtin_amdgcn_s_setprio(1);
 
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_mb2_kernel(BlindRotateMb2
             typedef const __attribute__((address_space(4))) double2_t *ck_t;
             const ck_t r16 = (ck_t)P.r16;
             const cplx *par = reinterpret_cast<const cplx *>(partner) + lane;
-            cplx g = par[0];
+            cplx gq[2] = {par[0], par[64]};               // two partner points in flight ahead of their use
             cplx a, b, a1, b1, ab1;
             double rr = 0, ii = 0;
 #pragma unroll
@@ -190,10 +197,11 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_mb2_kernel(BlindRotateMb2
                     rr = fr * A.r; rr = __builtin_fma(-fi, A.i, rr);
                     ii = fr * A.i; ii = __builtin_fma(fi, A.r, ii);
                 } else {
+                    const cplx g = gq[c & 1];
+                    if (c + 2 < 16) gq[c & 1] = par[(c + 2) * 64];
                     rr = __builtin_fma(g.r, A.r, rr); rr = __builtin_fma(-g.i, A.i, rr);
                     ii = __builtin_fma(g.r, A.i, ii); ii = __builtin_fma(g.i, A.r, ii);
                     z[c].r = rr; z[c].i = ii;
-                    if (c < 15) g = par[(c + 1) * 64];
                 }
             }
         }

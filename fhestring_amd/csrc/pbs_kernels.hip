@@ -74,8 +74,12 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
     }
     __syncthreads();
 
+    uint64_t ks_next = ks[0];   // requested one iteration ahead (ks[LWE_N], the body, is a valid address)
     for (int i = 0; i < LWE_N; i++) {
-        const uint32_t a = mod_switch(ks[i]);
+        asm volatile("" : "+v"(ks_next));
+        const uint32_t a = __builtin_amdgcn_readfirstlane(mod_switch(ks_next));
+        __builtin_amdgcn_sched_barrier(0);
+        ks_next = ks[i + 1];
         if (a == 0) continue;   // X^0*acc - acc == 0: exact no-op (uniform for the workgroup)
         const uint32_t s = a & (POLY_N - 1);
         const bool neg = a >= POLY_N;

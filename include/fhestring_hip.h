@@ -79,8 +79,10 @@ int fhs_load_server_key(fhs_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk);
 #define FHS_ARITH_F64_FFT_MB2 2
 /* EXACT_NTT_MB2: the same two-key-bits-per-product blind rotation in EXACT integer arithmetic (two-prime NTT, like
  * EXACT_NTT): no f64 rounding anywhere, bootstrap output sigma 2^48.8 (lower than the classic f64 FFT's), 1.6x the rate
- * of EXACT_NTT.  Select it, load the server key, then fhs_load_multibit_key: the pair key is converted for the
- * arithmetic that is selected at that moment (residues modulo the two NTT primes here, on the 57-bit torus grid).
+ * of EXACT_NTT.  Working order: fhs_load_server_key, then fhs_load_multibit_key WHILE arithmetic 0 (EXACT_NTT) is
+ * selected -- the pair key is converted for the arithmetic selected at that moment: residues modulo the two NTT primes
+ * on the 57-bit torus grid for 0 / 3, the Fourier domain for 1 / 2 -- then fhs_set_arithmetic(3), which is refused
+ * until the converted key exists (likewise: load under arithmetic 1, then select 2).
  * Bit-exact against mode 5 of the CPU oracle (an independent exact algorithm).  csrc/nttmb_kernels.hip. */
 #define FHS_ARITH_EXACT_NTT_MB2 3
 #define FHS_BSK_MB2_WORDS ((size_t)371 * 3 * 4 * 2048)

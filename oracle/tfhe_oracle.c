@@ -22,6 +22,7 @@
  *
  * Everything here is exact integer arithmetic (wrapping u64 torus).
  */
+#include <immintrin.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdint.h>
@@ -437,6 +438,195 @@ void orc_fft_bsk_convert(const u64 *bsk_quantised, double *out /* [742*4][16][64
     for (size_t p = 0; p < BSK_POLYS; p++) fmirror_bsk_poly(bsk_quantised + p * POLY_N, out + p * 2 * FM);
 }
 
+/* ---- mode 6: the CPU BASELINE of bench.py -- f64 FFT external product, AVX2 + FMA ----------------------------------
+ * The algorithm class of the reference's engine (tfhe 0.5.2 + concrete-fft 0.4.0, Cargo.lock:168-179: a folded
+ * 1024-point complex f64 FFT, SIMD through `pulp`), written for 4-wide vectors over split re / im arrays: merged-twist
+ * Cooley-Tukey forward (natural order in, bit-reversed out, no separate twist pass and no permutation), Gentleman-Sande
+ * inverse, the same twiddle table W as mode 3; the two narrowest stages use in-register permutes.  Torus conversion,
+ * rotation + decomposition and the pointwise products are vector loops as well.  It exists so that the CPU figure
+ * beside the GPU number is an honest one (the scalar port was ~2x slower per core than published tfhe-rs);
+ * it is decrypt-checked against the exact modes (tests/test_oracle_pbs.py) and is NEVER the parity oracle. */
+static double vW1_re[FM / 2 * 2], vW1_im[FM / 2 * 2];   /* twiddles of the distance-1 stage in unpack order */
+static int vec_ready = 0;
+static void vec_init(void) {
+    fmirror_init();
+    pthread_mutex_lock(&g_tab_mu);
+    if (!vec_ready) {
+        /* stage t = 1: m = 512 groups of 2; 8 consecutive points = pairs (0,1)(2,3)(4,5)(6,7) = groups g..g+3; after
+         * unpacklo / unpackhi of [x0..x3] and [x4..x7] the lanes hold pairs in the order g, g+2, g+1, g+3 */
+        for (int g = 0; g < 512; g += 4) {
+            const int o[4] = {g, g + 2, g + 1, g + 3};
+            for (int k = 0; k < 4; k++) { vW1_re[g + k] = fW_re[512 + o[k]]; vW1_im[g + k] = fW_im[512 + o[k]]; }
+        }
+        vec_ready = 1;
+    }
+    pthread_mutex_unlock(&g_tab_mu);
+}
+#define VLD(p) _mm256_loadu_pd(p)
+#define VST(p, v) _mm256_storeu_pd(p, v)
+/* forward butterfly on vectors: (a, b) <- (a + w b, a - w b) */
+#define VBF_FWD(ar, ai, br, bi, wr, wi) do { \
+        const __m256d tr_ = _mm256_fnmadd_pd(bi, wi, _mm256_mul_pd(br, wr)); \
+        const __m256d ti_ = _mm256_fmadd_pd(bi, wr, _mm256_mul_pd(br, wi)); \
+        br = _mm256_sub_pd(ar, tr_); bi = _mm256_sub_pd(ai, ti_); \
+        ar = _mm256_add_pd(ar, tr_); ai = _mm256_add_pd(ai, ti_); } while (0)
+/* inverse butterfly: (a, b) <- (a + b, (a - b) conj(w)) */
+#define VBF_INV(ar, ai, br, bi, wr, wi) do { \
+        const __m256d dr_ = _mm256_sub_pd(ar, br), di_ = _mm256_sub_pd(ai, bi); \
+        ar = _mm256_add_pd(ar, br); ai = _mm256_add_pd(ai, bi); \
+        br = _mm256_fmadd_pd(di_, wi, _mm256_mul_pd(dr_, wr)); \
+        bi = _mm256_fnmadd_pd(dr_, wi, _mm256_mul_pd(di_, wr)); } while (0)
+static void vec_forward(double *restrict re, double *restrict im) {
+    /* stages t = 512 .. 4 two at a time (one pass over memory per pair): distance t with W[m + i], then distance t/2
+     * with W[2m + 2i] (lower half of the block) and W[2m + 2i + 1] (upper half) */
+    for (int m = 1, t = FM / 2; t >= 8; m <<= 2, t >>= 2)
+        for (int i = 0; i < m; i++) {
+            const __m256d w1r = _mm256_set1_pd(fW_re[m + i]), w1i = _mm256_set1_pd(fW_im[m + i]);
+            const __m256d w2r = _mm256_set1_pd(fW_re[2 * m + 2 * i]), w2i = _mm256_set1_pd(fW_im[2 * m + 2 * i]);
+            const __m256d w3r = _mm256_set1_pd(fW_re[2 * m + 2 * i + 1]), w3i = _mm256_set1_pd(fW_im[2 * m + 2 * i + 1]);
+            double *pr = re + 2 * i * t, *pi = im + 2 * i * t;
+            const int h = t / 2;
+            for (int j = 0; j < h; j += 4) {
+                __m256d x0r = VLD(pr + j), x0i = VLD(pi + j), x1r = VLD(pr + j + h), x1i = VLD(pi + j + h);
+                __m256d x2r = VLD(pr + j + t), x2i = VLD(pi + j + t), x3r = VLD(pr + j + t + h), x3i = VLD(pi + j + t + h);
+                VBF_FWD(x0r, x0i, x2r, x2i, w1r, w1i);
+                VBF_FWD(x1r, x1i, x3r, x3i, w1r, w1i);
+                VBF_FWD(x0r, x0i, x1r, x1i, w2r, w2i);
+                VBF_FWD(x2r, x2i, x3r, x3i, w3r, w3i);
+                VST(pr + j, x0r); VST(pi + j, x0i); VST(pr + j + h, x1r); VST(pi + j + h, x1i);
+                VST(pr + j + t, x2r); VST(pi + j + t, x2i); VST(pr + j + t + h, x3r); VST(pi + j + t + h, x3i);
+            }
+        }
+    for (int g = 0; g < 256; g += 2) {      /* t = 2: groups of 4 points, two groups per pass */
+        double *pr = re + 4 * g, *pi = im + 4 * g;
+        const __m256d v0r = VLD(pr), v1r = VLD(pr + 4), v0i = VLD(pi), v1i = VLD(pi + 4);
+        __m256d ar = _mm256_permute2f128_pd(v0r, v1r, 0x20), br = _mm256_permute2f128_pd(v0r, v1r, 0x31);
+        __m256d ai = _mm256_permute2f128_pd(v0i, v1i, 0x20), bi = _mm256_permute2f128_pd(v0i, v1i, 0x31);
+        const __m256d wr = _mm256_setr_pd(fW_re[256 + g], fW_re[256 + g], fW_re[257 + g], fW_re[257 + g]);
+        const __m256d wi = _mm256_setr_pd(fW_im[256 + g], fW_im[256 + g], fW_im[257 + g], fW_im[257 + g]);
+        VBF_FWD(ar, ai, br, bi, wr, wi);
+        VST(pr, _mm256_permute2f128_pd(ar, br, 0x20)); VST(pr + 4, _mm256_permute2f128_pd(ar, br, 0x31));
+        VST(pi, _mm256_permute2f128_pd(ai, bi, 0x20)); VST(pi + 4, _mm256_permute2f128_pd(ai, bi, 0x31));
+    }
+    for (int g = 0; g < 512; g += 4) {      /* t = 1: pairs of neighbours, four groups per pass */
+        double *pr = re + 2 * g, *pi = im + 2 * g;
+        const __m256d v0r = VLD(pr), v1r = VLD(pr + 4), v0i = VLD(pi), v1i = VLD(pi + 4);
+        __m256d ar = _mm256_unpacklo_pd(v0r, v1r), br = _mm256_unpackhi_pd(v0r, v1r);
+        __m256d ai = _mm256_unpacklo_pd(v0i, v1i), bi = _mm256_unpackhi_pd(v0i, v1i);
+        const __m256d wr = VLD(vW1_re + g), wi = VLD(vW1_im + g);
+        VBF_FWD(ar, ai, br, bi, wr, wi);
+        VST(pr, _mm256_unpacklo_pd(ar, br)); VST(pr + 4, _mm256_unpackhi_pd(ar, br));
+        VST(pi, _mm256_unpacklo_pd(ai, bi)); VST(pi + 4, _mm256_unpackhi_pd(ai, bi));
+    }
+}
+static void vec_inverse(double *restrict re, double *restrict im) {
+    for (int g = 0; g < 512; g += 4) {
+        double *pr = re + 2 * g, *pi = im + 2 * g;
+        const __m256d v0r = VLD(pr), v1r = VLD(pr + 4), v0i = VLD(pi), v1i = VLD(pi + 4);
+        __m256d ar = _mm256_unpacklo_pd(v0r, v1r), br = _mm256_unpackhi_pd(v0r, v1r);
+        __m256d ai = _mm256_unpacklo_pd(v0i, v1i), bi = _mm256_unpackhi_pd(v0i, v1i);
+        const __m256d wr = VLD(vW1_re + g), wi = VLD(vW1_im + g);
+        VBF_INV(ar, ai, br, bi, wr, wi);
+        VST(pr, _mm256_unpacklo_pd(ar, br)); VST(pr + 4, _mm256_unpackhi_pd(ar, br));
+        VST(pi, _mm256_unpacklo_pd(ai, bi)); VST(pi + 4, _mm256_unpackhi_pd(ai, bi));
+    }
+    for (int g = 0; g < 256; g += 2) {
+        double *pr = re + 4 * g, *pi = im + 4 * g;
+        const __m256d v0r = VLD(pr), v1r = VLD(pr + 4), v0i = VLD(pi), v1i = VLD(pi + 4);
+        __m256d ar = _mm256_permute2f128_pd(v0r, v1r, 0x20), br = _mm256_permute2f128_pd(v0r, v1r, 0x31);
+        __m256d ai = _mm256_permute2f128_pd(v0i, v1i, 0x20), bi = _mm256_permute2f128_pd(v0i, v1i, 0x31);
+        const __m256d wr = _mm256_setr_pd(fW_re[256 + g], fW_re[256 + g], fW_re[257 + g], fW_re[257 + g]);
+        const __m256d wi = _mm256_setr_pd(fW_im[256 + g], fW_im[256 + g], fW_im[257 + g], fW_im[257 + g]);
+        VBF_INV(ar, ai, br, bi, wr, wi);
+        VST(pr, _mm256_permute2f128_pd(ar, br, 0x20)); VST(pr + 4, _mm256_permute2f128_pd(ar, br, 0x31));
+        VST(pi, _mm256_permute2f128_pd(ai, bi, 0x20)); VST(pi + 4, _mm256_permute2f128_pd(ai, bi, 0x31));
+    }
+    /* stages t = 4 .. 512 two at a time: distance h = t/2 first (groups 2i, 2i + 1 of the finer level), then distance t */
+    for (int t = 8, m = FM / 16; t < FM; t <<= 2, m >>= 2)
+        for (int i = 0; i < m; i++) {
+            const __m256d w1r = _mm256_set1_pd(fW_re[m + i]), w1i = _mm256_set1_pd(fW_im[m + i]);
+            const __m256d w2r = _mm256_set1_pd(fW_re[2 * m + 2 * i]), w2i = _mm256_set1_pd(fW_im[2 * m + 2 * i]);
+            const __m256d w3r = _mm256_set1_pd(fW_re[2 * m + 2 * i + 1]), w3i = _mm256_set1_pd(fW_im[2 * m + 2 * i + 1]);
+            double *pr = re + 2 * i * t, *pi = im + 2 * i * t;
+            const int h = t / 2;
+            for (int j = 0; j < h; j += 4) {
+                __m256d x0r = VLD(pr + j), x0i = VLD(pi + j), x1r = VLD(pr + j + h), x1i = VLD(pi + j + h);
+                __m256d x2r = VLD(pr + j + t), x2i = VLD(pi + j + t), x3r = VLD(pr + j + t + h), x3i = VLD(pi + j + t + h);
+                VBF_INV(x0r, x0i, x1r, x1i, w2r, w2i);
+                VBF_INV(x2r, x2i, x3r, x3i, w3r, w3i);
+                VBF_INV(x0r, x0i, x2r, x2i, w1r, w1i);
+                VBF_INV(x1r, x1i, x3r, x3i, w1r, w1i);
+                VST(pr + j, x0r); VST(pi + j, x0i); VST(pr + j + h, x1r); VST(pi + j + h, x1i);
+                VST(pr + j + t, x2r); VST(pi + j + t, x2i); VST(pr + j + t + h, x3r); VST(pi + j + t + h, x3i);
+            }
+        }
+}
+/* key polynomial -> [re 1024 | im 1024] in the forward transform's output order, pre-scaled by 2^-74 (1/1024, 2^-64) */
+static void vec_bsk_poly(const u64 *src, double *dst) {
+    double *re = dst, *im = dst + FM;
+    for (int n = 0; n < FM; n++) {
+        re[n] = (double)(int32_t)(src[n] >> 32) * 0x1p32 + (double)(uint32_t)src[n];
+        im[n] = (double)(int32_t)(src[n + FM] >> 32) * 0x1p32 + (double)(uint32_t)src[n + FM];
+    }
+    vec_forward(re, im);
+    for (int n = 0; n < 2 * FM; n++) dst[n] *= 0x1p-74;
+}
+/* acc += torus(t), t = increment / 2^64 (fractional part; one rounding at 2^-52 like the GPU kernel's conversion) */
+static inline void vec_acc_add(u64 *restrict acc, const double *restrict tv) {
+    const __m256d one = _mm256_set1_pd(1.0);
+    for (int n = 0; n < FM; n += 4) {
+        const __m256d x = VLD(tv + n);
+        const __m256d g = _mm256_add_pd(one, _mm256_sub_pd(x, _mm256_floor_pd(x)));
+        const __m256i b = _mm256_slli_epi64(_mm256_castpd_si256(g), 12);
+        _mm256_storeu_si256((__m256i *)(acc + n), _mm256_add_epi64(_mm256_loadu_si256((const __m256i *)(acc + n)), b));
+    }
+}
+static void poly_rotate(const u64 *in, unsigned a, u64 *out);
+static void blind_rotate_vec(const double *restrict bsk_vec, const u32 *ms, const u64 *lut, u64 *restrict acc /* [2][N] */) {
+    static __thread double F[2][2 * FM] __attribute__((aligned(32)));
+    static __thread double T[2 * FM] __attribute__((aligned(32)));
+    static __thread int32_t dig32[POLY_N] __attribute__((aligned(32)));
+    memset(acc, 0, POLY_N * sizeof(u64));
+    poly_rotate(lut, (2 * POLY_N - ms[LWE_N]) & (2 * POLY_N - 1), acc + POLY_N);
+    for (int i = 0; i < LWE_N; i++) {
+        const unsigned a = ms[i];
+        if (a == 0) continue;
+        const unsigned s = a & (POLY_N - 1);
+        const u64 sg = (a >> 11) & 1 ? ~0ull : 0ull;      /* X^a = -X^(a - N) for a >= N: two's complement through (v ^ sg) - sg */
+        for (int c = 0; c < 2; c++) {
+            const u64 *restrict ac = acc + c * POLY_N;
+            double *restrict re = F[c];                  /* [re 1024 | im 1024] = coefficients 0..2047 */
+            /* digit of X^a acc - acc: closest multiple of 2^41 as a signed 23-bit digit; two branch-free ranges */
+            for (unsigned n = 0; n < s; n++) {
+                const u64 v = (((u64)0 - ac[n + POLY_N - s]) ^ sg) - sg;
+                dig32[n] = (int32_t)((i64)(v - ac[n] + (1ull << 40)) >> 41);
+            }
+            for (unsigned n = s; n < POLY_N; n++) {
+                const u64 v = (ac[n - s] ^ sg) - sg;
+                dig32[n] = (int32_t)((i64)(v - ac[n] + (1ull << 40)) >> 41);
+            }
+            for (int n = 0; n < POLY_N; n++) re[n] = (double)dig32[n];
+            vec_forward(re, re + FM);
+        }
+        for (int col = 0; col < 2; col++) {
+            const double *b0 = bsk_vec + ((((size_t)i * 2 + 0) * 2 + col)) * 2 * FM;
+            const double *b1 = bsk_vec + ((((size_t)i * 2 + 1) * 2 + col)) * 2 * FM;
+            for (int q = 0; q < FM; q += 4) {
+                const __m256d f0r = VLD(F[0] + q), f0i = VLD(F[0] + FM + q), f1r = VLD(F[1] + q), f1i = VLD(F[1] + FM + q);
+                const __m256d k0r = VLD(b0 + q), k0i = VLD(b0 + FM + q), k1r = VLD(b1 + q), k1i = VLD(b1 + FM + q);
+                __m256d rr = _mm256_mul_pd(f0r, k0r), ii = _mm256_mul_pd(f0r, k0i);
+                rr = _mm256_fnmadd_pd(f0i, k0i, rr); ii = _mm256_fmadd_pd(f0i, k0r, ii);
+                rr = _mm256_fmadd_pd(f1r, k1r, rr);  ii = _mm256_fmadd_pd(f1r, k1i, ii);
+                rr = _mm256_fnmadd_pd(f1i, k1i, rr); ii = _mm256_fmadd_pd(f1i, k1r, ii);
+                VST(T + q, rr); VST(T + FM + q, ii);
+            }
+            vec_inverse(T, T + FM);
+            vec_acc_add(acc + col * POLY_N, T);
+            vec_acc_add(acc + col * POLY_N + FM, T + FM);
+        }
+    }
+}
+
 /* ---- server key --------------------------------------------------------- */
 typedef struct {
     u64 *bsk;      /* [742][2 rows][2 cols][2048] std domain, quantised to 2^6 */
@@ -444,6 +634,7 @@ typedef struct {
     u64 *bsk_ntt;  /* [742][2 rows][2 cols][2 limbs][2048] Goldilocks NTT     */
     double *bsk_fft; /* [742][2 rows][2 cols][1024] complex (re,im): f64-FFT variant (mode 2) */
     double *bsk_fm;  /* [742][2 rows][2 cols][16][64][2]: mirror of the GPU FFT kernel (mode 3), lazy */
+    double *bsk_vec; /* [742][2 rows][2 cols][re 1024 | im 1024]: Fourier-domain key of the vectorised CPU baseline (mode 6), lazy */
     double *bsk_mb;  /* [371][K1,K2,K3][2 rows][2 cols][16][64][2]: pair key of mode 4 (orc_server_key_set_mb2) */
     u64 *bsk_mb_q7;  /* [371][K1,K2,K3][2 rows][2 cols][2048] std domain, rounded to multiples of 2^7: mode 5 */
 } orc_server_key;
@@ -594,7 +785,7 @@ void orc_server_key_set_mb2(orc_server_key *k, const u64 *bsk_mb2) {
 
 void orc_server_key_free(orc_server_key *k) {
     if (!k) return;
-    free(k->bsk); free(k->ksk); free(k->bsk_ntt); free(k->bsk_fft); free(k->bsk_fm); free(k->bsk_mb); free(k->bsk_mb_q7); free(k);
+    free(k->bsk); free(k->ksk); free(k->bsk_ntt); free(k->bsk_fft); free(k->bsk_fm); free(k->bsk_vec); free(k->bsk_mb); free(k->bsk_mb_q7); free(k);
 }
 
 /* ---- client side (src/client_key.rs:85-106 via RadixClientKey) ---------- */
@@ -644,6 +835,23 @@ void orc_make_lut(const u64 *f_table, u64 *lut) {
     for (int t = 0; t < half; t++) lut[POLY_N - half + t] = (u64)0 - tmp[t];
 }
 
+/* acc[j] -= d * row[j] for a balanced base-8 digit d in [-4, 3], d != 0: shifts and adds on 4-wide vectors (AVX2 has no
+ * 64-bit multiply; the compiler's emulation through 32-bit products is ~2x slower).  Used by the CPU-baseline keyswitch
+ * below; the result is the same wrapping u64 arithmetic as the plain loop. */
+static inline void ks_row_mac(u64 *restrict acc, const u64 *restrict row, int d) {
+    const int n4 = SMALL_CT & ~3;
+    const int neg = d < 0, ad = neg ? -d : d;            /* |d| in 1..4 */
+    for (int j = 0; j < n4; j += 4) {
+        const __m256i x = _mm256_loadu_si256((const __m256i *)(row + j));
+        __m256i m = ad == 1 ? x : ad == 2 ? _mm256_slli_epi64(x, 1) : ad == 3 ? _mm256_add_epi64(_mm256_slli_epi64(x, 1), x)
+                                                                             : _mm256_slli_epi64(x, 2);
+        __m256i a = _mm256_loadu_si256((__m256i *)(acc + j));
+        a = neg ? _mm256_add_epi64(a, m) : _mm256_sub_epi64(a, m);
+        _mm256_storeu_si256((__m256i *)(acc + j), a);
+    }
+    for (int j = n4; j < SMALL_CT; j++) acc[j] -= (u64)(i64)d * row[j];
+}
+
 /* ---- keyswitch + modulus switch ------------------------------------------ */
 /* out[743]: a~_0..a~_741, b~ in [0,4096) */
 void orc_keyswitch_modswitch(const orc_server_key *k, const u64 *in, u32 *out) {
@@ -659,9 +867,7 @@ void orc_keyswitch_modswitch(const orc_server_key *k, const u64 *in, u32 *out) {
             v >>= 3;
             if (d >= 4) { d -= 8; v += 1; }
             if (d == 0) continue;
-            const u64 *row = k->ksk + ((size_t)i * KS_LEVEL + l) * SMALL_CT;
-            u64 du = (u64)d;
-            for (int j = 0; j < SMALL_CT; j++) acc[j] -= du * row[j];
+            ks_row_mac(acc, k->ksk + ((size_t)i * KS_LEVEL + l) * SMALL_CT, (int)d);
         }
     }
     for (int j = 0; j < SMALL_CT; j++)
@@ -845,6 +1051,7 @@ static void blind_rotate(const orc_server_key *k, const u32 *ms, const u64 *lut,
                          u64 *acc /* [2][N] */, int mode) {
     if (mode == 4) { blind_rotate_mb2(k, ms, lut, acc); return; }
     if (mode == 5) { blind_rotate_mb2_exact(k, ms, lut, acc); return; }
+    if (mode == 6) { blind_rotate_vec(k->bsk_vec, ms, lut, acc); return; }
     u64 *rot = (u64 *)malloc(POLY_N * sizeof(u64));
     i64 *dig = (i64 *)malloc(2 * POLY_N * sizeof(i64));
     u64 *dn = (u64 *)malloc(2 * POLY_N * sizeof(u64));
@@ -941,6 +1148,20 @@ static void ensure_mode(const orc_server_key *kc, int mode) {
     if ((mode == 4 || mode == 5) && !k->bsk_mb) {
         fprintf(stderr, "oracle: modes 4 and 5 need the pair key (orc_server_key_set_mb2)\n");
         abort();
+    }
+    if (mode == 6) {
+        vec_init();
+        pthread_mutex_lock(&g_tab_mu);
+        const int need6 = k->bsk_vec == 0;
+        pthread_mutex_unlock(&g_tab_mu);
+        if (need6) {
+            double *m = (double *)aligned_alloc(32, BSK_POLYS * 2 * FM * sizeof(double));
+            for (size_t p = 0; p < BSK_POLYS; p++) vec_bsk_poly(k->bsk + p * POLY_N, m + p * 2 * FM);
+            pthread_mutex_lock(&g_tab_mu);
+            if (!k->bsk_vec) k->bsk_vec = m; else free(m);
+            pthread_mutex_unlock(&g_tab_mu);
+        }
+        return;
     }
     if (mode != 3) return;
     pthread_mutex_lock(&g_tab_mu);

@@ -55,6 +55,29 @@ def test_fft_baseline_variant_decrypts_like_the_exact_path(oracle_keys, oracle_s
         assert min(e, 2**64 - e) < 2**53
 
 
+def test_vectorised_cpu_baseline_tracks_the_exact_path(oracle_keys, oracle_sk):
+    """mode 6 = bench.py's cpu_baseline (AVX2 + FMA f64 FFT external product, vector keyswitch): never the parity oracle,
+    but it must be RIGHT -- same plaintexts as the exact path for every input, output phase within 2^52 of it, and its
+    shift-and-add keyswitch must equal the plain multiply-accumulate loop word for word."""
+    names = ["msg", "carry", "eq_biv", "sign"]
+    luts = np.stack([radix.lut_poly(n) for n in names])
+    rng = np.random.default_rng(77)
+    msgs = np.concatenate([np.arange(16), rng.integers(0, 16, 8)])
+    idx = (np.arange(len(msgs)) % 4).astype(np.uint32)
+    cts = np.stack([oracle_keys.encrypt_block(int(m)) for m in msgs])
+    outs = oracle_sk.pbs_batch(cts, idx, luts, mode=6)
+    exact = oracle_sk.pbs_batch(cts, idx, luts, mode=0)
+    assert not np.array_equal(outs, exact)
+    for b in range(len(msgs)):
+        assert oracle_keys.decrypt_block(outs[b]) == radix.lut_eval(names[idx[b]], int(msgs[b]))
+        d = (oracle_keys.phase(outs[b]) - oracle_keys.phase(exact[b])) & (2**64 - 1)
+        assert min(d, 2**64 - d) < 2**52
+    for b in (0, 5, 17):
+        raw = oracle_sk.keyswitch(cts[b])                                   # plain loop, before the modulus switch
+        want = ((raw + np.uint64(1 << 51)) >> np.uint64(52)) & np.uint64(4095)
+        assert np.array_equal(oracle_sk.keyswitch_modswitch(cts[b]).astype(np.uint64), want)
+
+
 def test_fft_mirror_mode_decrypts_and_tracks_the_exact_path(oracle_keys, oracle_sk):
     """mode 3 mirrors the product's optional f64-FFT kernel lane for lane (the GPU test asserts
     bit-equality with it); here: same plaintexts as the exact path, phase within 2^52 of it."""

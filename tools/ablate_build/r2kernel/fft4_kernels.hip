@@ -117,14 +117,8 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
     for (int r = 0; r < 16; r++) stage[64 + k0 + 64 * (r & 7) + 1024 * (r >> 3)] = acc[r];
     if (h == 1) stage[lane] = acc[15];                // row 31 again in front of row 0 (see the rotated read)
 
-    // the mask element of the NEXT iteration is requested one iteration ahead (ks[LWE_N], the body, is a valid address):
-    // for a lone ciphertext its global-memory round trip at the top of every iteration was pure latency
-    uint64_t ks_next = ks[0];
     for (int i = 0; i < LWE_N; i++) {
-        asm volatile("" : "+v"(ks_next));
-        const uint32_t a = __builtin_amdgcn_readfirstlane(fft_mod_switch(ks_next));
-        __builtin_amdgcn_sched_barrier(0);
-        ks_next = ks[i + 1];
+        const uint32_t a = fft_mod_switch(ks[i]);
         if (a == 0) continue;
         const uint32_t s = a & (POLY_N - 1);
         const bool neg = a >= POLY_N;
@@ -138,25 +132,16 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         // register; this wave's register r is row 8 h + (r & 7) + 16 (r >> 3)), borrowing lanes one row lower
         const uint32_t sl = s & 63, sh = s >> 6;
         const bool borrow = (uint32_t)lane < sl;
-        const uint64_t negmask = neg ? ~0ull : 0ull;
         const uint64_t *vbase = stage + (((uint32_t)lane - sl) & 63) + (borrow ? 0 : 64);
-        // as in fft_kernels.hip: the index wrapped where 64 row + lane < s (one vector compare per row against a per-lane
-        // threshold), and the reads run RW rows ahead of their use instead of paying one LDS round trip each
-        const int32_t thr = (int32_t)s - lane;
-        constexpr int RW = 8;
-        uint64_t vq[RW];
-#pragma unroll
-        for (int k = 0; k < RW; k++) vq[k] = vbase[64 * ((8 * h + (k & 7) + 16 * (k >> 3) - sh) & 31)];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int row = 8 * h + (r & 7) + 16 * (r >> 3);
-            const uint64_t v = vq[r % RW];
-            if (r + RW < 16) vq[r % RW] = vbase[64 * ((8 * h + ((r + RW) & 7) + 16 * ((r + RW) >> 3) - sh) & 31)];
-            const uint64_t wrapmask = __builtin_amdgcn_ballot_w64(64 * row < thr);
-            const uint32_t dhi = rot_sub_hi(v, acc[r], wrapmask ^ negmask);
-            const int32_t dig = (int32_t)(dhi + 0x100u) >> 9;
+            const uint32_t row = 8 * h + (r & 7) + 16 * (r >> 3);
+            uint64_t v = vbase[64 * ((row - sh) & 31)];
+            const bool wrapped = (row < sh) || (row == sh && borrow);
+            if (wrapped != neg) v = (uint64_t)0 - v;
+            const uint64_t d = v - acc[r];
+            const int32_t dig = (int32_t)((uint32_t)(d >> 32) + 0x100u) >> 9;
             if (r < 8) z[r].r = (double)dig; else z[r - 8].i = (double)dig;
-            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                              // all rotated reads done before the area is reused
 
@@ -177,17 +162,11 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
 #pragma unroll
             for (int r = 0; r < 8; r++) mine[pslot(lane + 64 * r)] = z[r];
             __syncthreads();
-            // all 8 partner points requested first, ONE wave-uniform branch around the butterflies (a branch and a
-            // serialized LDS round trip per point before)
-            cplx o[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) o[r] = pair[pslot(lane + 64 * r)];
-            if (h == 0) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) bf_fwd<false>(z[r], o[r], w1.r, w1.i);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 8; r++) bf_fwd<false>(o[r], z[r], w1.r, w1.i);
+            for (int r = 0; r < 8; r++) {
+                cplx o = pair[pslot(lane + 64 * r)];
+                if (h == 0) bf_fwd<false>(z[r], o, w1.r, w1.i);      // wave-uniform branch
+                else bf_fwd<false>(o, z[r], w1.r, w1.i);
             }
             __syncthreads();                          // the partner has read this half's points
         }
@@ -289,15 +268,11 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
 #pragma unroll
             for (int r = 0; r < 8; r++) mine[pslot(lane + 64 * r)] = z[r];
             __syncthreads();
-            cplx o[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) o[r] = pair[pslot(lane + 64 * r)];
-            if (h == 0) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) bf_inv<false>(z[r], o[r], w1.r, w1.i);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 8; r++) bf_inv<false>(o[r], z[r], w1.r, w1.i);
+            for (int r = 0; r < 8; r++) {
+                cplx o = pair[pslot(lane + 64 * r)];
+                if (h == 0) bf_inv<false>(z[r], o, w1.r, w1.i);
+                else bf_inv<false>(o, z[r], w1.r, w1.i);
             }
             __syncthreads();                          // the partner has read this half's points
         }
