@@ -299,16 +299,21 @@ def cpu_baseline(n_pbs, level_widths):
 
 
 def load_counters():
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r02_counters.json")))
-    except Exception:
-        return {}
+    """Hardware-counted figures of the committed kernels (rocprofv3 --pmc passes of THIS bench command, profiles/README.md):
+    round 3's for the kernels re-profiled this round, round 2's for the others."""
+    out = {}
+    for name in ("r02_counters.json", "r03_counters.json"):
+        try:
+            out.update(json.load(open(os.path.join(ROOT, "profiles", name))))
+        except Exception:
+            pass
+    return out
 
 
 def roofline_for(kernel, pbs_per_launch, launch_ms, n_launches, counters, traffic):
     """Bounding resource: FP64 vector issue (SQ counters: the VALU is the busiest unit, HBM sits at a fraction of a
     percent).  achieved = FP64 flop per PBS, COUNTED by SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 under rocprofv3 on this kernel
-    (profiles/r02_counters.json), x PBS per launch / HIP-event launch time measured live.  frac <= 1 by construction."""
+    (profiles/r03_counters.json), x PBS per launch / HIP-event launch time measured live.  frac <= 1 by construction."""
     c = counters.get(kernel, {})
     flop = c.get("fp64_flop_per_pbs")
     r = {"bound": "fp64_valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,

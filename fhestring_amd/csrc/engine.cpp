@@ -256,8 +256,14 @@ Bid Engine::pbs(Bid x, int lut) {
         // while the host is still recording, and nothing narrower than one full round of workgroups is launched early
         // (level-parallel ranks must all take the same decisions: there only the deterministic count rule applies)
         bool go = n_depth1_ >= auto_flush_pending;
-        if (!go && n_depth1_ >= 1024 && !planner && !level_parallel && last_group_done_ && (++idle_poll_ & 255) == 0)
+        peel_limit_ = 0;
+        const size_t round = balance_slots ? balance_slots : 1024;
+        if (!go && n_depth1_ >= round && !planner && !level_parallel && last_group_done_ && (++idle_poll_ & 255) == 0) {
             go = hipEventQuery(last_group_done_) == hipSuccess;
+            // an idle GPU gets whole rounds of the persistent kernel only: 1 191 ready rows launched as they are cost two
+            // rounds; the remainder stays pending (it is ready, and joins the next launch)
+            peel_limit_ = n_depth1_ / round * round;
+        }
         if (go) {
             in_auto_flush_ = true;
             if (int rc = plan_job(true, true)) {              // kept: the caller's next flush reports THIS cause
@@ -322,15 +328,26 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
         // peel depth 1 only: the other pending nodes stay pending, one level shallower than before
         std::vector<Pend> rest;
         n_depth1_ = 0;
+        const size_t limit = peel_limit_ ? peel_limit_ : ~(size_t)0;
+        size_t left_ready = 0;
         for (const Pend &p : pending_) {
             BlockNode &n = nodes_[p.id];
             if (n.kind != BlockNode::PBS || n.gen != p.gen) continue;
-            if (n.level <= 1) by_level[1].push_back(p.id);
+            if (n.level <= 1 && by_level[1].size() < limit) by_level[1].push_back(p.id);
             else {
-                if (--n.level == 1) n_depth1_++;
+                if (n.level <= 1) left_ready++;
                 rest.push_back(p);
             }
         }
+        // every ready row taken: the rest moves one level up.  A partial peel (whole rounds only) leaves the levels alone:
+        // a stale level is only ever too HIGH, which keeps the order valid
+        if (left_ready == 0) {
+            for (const Pend &p : rest)
+                if (--nodes_[p.id].level == 1) n_depth1_++;
+        } else {
+            n_depth1_ = left_ready;
+        }
+        peel_limit_ = 0;
         pending_.swap(rest);
     } else {
         for (const Pend &p : pending_)

@@ -180,6 +180,7 @@ class Engine {
     int plan_job(bool run_now, bool first_level_only = false, bool stream_pump = false);
     uint64_t job_counter_ = 0;
     size_t n_depth1_ = 0;                // pending bootstraps whose inputs are all available
+    size_t peel_limit_ = 0;              // automatic partial flush of an idle GPU: take this many ready rows (0 = all)
     hipEvent_t last_group_done_ = nullptr;   // recorded behind every launch group: tells whether the GPU has run dry
     uint32_t idle_poll_ = 0;
     // Pinned staging for plan uploads: a hipMemcpyAsync from PAGEABLE memory blocks the host until the stream reaches

@@ -85,3 +85,40 @@ def test_config5_eq_ignore_case_and_le_4096(product):
     assert ck.decrypt_char(sk.len(ea)) == 4096 % 256      # u8 wrap, like the reference (G10)
     st = sk.stats()
     assert st["levels"] < 400                              # the as-written DAGs are 16k-24k levels deep
+
+
+def test_configs_with_round_aligned_launch_groups():
+    """fhs_set_tick_balance inside ONE operation (round 3): fhs_flush goes through the row-granular tick scheduler, rows of
+    a level may run one launch later than their siblings, and every launch group except the narrow tail is a whole
+    number of rounds of the persistent kernel.  Same plaintext results as without it, at full size, f64-FFT arithmetic."""
+    from fhestring_amd.api import MyClientKey
+    ck = MyClientKey(SEED)
+    sk = ck.get_server_key(0, arith=1)
+    sk.set_mode(1)
+    slots = sk.set_tick_balance()
+    try:
+        rnd = random.Random(SEED + 9)
+        a = _rand(rnd, 4096)
+        b = list(a.swapcase())
+        b[4000] = "a" if a[4000].lower() != "a" else "b"
+        b = "".join(b)
+        ea, eb = ck.encrypt(a, 1, None, sk), ck.encrypt(b, 1, None, sk)
+        sk.flush()
+        sk.stats(reset=True)
+        r1, r2, r3 = sk.eq_ignore_case(ea, eb), sk.le(ea, eb), sk.le(eb, ea)
+        sk.flush()
+        widths = sk.level_widths()
+        assert (ck.decrypt_char(r1), ck.decrypt_char(r2), ck.decrypt_char(r3)) == (0, int(a <= b), int(b <= a))
+        wide = [w for w in widths if w >= slots]
+        assert len(wide) >= 5 and sum(w % slots == 0 for w in wide) >= len(wide) - 2, widths
+        s = list(_rand(rnd, 1024).replace("~", "-"))
+        for k in range(8):
+            s[20 + 120 * k:25 + 120 * k] = "~from"
+        s = "".join(s)
+        out = sk.replace(ck.encrypt(s, 1, None, sk), ck.encrypt_no_padding("~from", sk), ck.encrypt_no_padding("[to!]", sk))
+        assert ck.decrypt(out) == s.replace("~from", "[to!]")
+        p = list(_rand(rnd, 256)); p[200:204] = "Qz7#"; p = "".join(p)
+        assert ck.decrypt_char(sk.find(ck.encrypt(p, 1, None, sk), ck.encrypt_no_padding("Qz7#", sk))) == p.find("Qz7#")
+    finally:
+        sk.close()
+        ck.close()

@@ -207,3 +207,34 @@ def test_position_sums_over_mixed_trivial_and_encrypted_strings(sk):
         st = sk.stats()
         assert st["pbs_executed"] > 0 and st["max_input_sum_c2"] <= BUDGET, (n_enc, n_triv, st)
         del r
+
+
+def test_round_alignment_inside_one_operation(sk):
+    """fhs_set_tick_balance + fhs_flush (round 3): one op's levels go through the row-granular tick scheduler.  Every
+    launch group at least one round wide is a whole number of rounds (except where a level's late rows join), nothing is
+    lost or duplicated, and only a final narrow tail is added to the number of launches."""
+    sk.set_mode(1)
+    sk.set_auto_flush(0)
+    def run(fn, balance):
+        slots = sk.set_tick_balance(balance)
+        sk.stats(reset=True)
+        keep = fn()
+        sk.flush()
+        st = sk.stats()
+        assert st["max_input_sum_c2"] <= BUDGET
+        return st["pbs_executed"], st["levels"], sk.level_widths()
+    try:
+        a, b = sk.dummy_string(4097), sk.dummy_string(4097)
+        for fn in (lambda: sk.le(a, b), lambda: sk.eq_ignore_case(a, b),
+                   lambda: sk.replace(sk.dummy_string(257), sk.dummy_string(3), sk.dummy_string(2))):
+            pbs0, lv0, w0 = run(fn, 0)
+            pbs1, lv1, w1 = run(fn, 1024)
+            assert pbs1 == pbs0 and sum(w1) == sum(w0)
+            assert lv0 <= lv1 <= lv0 + 2
+            wide0 = [w for w in w0 if w >= 1024]
+            wide1 = [w for w in w1 if w >= 1024]
+            assert sum(w % 1024 == 0 for w in wide1) >= len(wide1) - 1, w1
+            assert sum(w % 1024 == 0 for w in wide0) < len(wide0) or not wide0, w0     # it was ragged before
+    finally:
+        sk.set_tick_balance(0)
+        sk.set_auto_flush(8192)

@@ -38,6 +38,11 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--pbs="):
             pbs = int(a.split("=")[1])
+    flop_per_pbs = {}                      # --flop-per-pbs=kernel:value : PBS per dispatch = counted FP64 flop / value
+    for a in sys.argv[1:]:
+        if a.startswith("--flop-per-pbs="):
+            k, v = a.split("=", 1)[1].split(":")
+            flop_per_pbs[k] = float(v)
     out_path, dirs = args[0], args[1:]
     tot = defaultdict(float)
     disp = defaultdict(set)
@@ -61,6 +66,11 @@ def main():
         if "blind_rotate" in short and "fft4" not in short:
             n = pbs
             fma, add, mul = c.get("SQ_INSTS_VALU_FMA_F64"), c.get("SQ_INSTS_VALU_ADD_F64"), c.get("SQ_INSTS_VALU_MUL_F64")
+            if short in flop_per_pbs and fma is not None and add is not None and mul is not None:
+                # launch widths vary (round-aligned launch groups): the average width follows from the hardware's own flop
+                # count and the kernel's flop per PBS (fixed by its instruction stream: unchanged arithmetic)
+                n = (2 * fma + add + mul) * 64 / flop_per_pbs[short]
+                e["pbs_per_dispatch_from_flop_count"] = n
             if fma is not None and add is not None and mul is not None:
                 e["fp64_flop_per_pbs"] = (2 * fma + add + mul) * 64 / n          # wave instructions x 64 lanes
                 e["fp64_insts_per_pbs"] = (fma + add + mul) / n
@@ -80,6 +90,10 @@ def main():
                 e["clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8 / (e["avg_duration_ms"] * 1e6)
                 if "SQ_LDS_IDX_ACTIVE" in c:
                     e["lds_array_busy_frac"] = c["SQ_LDS_IDX_ACTIVE"] / 256 / (c["GRBM_GUI_ACTIVE"] / 8)
+            if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None:
+                e["l2_hit_frac"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+            if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") and c.get("TCP_TCC_READ_REQ_sum") is not None:
+                e["l1_hit_frac"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
             e["pbs_per_dispatch_assumed"] = n
         e["profile"] = "rocprofv3 --kernel-trace --pmc ... -- python3 bench.py --steps 3 --warmup 1 --cpu-pbs 0 " \
                        "--skip-single-op --skip-secondary --skip-extras --pipelines 1 (separate passes; tools/pmc_to_json.py)"

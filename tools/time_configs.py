@@ -3,21 +3,29 @@ import random, sys, time
 sys.path.insert(0, ".")
 from fhestring_amd.api import MyClientKey
 SEED = 0xF5E57121
-arith = 1 if (len(sys.argv) < 2 or sys.argv[1] == "fft") else 0
+arith = 0 if "exact" in sys.argv[1:] else 1
+BALANCE = "--balance" in sys.argv       # round-aligned launch groups inside one op (fhs_set_tick_balance)
 ck = MyClientKey(SEED)
 sk = ck.get_server_key(0, arith=arith)
 sk.set_mode(1)
+if BALANCE:
+    print("round alignment on, slots", sk.set_tick_balance())
 rnd = random.Random(SEED)
 R = lambda n: "".join(chr(rnd.randint(0x20, 0x7E)) for _ in range(n))
 
 
 def timed(name, fn, check):
-    sk.flush(); sk.stats(reset=True)
-    t0 = time.perf_counter(); out = fn(); sk.flush(); dt = time.perf_counter() - t0
-    st = sk.stats()
+    out = fn(); sk.flush()                                # warm-up, then the better of two
+    best = None
+    for _ in range(2):
+        sk.flush(); sk.stats(reset=True)
+        t0 = time.perf_counter(); out = fn(); sk.flush(); dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, sk.stats(), sk.level_widths())
+    dt, st, w = best
     ok = check(out)
-    print("%-34s %9.1f ms  %8d PBS  %4d levels  %8.0f PBS/s  %s" % (name, dt * 1e3, st["pbs_executed"], st["levels"],
-          st["pbs_executed"] / dt, "OK" if ok else "WRONG"))
+    print("%-34s %9.1f ms  %8d PBS  %4d levels  %8.0f PBS/s  %s  %s" % (name, dt * 1e3, st["pbs_executed"], st["levels"],
+          st["pbs_executed"] / dt, "OK" if ok else "WRONG", w[:14]))
 
 
 s = R(64); es = ck.encrypt(s, 1, None, sk); pat = s[20:24]
