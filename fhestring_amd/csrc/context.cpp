@@ -91,6 +91,7 @@ int Context::init(int device_id) {
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return fail(-2, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
     HIP_TRY(prepare_device_for_kernels(), "hipFuncSetAttribute (dynamic LDS)");
+    HIP_TRY(prepare_device_for_fft4(), "hipFuncSetAttribute (dynamic LDS, 4-wavefront kernel)");
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
     wg_slots = 4 * prop.multiProcessorCount;
     // two-bit f64 kernel: one round of resident workgroups per launch (its 73 MB key only stays inside the L2 window

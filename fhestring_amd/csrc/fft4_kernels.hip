@@ -73,14 +73,25 @@ template <bool INV> __device__ __forceinline__ void stagesA(cplx (&z)[8], tw_t w
     }
 }
 
-// one ciphertext on the 4 wavefronts of the calling workgroup
+// one ciphertext on the 4 wavefronts of the calling workgroup.
+// WIDE: four separate LDS areas per workgroup (accumulator staging | cross-half exchange | private transposes | published
+// transform; 4 x 34 816 B, one workgroup per CU) instead of one area reused for everything.  Half of the 8 workgroup
+// barriers per iteration only kept a reader ahead of the NEXT writer of a shared area; with an area of its own every
+// exchange is rewritten only after a later barrier that all its readers have passed, and 4 barriers remain (staged
+// accumulator visible, forward cross stage visible, transform published, inverse cross stage visible).  A lone
+// ciphertext waits at each of them for the slowest of its four wavefronts.
+template <bool WIDE>
 __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, char *smem, const int ct) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = w >> 1, h = w & 1;
-    cplx *mine = reinterpret_cast<cplx *>(smem + w * F4_WAVE_BYTES);
-    const cplx *pair = reinterpret_cast<const cplx *>(smem + (w ^ 1) * F4_WAVE_BYTES);     // other half, same polynomial
-    const cplx *other = reinterpret_cast<const cplx *>(smem + (w ^ 2) * F4_WAVE_BYTES);    // same half, other polynomial
+    constexpr int AREA = 4 * F4_WAVE_BYTES;
+    char *const xbase = smem + (WIDE ? AREA : 0), *const mbase = smem + (WIDE ? 2 * AREA : 0), *const pbase = smem + (WIDE ? 3 * AREA : 0);
+    cplx *mine = reinterpret_cast<cplx *>(mbase + w * F4_WAVE_BYTES);                      // private transposes
+    cplx *xmine = reinterpret_cast<cplx *>(xbase + w * F4_WAVE_BYTES);                     // cross-half exchange, own half
+    const cplx *pair = reinterpret_cast<const cplx *>(xbase + (w ^ 1) * F4_WAVE_BYTES);    // other half, same polynomial
+    cplx *pmine = reinterpret_cast<cplx *>(pbase + w * F4_WAVE_BYTES);                     // published transform
+    const cplx *other = reinterpret_cast<const cplx *>(pbase + (w ^ 2) * F4_WAVE_BYTES);   // same half, other polynomial
     uint64_t *stage = reinterpret_cast<uint64_t *>(smem + j * 2 * F4_WAVE_BYTES);          // 2048 words of polynomial j
 
     const uint64_t *ks = P.ks + (size_t)ct * SMALL_CT;
@@ -92,6 +103,13 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
     const tw_t w8[4] = {ld_tw(weff0, 8 + 4 * h), ld_tw(weff0, 9 + 4 * h), ld_tw(weff0, 10 + 4 * h), ld_tw(weff0, 11 + 4 * h)};
     const int eB = 8 * h + (lane >> 3);             // bits 9..6 of n in layout B'
     const int eC = 64 * h + lane;                   // bits 9..3 of n in layout C'
+    // per-lane twiddles, RESIDENT for the whole bootstrap (32 VGPRs): this kernel only runs narrow levels (at most two
+    // workgroups per CU, 256 registers per wave either way), where reloading them four times per iteration put four
+    // L1 / L2 round trips into the latency of a lone ciphertext
+    const tw_t t32 = ld_tw(weff0, 16 + eB), t16 = ld_tw(weff0, 32 + 2 * eB);
+    const tw_t t8a = ld_tw(weff0, 64 + 4 * eB), t8b = ld_tw(weff0, 64 + 4 * eB + 2);
+    const tw_t t4 = ld_tw(weff0, 128 + eC), t2 = ld_tw(weff0, 256 + 2 * eC);
+    const tw_t t1a = ld_tw(weff0, 512 + 4 * eC), t1b = ld_tw(weff0, 512 + 4 * eC + 2);
 
     // acc[r]: coefficient k(r) = 512 h + lane + 64 (r & 7) + 1024 (r >> 3) of polynomial j
     const uint32_t k0 = 512 * h + lane;
@@ -128,8 +146,6 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         if (a == 0) continue;
         const uint32_t s = a & (POLY_N - 1);
         const bool neg = a >= POLY_N;
-        gdptr_t weff = weff0;
-        asm volatile("" : "+s"(weff));               // keep the per-lane twiddle loads inside the iteration
 
         // ---- rotate, subtract, decompose: z[r] = digit(k(r)) + i digit(k(r) + 1024) -------------------------------
         __syncthreads();                              // staged accumulator of both halves visible
@@ -158,7 +174,7 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
             if (r < 8) z[r].r = (double)dig; else z[r - 8].i = (double)dig;
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                              // all rotated reads done before the area is reused
+        if (!WIDE) __syncthreads();                   // all rotated reads done before the area is reused
 
         // key rows of this iteration: own transform first (row j), then the partner polynomial's (row 1-j), column j;
         // point n = 8 (64 h + lane) + c sits at [c16 = 8 (lane & 1) + c][L = 32 h + (lane >> 1)] of the key layout
@@ -175,7 +191,7 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         __builtin_amdgcn_s_setprio(1);
         {   // stage t = 512 across the two halves: (a, b) = (lower, upper) point, this half keeps its own output
 #pragma unroll
-            for (int r = 0; r < 8; r++) mine[pslot(lane + 64 * r)] = z[r];
+            for (int r = 0; r < 8; r++) xmine[pslot(lane + 64 * r)] = z[r];
             __syncthreads();
             // all 8 partner points requested first, ONE wave-uniform branch around the butterflies (a branch and a
             // serialized LDS round trip per point before)
@@ -189,7 +205,7 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
 #pragma unroll
                 for (int r = 0; r < 8; r++) bf_fwd<false>(o[r], z[r], w1.r, w1.i);
             }
-            __syncthreads();                          // the partner has read this half's points
+            if (!WIDE) __syncthreads();               // the partner has read this half's points
         }
         stagesA<false>(z, w2, w4, w8);
 #pragma unroll
@@ -202,8 +218,6 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         }
         __builtin_amdgcn_wave_barrier();
         {
-            const tw_t t32 = ld_tw(weff, 16 + eB), t16 = ld_tw(weff, 32 + 2 * eB);
-            const tw_t t8a = ld_tw(weff, 64 + 4 * eB), t8b = ld_tw(weff, 64 + 4 * eB + 2);
             stage8<false, 4>(z, t32, t32);
             stage8<false, 2>(z, t16, t16);
             stage8<false, 1>(z, t8a, t8b);
@@ -221,8 +235,6 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         }
         __builtin_amdgcn_wave_barrier();
         {
-            const tw_t t4 = ld_tw(weff, 128 + eC), t2 = ld_tw(weff, 256 + 2 * eC);
-            const tw_t t1a = ld_tw(weff, 512 + 4 * eC), t1b = ld_tw(weff, 512 + 4 * eC + 2);
             stage8<false, 4>(z, t4, t4);
             stage8<false, 2>(z, t2, t2);
             stage8<false, 1>(z, t1a, t1b);
@@ -230,7 +242,7 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
 
         // ---- publish, pointwise multiply-accumulate with GGSW_i -------------------------------------------------
 #pragma unroll
-        for (int c = 0; c < 8; c++) mine[c * 64 + lane] = z[c];
+        for (int c = 0; c < 8; c++) pmine[c * 64 + lane] = z[c];
         __syncthreads();
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
@@ -245,13 +257,11 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
             z[c].r = rr; z[c].i = ii;
             if (c + HB < 8) { bo[k] = b_own[(c + HB) * 64]; bp[k] = b_par[(c + HB) * 64]; }
         }
-        __syncthreads();                              // the other polynomial has read this wave's transform
+        if (!WIDE) __syncthreads();                   // the other polynomial has read this wave's transform
         __builtin_amdgcn_s_setprio(0);
 
         // ---- inverse transform -------------------------------------------------------------------------------
         {
-            const tw_t t4 = ld_tw(weff, 128 + eC), t2 = ld_tw(weff, 256 + 2 * eC);
-            const tw_t t1a = ld_tw(weff, 512 + 4 * eC), t1b = ld_tw(weff, 512 + 4 * eC + 2);
             stage8<true, 1>(z, t1a, t1b);
             stage8<true, 2>(z, t2, t2);
             stage8<true, 4>(z, t4, t4);
@@ -269,8 +279,6 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         }
         __builtin_amdgcn_wave_barrier();
         {
-            const tw_t t32 = ld_tw(weff, 16 + eB), t16 = ld_tw(weff, 32 + 2 * eB);
-            const tw_t t8a = ld_tw(weff, 64 + 4 * eB), t8b = ld_tw(weff, 64 + 4 * eB + 2);
             stage8<true, 1>(z, t8a, t8b);
             stage8<true, 2>(z, t16, t16);
             stage8<true, 4>(z, t32, t32);
@@ -287,7 +295,7 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         stagesA<true>(z, w2, w4, w8);
         {   // stage t = 512 across the two halves
 #pragma unroll
-            for (int r = 0; r < 8; r++) mine[pslot(lane + 64 * r)] = z[r];
+            for (int r = 0; r < 8; r++) xmine[pslot(lane + 64 * r)] = z[r];
             __syncthreads();
             cplx o[8];
 #pragma unroll
@@ -299,7 +307,7 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
 #pragma unroll
                 for (int r = 0; r < 8; r++) bf_inv<false>(o[r], z[r], w1.r, w1.i);
             }
-            __syncthreads();                          // the partner has read this half's points
+            if (!WIDE) __syncthreads();               // the partner has read this half's points
         }
 
         // ---- back to the torus, update and restage the accumulator -------------------------------------------
@@ -331,12 +339,27 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
 // used for batches <= 512 (at most 2 workgroups per CU): aim for 2 waves per SIMD and spend registers on latency
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blind_rotate_fft4_kernel(BlindRotateFftParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    fft4_bootstrap(P, smem, blockIdx.x);
+    fft4_bootstrap<false>(P, smem, blockIdx.x);
+}
+// batches of at most one ciphertext per CU: four LDS areas (136 KB per workgroup), 4 instead of 8 barriers per iteration
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void blind_rotate_fft4_wide_kernel(BlindRotateFftParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    fft4_bootstrap<true>(P, smem, blockIdx.x);
+}
+
+// more than 64 KB of dynamic LDS is a per-DEVICE opt-in (like the exact kernel's, pbs_kernels.hip): Context::init calls
+// this with the device current
+hipError_t prepare_device_for_fft4() {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(blind_rotate_fft4_wide_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 16 * F4_WAVE_BYTES);
 }
 
 hipError_t launch_blind_rotate_fft4(const BlindRotateFftParams &p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(blind_rotate_fft4_kernel, dim3(p.B), dim3(256), 4 * F4_WAVE_BYTES, s, p);
+    if (p.B * 4 <= p.slots)        // slots = 4 per CU: at most one of these workgroups per CU
+        hipLaunchKernelGGL(blind_rotate_fft4_wide_kernel, dim3(p.B), dim3(256), 16 * F4_WAVE_BYTES, s, p);
+    else
+        hipLaunchKernelGGL(blind_rotate_fft4_kernel, dim3(p.B), dim3(256), 4 * F4_WAVE_BYTES, s, p);
     return hipGetLastError();
 }
 

@@ -120,6 +120,11 @@ def test_fft_kernels_agree_on_a_wide_batch(fft_ctx, oracle_keys):
     b = fft_ctx.pbs_batch(cts, idx, luts)
     fft_ctx.set_fft4_max_batch(512)
     assert np.array_equal(a, b)
+    # the routes the engine takes by itself for narrow levels: one workgroup per CU or less -> the wide-LDS variant of the
+    # 4-wavefront kernel (4 barriers per iteration), 257..512 rows -> the shared-area variant (8 barriers)
+    for B in (256, 300, 512):
+        got = fft_ctx.pbs_batch(cts[:B], idx[:B], luts)
+        assert np.array_equal(got, a[:B]), B
 
 
 def test_fft_noise_close_to_exact(fft_ctx, oracle_keys, oracle_sk):

@@ -110,7 +110,9 @@ def test_configs_with_round_aligned_launch_groups():
         widths = sk.level_widths()
         assert (ck.decrypt_char(r1), ck.decrypt_char(r2), ck.decrypt_char(r3)) == (0, int(a <= b), int(b <= a))
         wide = [w for w in widths if w >= slots]
-        assert len(wide) >= 5 and sum(w % slots == 0 for w in wide) >= len(wide) - 2, widths
+        # three ops in one flush: where late rows of one op's level join another's the group is not a multiple, but
+        # most launch groups at least one round wide are whole rounds (none is without the alignment, except by chance)
+        assert len(wide) >= 5 and 3 * sum(w % slots == 0 for w in wide) >= 2 * len(wide), widths
         s = list(_rand(rnd, 1024).replace("~", "-"))
         for k in range(8):
             s[20 + 120 * k:25 + 120 * k] = "~from"
