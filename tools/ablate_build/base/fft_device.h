@@ -47,6 +47,24 @@ template <bool ROT> __device__ __forceinline__ void bf_inv(cplx &a, cplx &b, dou
     else { b.r = q.i; b.i = -q.r; }
 }
 
+// high word of (flip ? -v : v) - a (64-bit wrapping), flip given as a lane mask: the carry chains run through VCC
+// back to back (the compiler's own sequence carries through SGPR pairs and pays a wait state after each borrow)
+__device__ __forceinline__ uint32_t rot_sub_hi(uint64_t v, uint64_t a, uint64_t flipmask) {
+    const uint32_t vl = (uint32_t)v, vh = (uint32_t)(v >> 32), al = (uint32_t)a, ah = (uint32_t)(a >> 32);
+    uint32_t tl, th;
+    asm("v_sub_co_u32 %0, vcc, 0, %2\n\t"
+        "v_subb_co_u32 %1, vcc, 0, %3, vcc\n\t"
+        "v_cndmask_b32 %0, %2, %0, %6\n\t"
+        "v_cndmask_b32 %1, %3, %1, %6\n\t"
+        "v_sub_co_u32 %0, vcc, %0, %4\n\t"
+        "v_subb_co_u32 %1, vcc, %1, %5, vcc"
+        : "=&v"(tl), "=&v"(th)
+        : "v"(vl), "v"(vh), "v"(al), "v"(ah), "s"(flipmask)
+        : "vcc");
+    (void)tl;
+    return th;
+}
+
 // Torus value (mod 2^64) of t * 2^64, where t is the inverse transform's output: the Fourier-domain key carries
 // the factor 2^-64 (beside 1/1024), so the accumulator increment is the fractional part of t.  fract is exact;
 // 1 + f puts that fraction into the 52 mantissa bits of a double in [1, 2] (one rounding at 2^-52, i.e. 2^12 torus

@@ -28,24 +28,6 @@ namespace fhs {
 namespace {
 using namespace fftdev;
 
-// high word of (flip ? -v : v) - a (64-bit wrapping), flip given as a lane mask: the carry chains run through VCC
-// back to back (the compiler's own sequence carries through SGPR pairs and pays a wait state after each borrow)
-__device__ __forceinline__ uint32_t rot_sub_hi(uint64_t v, uint64_t a, uint64_t flipmask) {
-    const uint32_t vl = (uint32_t)v, vh = (uint32_t)(v >> 32), al = (uint32_t)a, ah = (uint32_t)(a >> 32);
-    uint32_t tl, th;
-    asm("v_sub_co_u32 %0, vcc, 0, %2\n\t"
-        "v_subb_co_u32 %1, vcc, 0, %3, vcc\n\t"
-        "v_cndmask_b32 %0, %2, %0, %6\n\t"
-        "v_cndmask_b32 %1, %3, %1, %6\n\t"
-        "v_sub_co_u32 %0, vcc, %0, %4\n\t"
-        "v_subb_co_u32 %1, vcc, %1, %5, vcc"
-        : "=&v"(tl), "=&v"(th)
-        : "v"(vl), "v"(vh), "v"(al), "v"(ah), "s"(flipmask)
-        : "vcc");
-    (void)tl;
-    return th;
-}
-
 }  // namespace
 
 __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFftParams P) {
@@ -97,6 +79,7 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
     // read at the top of its own iteration it cost one exposed global-memory round trip per iteration
     uint64_t ks_next = ks[0];
     for (int i = 0; i < LWE_N; i++) {
+        asm volatile("" : "+v"(ks_next));             // opaque until here: nothing of the next iteration is computed early
         const uint32_t a = __builtin_amdgcn_readfirstlane(fft_mod_switch(ks_next));
         __builtin_amdgcn_sched_barrier(0);            // use the value requested an iteration ago BEFORE the next request
         ks_next = ks[i + 1];

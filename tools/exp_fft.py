@@ -93,6 +93,21 @@ def merge(*vs):
 # inv6 with the untwist factors as constants (no table loads): isolates the effect of the lower FP64 count
 INV6C = {D: INV6[D], T: INV6[T], K: [(INV6[K][0][0], INV6[K][0][1].replace("kb[k] = utab[k * 64];", "kb[k] = double2_t{1.0 + k, 0.5};").replace("if (r < 8) kb[r] = utab[(r + 8) * 64];", ""))]}
 
+P1, P2, P0 = "__builtin_amdgcn_s_setprio(1);", "__builtin_amdgcn_s_setprio(2);", "__builtin_amdgcn_s_setprio(0);"
+TUNE = {
+    "rw4": {K: [("constexpr int RW = 8;", "constexpr int RW = 4;")]},
+    "rw12": {K: [("constexpr int RW = 8;", "constexpr int RW = 12;")]},
+    "pw2": {K: [("constexpr int PW = 4;", "constexpr int PW = 2;")]},
+    "pw8": {K: [("constexpr int PW = 4;", "constexpr int PW = 8;")]},
+    "prio_1_3_0": {K: [(P2, "__builtin_amdgcn_s_setprio(3);")]},
+    "prio_2_3_1": {K: [(P0, "__builtin_amdgcn_s_setprio(9);"), (P2, "__builtin_amdgcn_s_setprio(3);"), (P1, P2), ("__builtin_amdgcn_s_setprio(9);", P1)]},
+    "prio_0_1_0": {K: [(P1, P0), (P2, P1)]},
+    "noprio": {K: [(P1, ""), (P2, ""), (P0, "")]},
+    "sched_default": {},
+    "sched_memclause": {},
+}
+FLAGS = {"sched_default": [], "sched_memclause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]}
+
 VARIANTS = {
     "base": {},
     "inv6c": INV6C,
@@ -103,6 +118,7 @@ VARIANTS = {
     "inv6_acc52": merge(INV6, ACC52),
     "all3": merge(ONE_BARRIER, INV6, ACC52),
 }
+VARIANTS.update(TUNE)
 
 
 def build(names):
@@ -119,7 +135,7 @@ def build(names):
         obj = os.path.join(d, "fft_kernels.o")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", d, "-I", SRC,
                                "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(d, "fft_kernels.hip"), "-o", obj,
-                               "-mllvm", "-amdgpu-sched-strategy=max-ilp"], stderr=open(os.path.join(d, "resources.txt"), "w"))
+                               ] + FLAGS.get(name, ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]), stderr=open(os.path.join(d, "resources.txt"), "w"))
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
                                os.path.join(d, "libfhs.so"), obj] + objs + ["-lpthread", "-ldl"])
         os.remove(obj)
