@@ -31,7 +31,7 @@ def _check_roofline(r):
 
 
 def test_bench_json_line_contract():
-    d = _run("--cpu-pbs", "32", "--repeats", "5")
+    d = _run("--cpu-pbs", "64", "--repeats", "5")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -61,6 +61,24 @@ def test_bench_json_line_contract():
     for k in ("cfg3_find_encrypted_256", "cfg4_replace_1024", "cfg5_eq_ignore_case_4096", "cfg5_le_4096"):
         assert d["configs"][k]["ms_per_op"] > 0 and d["configs"][k]["pbs"] > 1000
         assert 0 < d["configs"][k]["ms_per_op_multi_bit"] < d["configs"][k]["ms_per_op"]     # two-bit f64 arithmetic
+    # round 3: both roofline figures labelled, cache hit rates, host timers split, config 2's other
+    # cases, config 4 at smaller n, as-written DAG shapes, the vectorised CPU port with extrapolations
+    r = d["roofline"]
+    assert r["survey_8d_frac"] > 1.0 > r["frac"] and "contract definition" in r["survey_8d_frac_note"]
+    assert 0.5 < r["counters"]["l2_hit_frac"] <= 1.0 and 0.3 < r["counters"]["l1_hit_frac"] <= 1.0
+    ht = d["single_op"]["host_timers"]
+    assert all(ht[k] >= 0 for k in ("encrypt_ms", "upload_ms", "op_ms", "download_ms", "decrypt_ms"))
+    assert ht["op_ms"] > ht["download_ms"] and abs(ht["op_ms"] - d["single_op_latency_ms"]) < 0.5 * d["single_op_latency_ms"]
+    v = d["single_op"]["cfg2_variants"]
+    assert v["m8_hit"]["found"] == 1 and v["m4_miss"]["found"] == 0 and v["m8_hit"]["pbs"] > v["m4_miss"]["pbs"]
+    sc = d["cfg4_replace_scaling"]
+    assert sc["128"]["pbs"] < sc["256"]["pbs"] < sc["512"]["pbs"] < d["configs"]["cfg4_replace_1024"]["pbs"]
+    aw = d["as_written_dag_shapes"]
+    assert aw["cfg3_find_encrypted_256"]["levels"] > 100 and aw["cfg5_le_4096"]["levels"] > 10_000
+    assert aw["cfg4_replace_256"]["pbs"] > 3.5 * aw["cfg4_replace_128"]["pbs"]              # the n^2 law of the bubble
+    assert c["variants_pbs_per_s"]["f64_fft_avx2_fma"] > 1.5 * c["variants_pbs_per_s"]["f64_fft_scalar_textbook"]
+    ex = c["extrapolated"]
+    assert ex["cfg4_replace_1024"]["as_written_dag_s"] > 100 * ex["cfg4_replace_1024"]["fused_dag_s"]
 
 
 @pytest.mark.parametrize("op", ["find_enc", "eq_ignore_case"])
@@ -88,3 +106,5 @@ def test_bench_two_ranks_on_one_gpu(extra):
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 1000 and "GPU(s)" in d["config"]["parallelism"]
+    ex = d["config"]["exchange"]                            # fhs_dist_stats over the timed region (host transport here)
+    assert ex["transport"] == "host" and ex["allgather_calls_per_step"] > 0 and ex["bytes_sent_per_rank_per_step"] > 0
