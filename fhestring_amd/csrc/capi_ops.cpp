@@ -13,6 +13,9 @@ FChar load(Engine &e, fhs_char_t h) {
     for (int i = 0; i < 4; i++) {
         e.retain(b[i]);
         c.b[i] = Ref(&e, b[i]);
+        // results handed back as sums of bootstrap outputs (find's index digits: up to 57 variances) are refreshed when
+        // they come back in as operands; verdict-like sums (<= 4) pass, every operator budgets for those
+        if (e.sum_c2(b[i]) > 4) c.b[i] = pbs(c.b[i], LUT_MSG);
     }
     return c;
 }

@@ -830,6 +830,48 @@ Ref Strings::or_tree(std::vector<Ref> f) {
     return cur[0];
 }
 
+// OR of flags of which AT MOST ONE is set.  Their sum never exceeds 1, so it is the noise budget, not the 4-bit message
+// space, that limits a group: up to FHS_NOISE_BUDGET_SUM_C2 fresh flags per refreshing bootstrap instead of 15, and the
+// last few partial sums (sum c^2 <= 4) are handed back as a linear combination without a bootstrap of their own.
+// 4097 flags: 65 + 2 bootstraps in 2 levels instead of 274 + 19 + 2 + 1 in 4 (the verdict of a 4096-character `le`).
+Ref Strings::onehot_or(std::vector<Ref> f) {
+    std::vector<Ref> cur;
+    for (Ref &x : f) {
+        if (e_->is_triv(x.id())) {
+            if (e_->triv_val(x.id()) & 1) return trivial_block(e_, 1);
+        } else cur.push_back(x);
+    }
+    if (cur.empty()) return trivial_block(e_, 0);
+    for (;;) {
+        if (cur.size() == 1) return cur[0];
+        int64_t total = 0;
+        for (const Ref &x : cur) total += e_->sum_c2(x.id());
+        if (total <= 4) {
+            Term tt[4];
+            for (size_t i = 0; i < cur.size(); i++) tt[i] = {1, cur[i].id()};
+            return Ref(e_, e_->lin(tt, cur.size(), 0));
+        }
+        std::vector<Ref> nxt;
+        Term tt[FHS_NOISE_BUDGET_SUM_C2];
+        size_t m = 0;
+        int64_t c2 = 0;
+        auto close = [&] {
+            if (m == 1) nxt.push_back(Ref(e_, (e_->retain(tt[0].blk), tt[0].blk)));
+            else if (m > 1) nxt.push_back(pbs(Ref(e_, e_->lin(tt, m, 0)), LUT_NZ));
+            m = 0;
+            c2 = 0;
+        };
+        for (const Ref &x : cur) {
+            const int64_t w = std::max<int64_t>(1, e_->sum_c2(x.id()));
+            if (c2 + w > FHS_NOISE_BUDGET_SUM_C2 || m == (size_t)FHS_NOISE_BUDGET_SUM_C2) close();
+            tt[m++] = {1, x.id()};
+            c2 += w;
+        }
+        close();
+        cur.swap(nxt);
+    }
+}
+
 FChar Strings::flags_or(const FStr &flags) {
     std::vector<Ref> f;
     for (const FChar &c : flags) f.push_back(c.b[0]);
@@ -885,20 +927,29 @@ std::vector<Ref> Strings::prefix_or(const std::vector<Ref> &f) {
     std::vector<Ref> p(n);
     if (n == 0) return p;
     const size_t nchunks = (n + 14) / 15;
-    std::vector<Ref> q;                      // exclusive prefix OR over whole chunks
+    std::vector<Ref> q, any;                 // q: exclusive prefix OR over whole chunks, any: the chunks' totals
     if (nchunks > 1) {
-        std::vector<Ref> any(nchunks - 1);   // the last chunk's total is never needed
+        any.resize(nchunks - 1);             // the last chunk's total is never needed
         for (size_t j = 0; j + 1 < nchunks; j++) any[j] = pbs(sum_refs(e_, &f[15 * j], 15), LUT_NZ);
         any.push_back(trivial_block(e_, 0));
         q = prefix_or(any);
     } else {
         q.push_back(trivial_block(e_, 0));
     }
+    auto depth = [&](const Ref &r) { return e_->node(r.id()).level; };
     for (size_t i = 0; i < n; i++) {
         const size_t j = i / 15, k = i % 15;
         Term tt[16];
         size_t m = 0;
         for (size_t u = 0; u < k; u++) tt[m++] = {1, f[15 * j + u].id()};
+        // the 16th chunk's prefix is the OR of 16 totals, one level deeper than its neighbours': the previous chunk's
+        // prefix and total say the same one level earlier (find on 256 characters ends one launch sooner)
+        if (j >= 1 && k >= 1 && k <= 13 && depth(q[j]) > std::max(depth(q[j - 1]), depth(any[j - 1]))) {
+            tt[m++] = {1, q[j - 1].id()};
+            tt[m++] = {1, any[j - 1].id()};
+            p[i] = pbs(Ref(e_, e_->lin(tt, m, 0)), LUT_NZ);
+            continue;
+        }
         tt[m++] = {1, q[j].id()};
         const bool q0 = e_->is_triv(q[j].id()) && e_->triv_val(q[j].id()) == 0;
         if (k == 0) { p[i] = q[j]; continue; }               // nothing of this chunk yet: the flag itself, no bootstrap
@@ -975,8 +1026,11 @@ FChar Strings::first_index(const std::vector<Ref> &before, const Ref &found) {
             blocks.swap(nxt);
         }
         Ref digit = blocks.empty() ? trivial_block(e_, 0) : (blocks.size() == 1 ? blocks[0] : sum_refs(e_, blocks.data(), blocks.size()));
-        digit = lin(e_, {{1, &digit}, {3, &nf}});            // 255 = 3,3,3,3 when absent
-        r.b[d] = pbs(digit, LUT_MSG);
+        // 255 = 3,3,3,3 when absent.  The digit is a sum of at most 48 + 9 bootstrap-output variances, inside the budget of
+        // one more bootstrap, and its value never leaves 0..3 (found: nf = 0; absent: every block is 0): it is handed back
+        // as it is -- like a comparison's verdict -- instead of paying one more dependency level for a refresh; consumers
+        // that weigh their operands refresh them by the engine's bookkeeping.
+        r.b[d] = lin(e_, {{1, &digit}, {3, &nf}});
     }
     return r;
 }
@@ -1071,7 +1125,7 @@ FChar Strings::f_comparison(const FStr &a_in, const FStr &b_in, int cmp) {
     std::vector<Ref> before = prefix_or(differs);
     std::vector<Ref> pick(min_len);
     for (size_t i = 0; i < min_len; i++) pick[i] = pbs(lin(e_, {{2, &x[i]}, {1, &before[i]}}), LUT_IS2);
-    Ref ret = or_tree(pick);                                 // at most one pick is set
+    Ref ret = onehot_or(pick);                               // at most one pick is set
     Ref any_diff = or_tree(differs);
     // :1520-1538 compares len(a) with len(b) (numbers of non-zero characters) when nothing differs.  With every common
     // position equal the two counts differ exactly by the non-zero characters in the tail of the longer buffer, so the
@@ -1124,7 +1178,7 @@ void Strings::f_cmp_partial(const FStr &a, const FStr &b, int cmp, FChar *any_di
     std::vector<Ref> before = prefix_or(differs);
     std::vector<Ref> pick(n);
     for (size_t i = 0; i < n; i++) pick[i] = pbs(lin(e_, {{2, &x[i]}, {1, &before[i]}}), LUT_IS2);
-    *verdict_out = ch_flag(e_, or_tree(pick));               // at most one pick is set
+    *verdict_out = ch_flag(e_, onehot_or(pick));             // at most one pick is set
     *any_diff_out = ch_flag(e_, or_tree(differs));
 }
 
@@ -1137,7 +1191,7 @@ FChar Strings::flags_first_decides(const FStr &any_diff, const FStr &verdict, in
     for (size_t r = 0; r < n; r++) d[r] = any_diff[r].b[0];
     std::vector<Ref> before = prefix_or(d);                  // exclusive: some earlier range differs
     for (size_t r = 0; r < n; r++) pick[r] = pbs(lin(e_, {{2, &verdict[r].b[0]}, {1, &before[r]}}), LUT_IS2);
-    Ref ret = or_tree(pick);                                 // at most one pick is set
+    Ref ret = onehot_or(pick);                               // at most one pick is set
     if (tie) {                                               // ret = 1 implies a difference: the sum stays in {0, 1}
         Ref one = trivial_block(e_, 1), any = or_tree(d);
         ret = lin(e_, {{1, &ret}, {1, &one}, {-1, &any}});

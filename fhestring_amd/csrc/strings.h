@@ -84,6 +84,7 @@ class Strings {
     // fused-mode helpers on single-block flags
     Ref and_tree(std::vector<Ref> flags);
     Ref or_tree(std::vector<Ref> flags);
+    Ref onehot_or(std::vector<Ref> flags);   // OR of flags of which at most one is set: noise-budget-wide groups
     std::vector<Ref> block_eq_flags(const FChar &a, const FChar &b);
     Ref window_match(const FStr &s, size_t at, const FStr &pat);
     FChar count_flags(std::vector<Ref> flags);   // sum of 0/1 flags mod 256 as a 4-block char
