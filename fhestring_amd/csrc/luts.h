@@ -35,6 +35,8 @@ enum LutId : uint16_t {
     LUT_EQIC_OK,       // v = LO + 4 a2: the row bit (bit 4) picks which of the two range flags counts
     LUT_EQIC_C1,       // v = B2 + 3 B3: 1 equal high nibbles, 2 case bit differs on a letter row, 0 unequal
     LUT_EQIC_FIN,      // v = C1 + 3 OK + 6 E_lo: low nibbles equal and (C1 == 1 or (C1 == 2 and OK))
+    // root of the three-state comparison tree (Strings::cmp_verdict): v = 8 + 4 s1 + 2 s2 + s3, s in {-1, 0, 1}
+    LUT_LT8, LUT_LE8, LUT_GT8, LUT_GE8,
     LUT_COUNT
 };
 
@@ -83,6 +85,10 @@ inline int lut_function(int id, int v) {
             const int c1 = v % 3, ok = (v / 3) & 1, e = v / 6;
             return v < 12 && e == 1 && (c1 == 1 || (c1 == 2 && ok));
         }
+        case LUT_LT8: return v < 8;
+        case LUT_LE8: return v <= 8;
+        case LUT_GT8: return v > 8;
+        case LUT_GE8: return v >= 8;
         default: break;
     }
     if (id >= LUT_GREEDY_NEXT0 && id <= LUT_GREEDY_NEXT7)

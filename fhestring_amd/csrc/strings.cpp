@@ -1079,85 +1079,59 @@ FChar Strings::find_first_decides(const std::vector<Ref> &found, const std::vect
     return r;
 }
 
-// comparison (mod.rs:1470-1541) re-associated.  The reference's 4-op state machine per character
-// (:1504-1513) selects the comparison result at the FIRST differing position; there `le` equals `lt`
-// and `ge` equals `gt`, so: pick_i = X_i & !prefix_or(differs)_i with X = lt (lt, le) or gt (gt, ge),
-// ret = OR pick_i.  When no position differs (the reference's 255 sentinel, :1483,1518) the result is
-// the length-based comparison (:1520-1538).
-// One character pair of a comparison: the two sign bootstraps of blk_cmp_flag (nibble differences through the padding
-// bit: lt / eq / gt per nibble) already say whether the characters are equal, so the equality flag is a second look-up
-// on the same packed pair (4 s_hi + s_lo == 5) instead of two nibble tests and an AND: 4 bootstraps per pair, not 6.
-void Strings::cmp_pair(const FChar &a_in, const FChar &b_in, int cmp_lut, Ref *eq, Ref *x) {
-    FChar a = a_in, b = b_in;
-    Ref s[2];
-    for (int p = 0; p < 2; p++) {
-        Ref *blk[4] = {&a.b[2 * p], &a.b[2 * p + 1], &b.b[2 * p], &b.b[2 * p + 1]};
-        Ref d = lin(e_, {{1, blk[0]}, {4, blk[1]}, {-1, blk[2]}, {-4, blk[3]}});
-        if (e_->sum_c2(d.id()) > FHS_NOISE_BUDGET_SUM_C2) {  // operands that are sums of bootstrap outputs: refresh
-            for (int k = 0; k < 4; k++)
-                if (e_->sum_c2(blk[k]->id()) > 1) *blk[k] = pbs(*blk[k], LUT_MSG);
-            d = lin(e_, {{1, blk[0]}, {4, blk[1]}, {-1, blk[2]}, {-4, blk[3]}});
+// Lexicographic comparison (mod.rs:1470-1541) as a tree of three-state values.  A leaf is the sign of one nibble
+// difference (a0 + 4 a1 - b0 - 4 b1 in [-15, 15] through the padding bit: -1 / 0 / 1), most significant first: position 0
+// before position 1, the high nibble before the low one, a character one buffer does not have counts as NUL.  Three
+// states reduce to one with sign(4 s1 + 2 s2 + s3) -- the first non-zero state decides, sum c^2 = 21 -- so the order of
+// 2 n nibbles is known after 1 + log3(2 n) levels and ~3 n bootstraps.  (Rounds 1-2: per pair two signs, `lt` and `==`
+// look-ups, a prefix OR over the `differs` flags, one pick per position and an OR over the picks: ~6 n bootstraps.)
+// The reference decides by len(a) vs len(b) (numbers of non-zero characters) when no common position differs; with every
+// common position equal those differ exactly by the non-zero characters in the longer buffer's tail, which is what the
+// tail leaves (tail character against NUL) say.
+std::vector<Ref> Strings::cmp_leaves(const FStr &a, const FStr &b) {
+    const size_t n = std::max(a.size(), b.size());
+    std::vector<Ref> st;
+    st.reserve(2 * n);
+    for (size_t i = 0; i < n; i++) {
+        FChar ca = i < a.size() ? a[i] : t(0), cb = i < b.size() ? b[i] : t(0);
+        for (int p = 1; p >= 0; p--) {
+            Ref *blk[4] = {&ca.b[2 * p], &ca.b[2 * p + 1], &cb.b[2 * p], &cb.b[2 * p + 1]};
+            Ref d = lin(e_, {{1, blk[0]}, {4, blk[1]}, {-1, blk[2]}, {-4, blk[3]}});
+            if (e_->sum_c2(d.id()) > FHS_NOISE_BUDGET_SUM_C2) {  // operands that are sums of bootstrap outputs: refresh
+                for (int k = 0; k < 4; k++)
+                    if (e_->sum_c2(blk[k]->id()) > 1) *blk[k] = pbs(*blk[k], LUT_MSG);
+                d = lin(e_, {{1, blk[0]}, {4, blk[1]}, {-1, blk[2]}, {-4, blk[3]}});
+            }
+            st.push_back(pbs(d, LUT_SIGN));
         }
-        Ref sg = pbs(d, LUT_SIGN);
-        s[p] = lin(e_, {{1, &sg}}, 1);                       // {0: lt, 1: eq, 2: gt}
     }
-    Ref v = lin(e_, {{4, &s[1]}, {1, &s[0]}});
-    *x = pbs(v, cmp_lut);
-    *eq = pbs(v, lut_is_k(5));
+    return st;
 }
 
-FChar Strings::f_comparison(const FStr &a_in, const FStr &b_in, int cmp) {
-    FStr a = a_in, b = b_in;
-    size_t min_len = std::min(a.size(), b.size());
-    if (min_len == 0) {                                      // :1490-1494
-        a.push_back(t(0));
-        b.push_back(t(0));
-        min_len = 1;
-    }
-    Ref one = trivial_block(e_, 1);
-    std::vector<Ref> differs(min_len), x(min_len);
-    const int xl = (cmp == 0 || cmp == 1) ? LUT_CMP_LT : LUT_CMP_GT;
-    for (size_t i = 0; i < min_len; i++) {
-        Ref eq;
-        cmp_pair(a[i], b[i], xl, &eq, &x[i]);
-        differs[i] = lin(e_, {{1, &one}, {-1, &eq}});
-    }
-    std::vector<Ref> before = prefix_or(differs);
-    std::vector<Ref> pick(min_len);
-    for (size_t i = 0; i < min_len; i++) pick[i] = pbs(lin(e_, {{2, &x[i]}, {1, &before[i]}}), LUT_IS2);
-    Ref ret = onehot_or(pick);                               // at most one pick is set
-    Ref any_diff = or_tree(differs);
-    // :1520-1538 compares len(a) with len(b) (numbers of non-zero characters) when nothing differs.  With every common
-    // position equal the two counts differ exactly by the non-zero characters in the tail of the longer buffer, so the
-    // verdict is a constant for equally long buffers and one OR over that tail otherwise -- instead of two 8-bit
-    // popcounts and their carry chains.
-    const bool a_longer = a.size() > b.size(), b_longer = b.size() > a.size();
-    int by_const = -1;                                       // 0 / 1: by_len is a constant
-    Ref by_len;
-    if (!a_longer && !b_longer) by_const = (cmp == 1 || cmp == 3) ? 1 : 0;     // equal lengths: le, ge hold
-    else {
-        const FStr &longer = a_longer ? a : b;
-        std::vector<Ref> nz;
-        for (size_t i = min_len; i < longer.size(); i++) {
-            nz.push_back(pbs(lin(e_, {{1, &longer[i].b[0]}, {4, &longer[i].b[1]}}), LUT_NZ));
-            nz.push_back(pbs(lin(e_, {{1, &longer[i].b[2]}, {4, &longer[i].b[3]}}), LUT_NZ));
+Ref Strings::cmp_root_sum(std::vector<Ref> st) {
+    while (st.size() > 3) {
+        std::vector<Ref> nx;
+        nx.reserve(st.size() / 3 + 1);
+        for (size_t i = 0; i < st.size(); i += 3) {
+            const size_t k = std::min<size_t>(3, st.size() - i);
+            if (k == 1) nx.push_back(st[i]);
+            else if (k == 2) nx.push_back(pbs(lin(e_, {{2, &st[i]}, {1, &st[i + 1]}}), LUT_SIGN));
+            else nx.push_back(pbs(lin(e_, {{4, &st[i]}, {2, &st[i + 1]}, {1, &st[i + 2]}}), LUT_SIGN));
         }
-        Ref tail = or_tree(nz);                              // the longer buffer really holds the longer string
-        Ref no_tail = lin(e_, {{1, &one}, {-1, &tail}});
-        if (b_longer) {                                      // len(a) <= len(b)
-            if (cmp == 0) by_len = tail; else if (cmp == 3) by_len = no_tail; else by_const = cmp == 1 ? 1 : 0;
-        } else {                                             // len(a) >= len(b)
-            if (cmp == 2) by_len = tail; else if (cmp == 1) by_len = no_tail; else by_const = cmp == 3 ? 1 : 0;
-        }
+        st.swap(nx);
     }
-    // result = any_diff ? ret : by_len; ret is 0 whenever nothing differs
-    if (by_const == 0) return ch_flag(e_, ret);
-    Ref sel = by_const == 1 ? lin(e_, {{1, &one}, {-1, &any_diff}})
-                            : pbs(lin(e_, {{2, &by_len}, {1, &any_diff}}), LUT_IS2);   // by_len & !any_diff
-    return ch_flag(e_, lin(e_, {{1, &sel}, {1, &ret}}));
+    if (st.size() == 3) return lin(e_, {{4, &st[0]}, {2, &st[1]}, {1, &st[2]}}, 8);
+    if (st.size() == 2) return lin(e_, {{2, &st[0]}, {1, &st[1]}}, 8);
+    if (st.size() == 1) return lin(e_, {{1, &st[0]}}, 8);
+    return trivial_block(e_, 8);
 }
 
-// The positional half of f_comparison on two equally long slices: (any position differs, verdict at the FIRST
+FChar Strings::f_comparison(const FStr &a, const FStr &b, int cmp) {
+    static const int root[4] = {LUT_LT8, LUT_LE8, LUT_GT8, LUT_GE8};
+    return ch_flag(e_, pbs(cmp_root_sum(cmp_leaves(a, b)), root[cmp & 3]));   // two empty buffers: 8 = equal (:1490-1494)
+}
+
+// The positional half of the comparison on two equally long slices: (any position differs, verdict at the FIRST
 // differing position; 0 when none differs).  Multi-GPU position sharding combines these per-range partials: the
 // first range that differs decides (fhestring_amd/parallel.py ShardedCmp).
 void Strings::f_cmp_partial(const FStr &a, const FStr &b, int cmp, FChar *any_diff_out, FChar *verdict_out) {
@@ -1167,19 +1141,11 @@ void Strings::f_cmp_partial(const FStr &a, const FStr &b, int cmp, FChar *any_di
         *verdict_out = t(0);
         return;
     }
-    Ref one = trivial_block(e_, 1);
-    std::vector<Ref> differs(n), x(n);
-    const int xl = (cmp == 0 || cmp == 1) ? LUT_CMP_LT : LUT_CMP_GT;
-    for (size_t i = 0; i < n; i++) {
-        Ref eq;
-        cmp_pair(a[i], b[i], xl, &eq, &x[i]);
-        differs[i] = lin(e_, {{1, &one}, {-1, &eq}});
-    }
-    std::vector<Ref> before = prefix_or(differs);
-    std::vector<Ref> pick(n);
-    for (size_t i = 0; i < n; i++) pick[i] = pbs(lin(e_, {{2, &x[i]}, {1, &before[i]}}), LUT_IS2);
-    *verdict_out = ch_flag(e_, onehot_or(pick));             // at most one pick is set
-    *any_diff_out = ch_flag(e_, or_tree(differs));
+    FStr ca(a.begin(), a.begin() + n), cb(b.begin(), b.begin() + n);
+    Ref v = cmp_root_sum(cmp_leaves(ca, cb));
+    Ref one = trivial_block(e_, 1), same = pbs(v, LUT_IS8);
+    *verdict_out = ch_flag(e_, pbs(v, (cmp == 0 || cmp == 1) ? LUT_LT8 : LUT_GT8));
+    *any_diff_out = ch_flag(e_, lin(e_, {{1, &one}, {-1, &same}}));
 }
 
 // Combines per-range partials of f_cmp_partial (ranges in string order): the first range that differs decides;

@@ -105,7 +105,9 @@ class Strings {
     FChar position_of(const std::vector<Ref> &pick, size_t index_offset, const Ref *absent_flag, int absent_value);
     FChar first_index(const std::vector<Ref> &before, const Ref &found);
     FChar f_eq_ignore_case(const FStr &a, const FStr &b);
-    void cmp_pair(const FChar &a, const FChar &b, int cmp_lut, Ref *eq, Ref *x);   // index of the first set flag, 255 if none
+    // lexicographic order as a tree of three-state values s = sign(a - b) in {-1, 0, 1}, most significant first
+    std::vector<Ref> cmp_leaves(const FStr &a, const FStr &b);          // one per nibble pair, missing characters are 0
+    Ref cmp_root_sum(std::vector<Ref> states);                          // 8 + 4 s1 + 2 s2 + s3 of the last <= 3 states   // index of the first set flag, 255 if none
     FChar f_rfind(const FStr &s, const FStr &pat);
     FChar f_ends_with(const FStr &s, const FStr &needle, std::vector<Ref> *pick_out);
     FStr f_trim(const FStr &s, bool from_end);

@@ -80,7 +80,7 @@ def test_config_dag_shapes(sk):
     st, w = run(lambda: sk.eq_ignore_case(a, b))
     assert (st["pbs_executed"], st["levels"]) == (28_975, 7)        # 68 541 / 19; as written: 418 k + 258 k PBS
     st, w = run(lambda: sk.le(a, b))
-    assert (st["pbs_executed"], st["levels"]) == (24_938, 11)       # 25 169 / 13 before the one-hot verdict tree (r3); as written: 344 k PBS, 24 591 levels
+    assert (st["pbs_executed"], st["levels"]) == (12_292, 10)       # 24 938 / 11 before the three-state sign tree (r3: two nibble signs per pair, then sign(4 s1 + 2 s2 + s3) per triple); as written: 344 k PBS, 24 591 levels
     sk.set_auto_flush(8192)
     sk.set_mode(0)
     st, w = run(lambda: sk.contains_clear(s65, "abcd"))
