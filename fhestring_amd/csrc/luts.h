@@ -30,11 +30,10 @@ enum LutId : uint16_t {
     LUT_GREEDY_NEXT7,
     // case-insensitive equality of two characters without folding either (Strings::f_eq_ignore_case)
     LUT_EQIC_B3,       // v = a3 + 4 b3 (top digits): 2 both are 1 (0x40..0x7F), 1 equal otherwise, 0 different
-    LUT_EQIC_B2,       // v = a2 + 4 b2 (bits 4, 5): 2 equal, 1 differ in bit 5 (the case bit) only, 0 otherwise
+    LUT_EQIC_Z,        // v = a2 + 4 b2 (bits 4, 5): 1 equal, 2 + row bit if they differ in bit 5 (the case bit) only, 0 otherwise
     LUT_EQIC_LO,       // low nibble v: (v >= 1) + 2 (v <= 10): letter rows 0x41..0x4F / 0x50..0x5A (and 0x6_, 0x7_)
-    LUT_EQIC_OK,       // v = LO + 4 a2: the row bit (bit 4) picks which of the two range flags counts
-    LUT_EQIC_C1,       // v = B2 + 3 B3: 1 equal high nibbles, 2 case bit differs on a letter row, 0 unequal
-    LUT_EQIC_FIN,      // v = C1 + 3 OK + 6 E_lo: low nibbles equal and (C1 == 1 or (C1 == 2 and OK))
+    LUT_EQIC_S1,       // v = Z + 4 LO: 1 same digit, 2 case bit differs and the low nibble is a letter's on that row, 0 otherwise
+    LUT_EQIC_FIN,      // v = B3 + 3 S1 + 7 E_lo: low nibbles equal and (S1 == 1 with equal top digits, or S1 == 2 on a letter row)
     // root of the three-state comparison tree (Strings::cmp_verdict): v = 8 + 4 s1 + 2 s2 + s3, s in {-1, 0, 1}
     LUT_LT8, LUT_LE8, LUT_GT8, LUT_GE8,
     LUT_COUNT
@@ -73,18 +72,13 @@ inline int lut_function(int id, int v) {
         case LUT_LO_WS0: return v == 0 || (v >= 9 && v <= 13);
         case LUT_GREEDY_SEL: return v == 1;
         case LUT_EQIC_B3: return (v & 3) != (v >> 2) ? 0 : ((v & 3) == 1 ? 2 : 1);
-        case LUT_EQIC_B2: return (v & 3) == (v >> 2) ? 2 : ((((v & 3) ^ (v >> 2)) == 2) ? 1 : 0);
+        case LUT_EQIC_Z: return (v & 3) == (v >> 2) ? 1 : ((((v & 3) ^ (v >> 2)) == 2) ? 2 + (v & 1) : 0);
         case LUT_EQIC_LO: return (v >= 1) + 2 * (v <= 10);
-        case LUT_EQIC_OK: return ((v >> 2) & 1) ? ((v >> 1) & 1) : (v & 1);
-        case LUT_EQIC_C1: {
-            const int b2 = v % 3, b3 = v / 3;                // both in 0..2 (v <= 8)
-            if (v > 8 || b3 == 0 || b2 == 0) return 0;
-            return b2 == 2 ? 1 : (b3 == 2 ? 2 : 0);
+        case LUT_EQIC_S1: {
+            const int z = v & 3, lo = v >> 2;
+            return z <= 1 ? z : (((z == 2 ? lo : lo >> 1) & 1) ? 2 : 0);
         }
-        case LUT_EQIC_FIN: {
-            const int c1 = v % 3, ok = (v / 3) & 1, e = v / 6;
-            return v < 12 && e == 1 && (c1 == 1 || (c1 == 2 && ok));
-        }
+        case LUT_EQIC_FIN: return v == 11 || v == 12 || v == 15;    // (B3, S1, E_lo) = (1, 1, 1), (2, 1, 1), (2, 2, 1)
         case LUT_LT8: return v < 8;
         case LUT_LE8: return v <= 8;
         case LUT_GT8: return v > 8;

@@ -310,7 +310,7 @@ FChar Strings::eq_ignore_case(const FStr &a, const FStr &b) {   // mod.rs:1221-1
 // eq(to_lower(a), to_lower(b)) without folding either string: two characters are equal ignoring case iff their low
 // nibbles are equal and their high nibbles are equal, or differ in the case bit 0x20 only with both characters letters
 // (top two bits 01, and the low nibble in 1..15 on the rows 0x4_ / 0x6_, in 0..10 on the rows 0x5_ / 0x7_: with equal
-// low nibbles one range test serves both).  7 bootstraps per position in 3 levels instead of 12 (case flags and folds
+// low nibbles one range test serves both).  6 bootstraps per position in 3 levels instead of 12 (case flags and folds
 // of both strings, then the nibble tests); the length condition of eq is the tail test of f_eq (NUL has no case).
 FChar Strings::f_eq_ignore_case(const FStr &a, const FStr &b) {
     std::vector<Ref> f;
@@ -324,11 +324,12 @@ FChar Strings::f_eq_ignore_case(const FStr &a, const FStr &b) {
         const FChar x = clean(a[i]), y = clean(b[i]);
         Ref e_lo = pbs(lin(e_, {{1, &x.b[0]}, {4, &x.b[1]}, {-1, &y.b[0]}, {-4, &y.b[1]}}), LUT_IS0);
         Ref b3 = pbs(lin(e_, {{1, &x.b[3]}, {4, &y.b[3]}}), LUT_EQIC_B3);
-        Ref b2 = pbs(lin(e_, {{1, &x.b[2]}, {4, &y.b[2]}}), LUT_EQIC_B2);
+        Ref z = pbs(lin(e_, {{1, &x.b[2]}, {4, &y.b[2]}}), LUT_EQIC_Z);
         Ref lo = pbs(lin(e_, {{1, &x.b[0]}, {4, &x.b[1]}}), LUT_EQIC_LO);
-        Ref ok = pbs(lin(e_, {{1, &lo}, {4, &x.b[2]}}), LUT_EQIC_OK);
-        Ref c1 = pbs(lin(e_, {{1, &b2}, {3, &b3}}), LUT_EQIC_C1);
-        f.push_back(pbs(lin(e_, {{1, &c1}, {3, &ok}, {6, &e_lo}}), LUT_EQIC_FIN));
+        Ref s1 = pbs(lin(e_, {{1, &z}, {4, &lo}}), LUT_EQIC_S1);
+        // the three partial verdicts as one sum without collisions between a passing and a failing combination:
+        // passing (B3, S1, E_lo) = (1, 1, 1), (2, 1, 1), (2, 2, 1) -> 11, 12, 15; sum c^2 = 59
+        f.push_back(pbs(lin(e_, {{1, &b3}, {3, &s1}, {7, &e_lo}}), LUT_EQIC_FIN));
     }
     const FStr &longer = a.size() > b.size() ? a : b;
     for (size_t i = common; i < longer.size(); i++) {

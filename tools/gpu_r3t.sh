@@ -1,6 +1,6 @@
 #!/bin/bash
 set -o pipefail
-O=gpurun_out/r3w
+O=gpurun_out/r3x
 mkdir -p $O
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
