@@ -65,6 +65,27 @@ __device__ __forceinline__ uint32_t rot_sub_hi(uint64_t v, uint64_t a, uint64_t 
     return th;
 }
 
+// The same difference for operands kept with an offset of -1 (vm = v - 1, am = a - 1, both mod 2^64): with t = vm or
+// ~vm (flip) and a borrow-in of 1 where the value is NOT flipped,
+//     am - t - borrow = a - v - 1 = ~(v - a)        (not flipped)
+//                     = a + v - 1 = ~(-v - a)       (flipped, ~vm = -v),
+// i.e. the complement of the wanted difference, exactly, in five operations instead of six -- and the rounding add
+// becomes a subtraction: digit = (hi(x) + 0x100) >> 9 = (0xFF - hi(~x)) >> 9.  Returns hi(~x).
+__device__ __forceinline__ uint32_t rot_sub_hi_compl(uint64_t vm, uint64_t am, uint64_t keepmask /* lanes NOT flipped */) {
+    const uint32_t vl = (uint32_t)vm, vh = (uint32_t)(vm >> 32), al = (uint32_t)am, ah = (uint32_t)(am >> 32);
+    uint32_t m, tl, th;
+    asm("v_cndmask_b32 %0, -1, 0, %7\n\t"
+        "v_xor_b32 %1, %3, %0\n\t"
+        "v_xor_b32 %2, %4, %0\n\t"
+        "v_subb_co_u32 %1, vcc, %5, %1, %7\n\t"
+        "v_subb_co_u32 %2, vcc, %6, %2, vcc"
+        : "=&v"(m), "=&v"(tl), "=&v"(th)
+        : "v"(vl), "v"(vh), "v"(al), "v"(ah), "s"(keepmask)
+        : "vcc");
+    (void)m; (void)tl;
+    return th;
+}
+
 // Torus value (mod 2^64) of t * 2^64, where t is the inverse transform's output: the Fourier-domain key carries
 // the factor 2^-64 (beside 1/1024), so the accumulator increment is the fractional part of t.  fract is exact;
 // 1 + f puts that fraction into the 52 mantissa bits of a double in [1, 2] (one rounding at 2^-52, i.e. 2^12 torus

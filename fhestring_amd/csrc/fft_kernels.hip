@@ -52,7 +52,8 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
 
     const uint64_t *ks = P.ks + (size_t)ct * SMALL_CT;
 
-    // acc[r] = coefficient (lane + 64 r) of polynomial j (u64 torus); registers r and r+16 form one complex point
+    // acc[r] = coefficient (lane + 64 r) of polynomial j (u64 torus) MINUS ONE -- the offset makes the rotate-and-
+    // subtract exact in five operations (rot_sub_hi_compl); registers r and r+16 form one complex point
     uint64_t acc[32];
     {
         const uint32_t b = fft_mod_switch(ks[LWE_N]);
@@ -68,13 +69,14 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
                 v = lut[(n - s) & (POLY_N - 1)];
                 if ((n < s) != neg) v = (uint64_t)0 - v;
             }
-            acc[r] = v;
+            acc[r] = v - 1;
         }
     }
 
 #pragma unroll
     for (int r = 0; r < 32; r++) my_u[64 + lane + 64 * r] = acc[r];
     my_u[lane] = acc[31];                             // row 31 again in front of row 0 (see the rotated read)
+    my_u[64 + lane + 64 * 32] = acc[0];               // and row 0 again behind row 31: rows are read in pairs
     // the mask element of the NEXT iteration is requested one iteration ahead (ks[LWE_N], the body, is a valid address):
     // read at the top of its own iteration it cost one exposed global-memory round trip per iteration
     uint64_t ks_next = ks[0];
@@ -105,26 +107,35 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
         // lower, which for row 0 is the copy of row 31 kept in front of it.  The sign flips where the index wrapped.
         const uint32_t sl = s & 63, sh = s >> 6;
         const bool borrow = (uint32_t)lane < sl;
-        const uint64_t negmask = neg ? ~0ull : 0ull;
+        const uint64_t keep_unless_wrapped = neg ? 0ull : ~0ull;
         const uint64_t *vbase = my_u + (((uint32_t)lane - sl) & 63) + (borrow ? 0 : 64);
         // the index wrapped (sign flip) where n = lane + 64 r < s, i.e. 64 r < s - lane: one vector compare per row
         // against a per-lane threshold instead of ~7 scalar operations per row building the same lane mask
         const int32_t thr = (int32_t)s - lane;
         // the reads run RW rows ahead of their use: issued one at a time right before its use, every row paid a full
-        // LDS round trip (32 exposed round trips per iteration)
+        // LDS round trip (32 exposed round trips per iteration).  Rows are read in PAIRS (source rows rho, rho + 1 of
+        // one address: ds_read2st64_b64, one address computation for two rows); row 32 is the copy of row 0.
         constexpr int RW = 8;
         uint64_t vq[RW];
 #pragma unroll
-        for (int k = 0; k < RW; k++) vq[k] = vbase[64 * ((k - sh) & 31)];
+        for (int k = 0; k < RW; k += 2) {
+            const uint64_t *pb = vbase + 64 * ((k - sh) & 31);
+            vq[k] = pb[0];
+            vq[k + 1] = pb[64];
+        }
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             const uint64_t v = vq[r % RW];
-            if (r + RW < 32) vq[r % RW] = vbase[64 * ((r + RW - sh) & 31)];
+            if ((r & 1) && r + RW - 1 < 32) {
+                const uint64_t *pb = vbase + 64 * ((r + RW - 1 - sh) & 31);
+                vq[(r - 1) % RW] = pb[0];
+                vq[r % RW] = pb[64];
+            }
             const uint64_t wrapmask = __builtin_amdgcn_ballot_w64(64 * r < thr);
-            const uint32_t dhi = rot_sub_hi(v, acc[r], wrapmask ^ negmask);
-            const int32_t dig = (int32_t)(dhi + 0x100u) >> 9;
+            const uint32_t nhi = rot_sub_hi_compl(v, acc[r], wrapmask ^ keep_unless_wrapped);
+            const int32_t dig = (int32_t)(0xFFu - nhi) >> 9;
             if (r < 16) z[r].r = (double)dig; else z[r - 16].i = (double)dig;
-            __builtin_amdgcn_sched_barrier(0);        // keep the read of row r + RW behind the use of row r, RW in flight
+            __builtin_amdgcn_sched_barrier(0);        // keep the reads of rows r + RW - 1, r + RW behind the use of row r
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -181,6 +192,7 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
             my_u[64 + lane + 64 * r] = acc[r];
             acc[r + 16] += to_torus(z[r].i);
             my_u[64 + lane + 64 * (r + 16)] = acc[r + 16];
+            if (r == 0) my_u[64 + lane + 64 * 32] = acc[0];
             if (r == 15) my_u[lane] = acc[31];
         }
     }
@@ -190,11 +202,11 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_fft_kernel(BlindRotateFft
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             const int n = lane + 64 * r;
-            if (n == 0) out[0] = acc[r];
-            else out[POLY_N - n] = (uint64_t)0 - acc[r];
+            if (n == 0) out[0] = acc[r] + 1;
+            else out[POLY_N - n] = (uint64_t)0 - (acc[r] + 1);
         }
     } else if (lane == 0) {
-        out[BIG_N] = acc[0];
+        out[BIG_N] = acc[0] + 1;
     }
     }   // persistent loop
 }
