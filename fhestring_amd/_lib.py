@@ -255,6 +255,8 @@ def _declare(L):
     L.fhs_level_widths.restype = i
     L.fhs_get_stats.argtypes = [vp, vp]
     L.fhs_get_stats.restype = i
+    L.fhs_char_sum_c2.argtypes = [vp, C.c_uint64, vp]
+    L.fhs_char_sum_c2.restype = i
     L.fhs_reset_stats.argtypes = [vp]
     L.fhs_reset_stats.restype = i
     L.fhs_client_create.argtypes = [C.POINTER(vp)]

@@ -312,6 +312,13 @@ class FheAsciiChar:
     def is_lowercase(self): return self._un("is_lowercase")
     def clone(self): return self._un("clone")
 
+    def sum_c2(self):
+        """Noise of the handle in bootstrap-output variances (fhs_char_sum_c2): results come back at <= 4 except find's
+        index (<= 57); above 4 a downloaded block must be bootstrapped before it is uploaded again."""
+        v = C.c_uint64(0)
+        self.sk.ctx._check(self.sk.ctx._L.fhs_char_sum_c2(self.sk.ctx._h, self.h, C.byref(v)))
+        return int(v.value)
+
     def download(self):
         out = np.zeros((4, BIG_CT), np.uint64)
         self.sk.flush()                      # (collective in level-parallel mode)

@@ -437,6 +437,14 @@ int fhs_get_stats(fhs_ctx *c, fhs_stats *out) {
     out->pbs_shared = c->eng.stats.pbs_shared;
     return FHS_OK;
 }
+int fhs_char_sum_c2(fhs_ctx *c, fhs_char_t h, uint64_t *out) {
+    if (!ok(c, h) || !out) return bad(c);
+    const Bid *b = c->eng.char_blocks(h);
+    int64_t m = 0;
+    for (int i = 0; i < 4; i++) m = std::max<int64_t>(m, c->eng.sum_c2(b[i]));
+    *out = (uint64_t)m;
+    return FHS_OK;
+}
 int fhs_level_widths(fhs_ctx *c, uint32_t *out, size_t cap, size_t *n) {
     if (!c || !n) return bad(c);
     const auto &w = c->eng.stats.level_widths;

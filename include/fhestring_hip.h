@@ -349,6 +349,12 @@ typedef struct {
  * set's 2^-40 failure probability is kept (tests/test_gpu_noise.py measures it). */
 #define FHS_NOISE_BUDGET_SUM_C2 64
 int fhs_get_stats(fhs_ctx *ctx, fhs_stats *out);
+/* Noise of a handle in the same unit: the largest sum of squared coefficients over its four blocks (0 trivial, 1 a
+ * bootstrap output or an upload).  Results are handed back at <= 4 except the index of find / find_clear, whose digits
+ * are sums of up to 57 bootstrap outputs (inside the decryption margin; saves one dependency level).  The library
+ * refreshes a block above 4 by itself when its handle is used as an operand; a host that downloads such a block and
+ * uploads it again (uploads count as 1) has to bootstrap it first -- this is the query for that. */
+int fhs_char_sum_c2(fhs_ctx *ctx, fhs_char_t h, uint64_t *out);
 /* Width (PBS count) of every dependency level executed since the last fhs_reset_stats, in execution order (the shape
  * of the levelized batches: what a CPU baseline has to run to do the same work).  *n = number of levels; out may be
  * NULL to query it. */

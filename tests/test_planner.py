@@ -71,6 +71,10 @@ def test_config_dag_shapes(sk):
     st, w = run(lambda: sk.find(s257, p4))
     assert (st["pbs_executed"], st["levels"]) == (2574, 6)          # 2 578 / 8 before the index digits were handed back unrefreshed and the 16th chunk got its prefix a level earlier (r3); 2 911 / 11 at the start of round 2
     # the unrefreshed digits come back through the handle boundary refreshed when they are used as operands
+    idx = sk.find(s257, p4)
+    assert 4 < idx.sum_c2() <= 57 and idx.eq(s257[0]).sum_c2() <= 4 and sk.le(s65, s65).sum_c2() <= 4
+    del idx
+    sk.flush()
     st, w = run(lambda: sk.find(s257, p4).eq(s257[0]))
     assert st["levels"] == 6 + 3 and 2574 + 3 <= st["pbs_executed"] <= 2574 + 4 + 12
     s1025, f5, t5 = sk.dummy_string(1025), sk.dummy_string(5), sk.dummy_string(5)
