@@ -34,6 +34,13 @@ enum LutId : uint16_t {
     LUT_EQIC_LO,       // low nibble v: (v >= 1) + 2 (v <= 10): letter rows 0x41..0x4F / 0x50..0x5A (and 0x6_, 0x7_)
     LUT_EQIC_S1,       // v = Z + 4 LO: 1 same digit, 2 case bit differs and the low nibble is a letter's on that row, 0 otherwise
     LUT_EQIC_FIN,      // v = B3 + 3 S1 + 7 E_lo: low nibbles equal and (S1 == 1 with equal top digits, or S1 == 2 on a letter row)
+    // character classes in three bootstraps (is_upper_flag, char_significant): a row class of the high nibble (1 / 2 / 0), a
+    // two-flag class of the low nibble, and the pick of the flag that belongs to the row
+    LUT_HI_ROW45,      // high nibble 4 -> 1, 5 -> 2, else 0 ('A'..'O' / 'P'..'Z')
+    LUT_HI_ROW67,      // high nibble 6 -> 1, 7 -> 2, else 0 ('a'..'o' / 'p'..'z')
+    LUT_HI_ROW02,      // high nibble 0 -> 1, 2 -> 2, else 0 (NUL, 0x09..0x0D / space)
+    LUT_LO_WSCLS,      // low nibble: (v == 0 or 9 <= v <= 13) + 2 (v == 0)
+    LUT_CLS_PICK,      // v = row + 4 flags: row 1 -> flags & 1, row 2 -> flags >> 1, row 0 -> 0
     // root of the three-state comparison tree (Strings::cmp_verdict): v = 8 + 4 s1 + 2 s2 + s3, s in {-1, 0, 1}
     LUT_LT8, LUT_LE8, LUT_GT8, LUT_GE8,
     LUT_COUNT
@@ -79,6 +86,11 @@ inline int lut_function(int id, int v) {
             return z <= 1 ? z : (((z == 2 ? lo : lo >> 1) & 1) ? 2 : 0);
         }
         case LUT_EQIC_FIN: return v == 11 || v == 12 || v == 15;    // (B3, S1, E_lo) = (1, 1, 1), (2, 1, 1), (2, 2, 1)
+        case LUT_HI_ROW45: return v == 4 ? 1 : (v == 5 ? 2 : 0);
+        case LUT_HI_ROW67: return v == 6 ? 1 : (v == 7 ? 2 : 0);
+        case LUT_HI_ROW02: return v == 0 ? 1 : (v == 2 ? 2 : 0);
+        case LUT_LO_WSCLS: return (v == 0 || (v >= 9 && v <= 13)) + 2 * (v == 0);
+        case LUT_CLS_PICK: return (v & 3) == 1 ? ((v >> 2) & 1) : ((v & 3) == 2 ? ((v >> 3) & 1) : 0);
         case LUT_LT8: return v < 8;
         case LUT_LE8: return v <= 8;
         case LUT_GT8: return v > 8;

@@ -96,8 +96,7 @@ FChar Strings::is_empty(const FStr &s) {                     // mod.rs:431-451
     const FChar zero = t(0);
     if (fused()) {
         std::vector<Ref> f;
-        for (const FChar &c : s)
-            for (const Ref &x : block_eq_flags(c, zero)) f.push_back(x);
+        for (const FChar &c : s) f.push_back(char_zero_test(c, true));
         return ch_flag(e_, and_tree(f));
     }
     FChar result = t(1);
@@ -332,11 +331,7 @@ FChar Strings::f_eq_ignore_case(const FStr &a, const FStr &b) {
         f.push_back(pbs(lin(e_, {{1, &b3}, {3, &s1}, {7, &e_lo}}), LUT_EQIC_FIN));
     }
     const FStr &longer = a.size() > b.size() ? a : b;
-    for (size_t i = common; i < longer.size(); i++) {
-        const FChar &c = longer[i];
-        f.push_back(pbs(lin(e_, {{1, &c.b[0]}, {4, &c.b[1]}}), lut_is_k(0)));
-        f.push_back(pbs(lin(e_, {{1, &c.b[2]}, {4, &c.b[3]}}), lut_is_k(0)));
-    }
+    for (size_t i = common; i < longer.size(); i++) f.push_back(char_zero_test(longer[i], true));
     return ch_flag(e_, and_tree(f));
 }
 
@@ -1172,19 +1167,29 @@ std::vector<Ref> Strings::suffix_or(const std::vector<Ref> &f) {
     return std::vector<Ref>(p.rbegin(), p.rend());
 }
 
-Ref Strings::char_nonzero(const FChar &c) {
-    Ref one = trivial_block(e_, 1);
-    Ref z = and_tree(block_eq_flags(c, t(0)));
-    return lin(e_, {{1, &one}, {-1, &z}});
+Ref Strings::char_nonzero(const FChar &c) { return char_zero_test(c, false); }
+
+// [c == 0] or [c != 0] in ONE bootstrap: the four base-4 digits are non-negative, so their sum (<= 12, inside the message
+// space) is zero iff every digit is -- instead of two nibble tests and a combining bootstrap.  Digits that are sums of
+// bootstrap outputs are refreshed first only if together they would leave the noise budget.
+Ref Strings::char_zero_test(const FChar &c_in, bool want_zero) {
+    FChar c = c_in;
+    int64_t c2 = 0;
+    for (int k = 0; k < 4; k++) c2 += e_->sum_c2(c.b[k].id());
+    if (c2 > FHS_NOISE_BUDGET_SUM_C2)
+        for (int k = 0; k < 4; k++)
+            if (e_->sum_c2(c.b[k].id()) > 1) c.b[k] = pbs(c.b[k], LUT_MSG);
+    return pbs(lin(e_, {{1, &c.b[0]}, {1, &c.b[1]}, {1, &c.b[2]}, {1, &c.b[3]}}), want_zero ? LUT_IS0 : LUT_NZ);
 }
 
 // NUL = 0x00, whitespace = 0x20, 0x09..0x0D (fheasciichar.rs:106-130): high nibble 0 with low nibble in
-// {0, 9..13}, or high nibble 2 with low nibble 0 -- same 5-PBS shape as the case detector
+// {0, 9..13}, or high nibble 2 with low nibble 0 -- same 3-bootstrap shape as the case detector (row class of the high
+// nibble, two range flags of the low nibble, the pick of the flag that belongs to the row)
 Ref Strings::char_significant(const FChar &c) {
     Ref lo = lin(e_, {{1, &c.b[0]}, {4, &c.b[1]}});
     Ref hi = lin(e_, {{1, &c.b[2]}, {4, &c.b[3]}});
-    Ref h0 = pbs(hi, LUT_IS0), h2 = pbs(hi, LUT_IS2), l0 = pbs(lo, LUT_IS0), lw = pbs(lo, LUT_LO_WS0);
-    Ref bad = pbs(lin(e_, {{1, &h0}, {1, &lw}, {4, &h2}, {4, &l0}}), LUT_CASEFLAG);
+    Ref row = pbs(hi, LUT_HI_ROW02), cls = pbs(lo, LUT_LO_WSCLS);
+    Ref bad = pbs(lin(e_, {{1, &row}, {4, &cls}}), LUT_CLS_PICK);
     Ref one = trivial_block(e_, 1);
     return lin(e_, {{1, &one}, {-1, &bad}});
 }
@@ -1454,17 +1459,7 @@ FStr Strings::f_compact(const FStr &s) {
     const size_t D = (size_t)(K + 1) / 2;
     const FChar zero = t(0);
     std::vector<Ref> z(n);
-    for (size_t i = 0; i < n; i++) {
-        // is-NUL flag: two nibble tests -- unless the blocks are sums of bootstrap outputs whose packing (weights 1, 4) would
-        // leave the noise budget: then four single-block tests (5 bootstraps) instead of refreshing all four blocks first (7)
-        bool heavy = false;
-        for (int h = 0; h < 2; h++)
-            heavy = heavy || e_->sum_c2(s[i].b[2 * h].id()) + 16 * e_->sum_c2(s[i].b[2 * h + 1].id()) > FHS_NOISE_BUDGET_SUM_C2;
-        if (!heavy) { z[i] = and_tree(block_eq_flags(s[i], zero)); continue; }
-        std::vector<Ref> f;
-        for (int k = 0; k < 4; k++) f.push_back(pbs(s[i].b[k], LUT_IS0));
-        z[i] = and_tree(f);
-    }
+    for (size_t i = 0; i < n; i++) z[i] = char_zero_test(s[i], true);   // is-NUL flag: one bootstrap on the digit sum
     // per-position shift = number of NULs before it; NUL positions get shift 0 (they stay and contribute zeros)
     std::vector<Num> shifts = flag_prefix_counts(z, D);
     std::vector<std::vector<Ref>> dg(n, std::vector<Ref>(D));
@@ -1564,7 +1559,7 @@ FChar Strings::count_flags(std::vector<Ref> flags) {
 
 FChar Strings::f_len(const FStr &s) {
     std::vector<Ref> nz;
-    for (const FChar &c : s) nz.push_back(blk_nonzero_flag(c));
+    for (const FChar &c : s) nz.push_back(char_zero_test(c, false));
     return count_flags(nz);
 }
 
@@ -1576,14 +1571,10 @@ FChar Strings::f_eq(const FStr &a, const FStr &b) {
         for (Ref &x : block_eq_flags(a[i], b[i])) f.push_back(x);
     // len(a) == len(b) (mod.rs:1133-1135,1148; len = number of non-zero characters): once every common position holds
     // equal characters the two counts differ exactly by the non-zero characters of the longer buffer's tail, so the
-    // condition is "that tail is all zero" -- two nibble tests per extra character instead of two 8-bit popcounts with
+    // condition is "that tail is all zero" -- one digit-sum test per extra character instead of two 8-bit popcounts with
     // their carry chains (eq_ignore_case on 4096 characters: 19 levels / 68 541 bootstraps before)
     const FStr &longer = a.size() > b.size() ? a : b;
-    for (size_t i = common; i < longer.size(); i++) {
-        const FChar &c = longer[i];
-        f.push_back(pbs(lin(e_, {{1, &c.b[0]}, {4, &c.b[1]}}), lut_is_k(0)));
-        f.push_back(pbs(lin(e_, {{1, &c.b[2]}, {4, &c.b[3]}}), lut_is_k(0)));
-    }
+    for (size_t i = common; i < longer.size(); i++) f.push_back(char_zero_test(longer[i], true));
     return ch_flag(e_, and_tree(f));
 }
 
@@ -1591,14 +1582,11 @@ FChar Strings::f_eq(const FStr &a, const FStr &b) {
 Ref Strings::is_upper_flag(const FChar &c, bool lower) {
     Ref lo = lin(e_, {{1, &c.b[0]}, {4, &c.b[1]}});
     Ref hi = lin(e_, {{1, &c.b[2]}, {4, &c.b[3]}});
-    Ref ha = pbs(hi, lut_is_k(lower ? 6 : 4));
-    Ref hb = pbs(hi, lut_is_k(lower ? 7 : 5));
-    Ref lnz = pbs(lo, LUT_NZ);
-    Ref lle = pbs(lo, LUT_LE10);
-    return pbs(lin(e_, {{1, &ha}, {1, &lnz}, {4, &hb}, {4, &lle}}), LUT_CASEFLAG);
+    Ref row = pbs(hi, lower ? LUT_HI_ROW67 : LUT_HI_ROW45);
+    Ref cls = pbs(lo, LUT_EQIC_LO);                          // (low >= 1) + 2 (low <= 10)
+    return pbs(lin(e_, {{1, &row}, {4, &cls}}), LUT_CLS_PICK);
 }
 
-// the case delta 32 = digit 2 of block 2; letters of the source case never carry/borrow out of it
 FStr Strings::f_case(const FStr &s, bool to_lower) {
     FStr r;
     for (const FChar &c : s) {

@@ -101,6 +101,7 @@ class Strings {
     FChar ite_flag(const Ref &flag, const FChar &t, const FChar &f);
     std::vector<Ref> suffix_or(const std::vector<Ref> &f);            // exclusive: OR_{k>i}
     Ref char_nonzero(const FChar &c);                                 // 1 block: c != 0
+    Ref char_zero_test(const FChar &c, bool want_zero);               // 1 block, 1 bootstrap: c == 0 / c != 0
     Ref char_significant(const FChar &c);                             // 1 block: c is neither NUL nor whitespace
     FChar position_of(const std::vector<Ref> &pick, size_t index_offset, const Ref *absent_flag, int absent_value);
     FChar first_index(const std::vector<Ref> &before, const Ref &found);
