@@ -102,6 +102,8 @@ def _declare(L):
     L.fhs_trivial.restype = h
     L.fhs_upload.argtypes = [vp, vp]
     L.fhs_upload.restype = h
+    L.fhs_upload_string.argtypes = [vp, vp, sz, vp]
+    L.fhs_upload_string.restype = i
     L.fhs_import_device.argtypes = [vp, vp]
     L.fhs_import_device.restype = h
     for name in ("eq", "ne", "le", "lt", "ge", "gt", "bitand", "bitor", "sub", "add"):

@@ -436,7 +436,10 @@ class MyServerKey:
 
     def upload_string(self, chars):
         chars = np.ascontiguousarray(chars, np.uint64).reshape(-1, 4, BIG_CT)
-        return FheString([self.upload_char(chars[i]) for i in range(chars.shape[0])])
+        n = chars.shape[0]
+        hs = (C.c_uint64 * max(1, n))()
+        self.ctx._check(self.ctx._L.fhs_upload_string(self.ctx._h, _ptr(chars), n, hs))
+        return FheString([FheAsciiChar(self, hs[i]) for i in range(n)])
 
     def import_device(self, d_ptr):
         return FheAsciiChar(self, self.ctx._L.fhs_import_device(self.ctx._h, C.c_void_p(d_ptr)))

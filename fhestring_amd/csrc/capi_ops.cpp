@@ -67,18 +67,16 @@ fhs_char_t fhs_trivial(fhs_ctx *c, uint8_t v) {
     return store(c->eng, r);
 }
 fhs_char_t fhs_upload(fhs_ctx *c, const uint64_t *blocks) {
-    if (!c || !blocks) { bad(c); return 0; }
-    if (!c->eng.planner && hipSetDevice(c->eng.ctx.device) != hipSuccess) { c->eng.ctx.fail(FHS_ERR_HIP, "hipSetDevice failed"); return 0; }
-    Bid b[4] = {0, 0, 0, 0};
-    for (int i = 0; i < 4; i++) {
-        b[i] = c->eng.from_host(blocks + (size_t)i * FHS_BIG_CT);
-        if (!b[i]) {
-            for (int k = 0; k < i; k++) c->eng.release(b[k]);
-            c->eng.ctx.fail(FHS_ERR_HIP, "upload failed (device allocation or copy)");
-            return 0;
-        }
-    }
-    return c->eng.new_char(b);
+    fhs_char_t h = 0;
+    return fhs_upload_string(c, blocks, 1, &h) == FHS_OK ? h : 0;
+}
+int fhs_upload_string(fhs_ctx *c, const uint64_t *blocks, size_t n, fhs_char_t *out) {
+    if (!c || (n && (!blocks || !out))) return bad(c);
+    if (!c->eng.planner && hipSetDevice(c->eng.ctx.device) != hipSuccess) return c->eng.ctx.fail(FHS_ERR_HIP, "hipSetDevice failed");
+    std::vector<Bid> b(4 * n);
+    if (c->eng.from_host_many(blocks, 4 * n, b.data())) return c->eng.ctx.fail(FHS_ERR_HIP, "upload failed (device allocation or copy)");
+    for (size_t i = 0; i < n; i++) out[i] = c->eng.new_char(&b[4 * i]);
+    return FHS_OK;
 }
 fhs_char_t fhs_import_device(fhs_ctx *c, const uint64_t *d_blocks) {
     if (!c || !d_blocks) { bad(c); return 0; }

@@ -35,6 +35,12 @@ void Engine::shutdown() {
     d_luts_ = nullptr;
     if (last_group_done_) (void)hipEventDestroy(last_group_done_);
     last_group_done_ = nullptr;
+    if (upload_done_) (void)hipEventDestroy(upload_done_);
+    upload_done_ = nullptr;
+    if (upload_pin_) (void)hipHostFree(upload_pin_);
+    if (upload_dev_) (void)hipFree(upload_dev_);
+    upload_pin_ = upload_dev_ = nullptr;
+    upload_words_ = 0;
     for (Staging &c : staging_) {
         if (c.done) (void)hipEventDestroy(c.done);
         if (c.p) (void)hipHostFree(c.p);
@@ -134,6 +140,65 @@ Bid Engine::from_host(const uint64_t *ct) {
     nodes_[id].kind = BlockNode::MAT;
     nodes_[id].dev = d;
     return id;
+}
+
+int Engine::from_host_many(const uint64_t *cts, size_t count, Bid *out) {
+    for (size_t i = 0; i < count; i++) out[i] = 0;
+    auto undo = [&](size_t n) {
+        for (size_t i = 0; i < n; i++) release(out[i]);
+        for (size_t i = 0; i < count; i++) out[i] = 0;
+        return -1;
+    };
+    auto one_by_one = [&](size_t from) {
+        for (size_t i = from; i < count; i++)
+            if (!(out[i] = from_host(cts + i * BIG_CT))) return undo(i);
+        return 0;
+    };
+    if (planner || count < 4) return one_by_one(0);
+    (void)hipSetDevice(ctx.device);
+    // staging: [count x 2049 words][count destination pointers], pinned on the host and mirrored on the device: one copy,
+    // one scatter launch (pool blocks are not neighbours once the free list has been through a few operations)
+    constexpr size_t MAX_BATCH = 2048;               // 33.6 MB per pass
+    for (size_t done = 0; done < count;) {
+        const size_t n = std::min(MAX_BATCH, count - done);
+        const size_t words = n * BIG_CT + n;
+        if (upload_words_ < words) {
+            if (upload_done_) (void)hipEventSynchronize(upload_done_);
+            if (upload_pin_) (void)hipHostFree(upload_pin_);
+            if (upload_dev_) { (void)hipStreamSynchronize(ctx.stream); (void)hipFree(upload_dev_); }
+            upload_pin_ = upload_dev_ = nullptr;
+            upload_words_ = 0;
+            const size_t want = std::max<size_t>(n, 260) * (BIG_CT + 1);
+            void *hp = nullptr, *dp = nullptr;
+            if (hipHostMalloc(&hp, want * 8, hipHostMallocDefault) == hipSuccess && hipMalloc(&dp, want * 8) == hipSuccess) {
+                upload_pin_ = static_cast<uint64_t *>(hp);
+                upload_dev_ = static_cast<uint64_t *>(dp);
+                upload_words_ = want;
+            } else {
+                if (hp) (void)hipHostFree(hp);
+                if (dp) (void)hipFree(dp);
+            }
+        }
+        if (!upload_pin_ || (!upload_done_ && hipEventCreateWithFlags(&upload_done_, hipEventDisableTiming) != hipSuccess))
+            return one_by_one(done);                 // no staging memory: block by block
+        (void)hipEventSynchronize(upload_done_);     // the previous copy has left the pinned buffer (no-op before the first)
+        std::memcpy(upload_pin_, cts + done * BIG_CT, n * BIG_CT * 8);
+        for (size_t k = 0; k < n; k++) {
+            uint64_t *d = alloc_block();
+            if (!d) return undo(done + k);
+            Bid id = new_node();
+            nodes_[id].kind = BlockNode::MAT;
+            nodes_[id].dev = d;
+            out[done + k] = id;
+            upload_pin_[n * BIG_CT + k] = (uint64_t)(uintptr_t)d;
+        }
+        if (hipMemcpyAsync(upload_dev_, upload_pin_, words * 8, hipMemcpyHostToDevice, ctx.stream) != hipSuccess) return undo(done + n);
+        (void)hipEventRecord(upload_done_, ctx.stream);
+        if (launch_scatter_blocks(upload_dev_, reinterpret_cast<uint64_t *const *>(upload_dev_ + n * BIG_CT), (int)n, ctx.stream) != hipSuccess)
+            return undo(done + n);
+        done += n;
+    }
+    return 0;
 }
 
 Bid Engine::from_device(const uint64_t *d_ct) {

@@ -61,6 +61,9 @@ class Engine {
     // ---- block graph (all returned ids carry one reference owned by the caller) ----
     Bid triv(int v);
     Bid from_host(const uint64_t *ct);          // uploads 2049 words
+    // `count` ciphertexts of 2049 words each, back to back on the host: one copy through a pinned staging buffer and one
+    // scatter launch into the pool blocks instead of one pageable copy (~10 us) per block
+    int from_host_many(const uint64_t *cts, size_t count, Bid *out);
     Bid from_device(const uint64_t *d_ct);      // D2D copy
     Bid lin(const Term *terms, size_t n, int konst);
     Bid pbs(Bid x, int lut);
@@ -140,6 +143,9 @@ class Engine {
 
     // device block pool
     std::vector<void *> chunks_;
+    uint64_t *upload_pin_ = nullptr, *upload_dev_ = nullptr;   // staging of from_host_many: pinned host side, device side
+    size_t upload_words_ = 0;
+    hipEvent_t upload_done_ = nullptr;           // the last copy out of upload_pin_
     std::vector<uint64_t *> free_blocks_;
     uint64_t live_dev_blocks_ = 0;
     uint64_t planner_tokens_ = 0;

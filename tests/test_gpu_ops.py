@@ -283,3 +283,25 @@ def test_eq_ignore_case_on_byte_pairs(product):
         assert ck.decrypt_char(o) == int(lower(a) == lower(b)), (hex(a), hex(b))
     assert [ck.decrypt_char(x) for x in extra] == [1, 1, 0]
     assert sk.stats()["max_input_sum_c2"] <= 64
+
+
+def test_string_upload_in_one_staged_copy(oracle_gpu):
+    """fhs_upload_string: runs of neighbouring pool blocks are filled by ONE staged copy; a fragmented pool (released
+    characters in between) falls back to shorter runs and single blocks.  What comes back is what went up."""
+    sk = oracle_gpu
+    from fhestring_amd.api import BIG_CT
+    rng = np.random.default_rng(7)
+    for n in (1, 5, 64, 300):
+        chars = rng.integers(0, 2**63, size=(n, 4, BIG_CT), dtype=np.uint64)
+        s = sk.upload_string(chars)
+        assert len(s) == n
+        for i in sorted({0, n // 2, n - 1}):
+            assert np.array_equal(s[i].download(), chars[i])
+        if n == 64:                                  # punch holes into the free list, then upload again
+            keep = [s[i] for i in range(0, n, 3)]
+            del s
+            t = sk.upload_string(chars[::-1].copy())
+            assert all(np.array_equal(t[i].download(), chars[n - 1 - i]) for i in (0, 1, 31, 63))
+            assert all(np.array_equal(k.download(), chars[3 * i]) for i, k in enumerate(keep))
+    one = rng.integers(0, 2**63, size=(4, BIG_CT), dtype=np.uint64)
+    assert np.array_equal(sk.upload_char(one).download(), one)
