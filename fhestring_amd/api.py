@@ -228,7 +228,7 @@ class MyClientKey:
 
     def encrypt_str_raw(self, text, padding):
         data = text.encode("ascii") if isinstance(text, str) else bytes(text)
-        out = np.zeros((len(data) + padding, 4, BIG_CT), np.uint64)
+        out = np.empty((len(data) + padding, 4, BIG_CT), np.uint64)      # every word is written by the call
         rc = self._L.fhs_client_encrypt_str(self._h, data, len(data), int(padding), _ptr(out))
         if rc != 0:
             raise AssertionError("The input string must only contain ascii letters and not include null characters")

@@ -7,7 +7,11 @@
 // generator state used for anything secret.  fhs_client_create_insecure_seeded derives the ChaCha key from a
 // 64-bit seed instead: reproducible keys for tests, benchmarks and multi-rank runs -- never for real data.
 #include <sys/random.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -31,10 +35,55 @@ constexpr int PBS_BASE_LOG = 23;
 struct ChaKey { uint32_t w[8]; };
 enum Domain : uint32_t { DOM_SECRET = 1, DOM_MASK = 2, DOM_NOISE = 3 };
 
+#if defined(__x86_64__)
+// Eight consecutive ChaCha20 blocks at once (one block per 32-bit lane of a 256-bit register): the same keystream as the
+// scalar block function, ~4x faster -- client-side encryption of a string is 16 KB of mask per block.
+__attribute__((target("avx2"))) void chacha20_blocks8(const uint32_t st[16], uint32_t out[128]) {
+    __m256i x[16], in[16];
+    for (int i = 0; i < 16; i++) in[i] = _mm256_set1_epi32((int)st[i]);
+    in[12] = _mm256_add_epi32(in[12], _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7));
+    for (int i = 0; i < 16; i++) x[i] = in[i];
+#define FHS_ROTL(v, n) _mm256_or_si256(_mm256_slli_epi32(v, n), _mm256_srli_epi32(v, 32 - (n)))
+    const __m256i rot16 = _mm256_setr_epi8(2, 3, 0, 1, 6, 7, 4, 5, 10, 11, 8, 9, 14, 15, 12, 13,
+                                           2, 3, 0, 1, 6, 7, 4, 5, 10, 11, 8, 9, 14, 15, 12, 13);
+    const __m256i rot8 = _mm256_setr_epi8(3, 0, 1, 2, 7, 4, 5, 6, 11, 8, 9, 10, 15, 12, 13, 14,
+                                          3, 0, 1, 2, 7, 4, 5, 6, 11, 8, 9, 10, 15, 12, 13, 14);
+#define FHS_QR(a, b, c, d)                                                                       \
+    x[a] = _mm256_add_epi32(x[a], x[b]); x[d] = _mm256_shuffle_epi8(_mm256_xor_si256(x[d], x[a]), rot16); \
+    x[c] = _mm256_add_epi32(x[c], x[d]); x[b] = _mm256_xor_si256(x[b], x[c]); x[b] = FHS_ROTL(x[b], 12);  \
+    x[a] = _mm256_add_epi32(x[a], x[b]); x[d] = _mm256_shuffle_epi8(_mm256_xor_si256(x[d], x[a]), rot8);  \
+    x[c] = _mm256_add_epi32(x[c], x[d]); x[b] = _mm256_xor_si256(x[b], x[c]); x[b] = FHS_ROTL(x[b], 7);
+    for (int r = 0; r < 10; r++) {
+        FHS_QR(0, 4, 8, 12) FHS_QR(1, 5, 9, 13) FHS_QR(2, 6, 10, 14) FHS_QR(3, 7, 11, 15)
+        FHS_QR(0, 5, 10, 15) FHS_QR(1, 6, 11, 12) FHS_QR(2, 7, 8, 13) FHS_QR(3, 4, 9, 14)
+    }
+#undef FHS_QR
+#undef FHS_ROTL
+    for (int i = 0; i < 16; i++) x[i] = _mm256_add_epi32(x[i], in[i]);
+    // word i of block b sits in lane b of x[i]: two 8 x 8 transposes (words 0-7, words 8-15) give every block its 64 bytes
+    for (int half = 0; half < 2; half++) {
+        __m256i *v = x + 8 * half;
+        const __m256i t0 = _mm256_unpacklo_epi32(v[0], v[1]), t1 = _mm256_unpackhi_epi32(v[0], v[1]);
+        const __m256i t2 = _mm256_unpacklo_epi32(v[2], v[3]), t3 = _mm256_unpackhi_epi32(v[2], v[3]);
+        const __m256i t4 = _mm256_unpacklo_epi32(v[4], v[5]), t5 = _mm256_unpackhi_epi32(v[4], v[5]);
+        const __m256i t6 = _mm256_unpacklo_epi32(v[6], v[7]), t7 = _mm256_unpackhi_epi32(v[6], v[7]);
+        const __m256i u0 = _mm256_unpacklo_epi64(t0, t2), u1 = _mm256_unpackhi_epi64(t0, t2);   // blocks 0|4, 1|5 words 0-3
+        const __m256i u2 = _mm256_unpacklo_epi64(t1, t3), u3 = _mm256_unpackhi_epi64(t1, t3);   // blocks 2|6, 3|7 words 0-3
+        const __m256i u4 = _mm256_unpacklo_epi64(t4, t6), u5 = _mm256_unpackhi_epi64(t4, t6);   // ... words 4-7
+        const __m256i u6 = _mm256_unpacklo_epi64(t5, t7), u7 = _mm256_unpackhi_epi64(t5, t7);
+        const __m256i r[8] = {_mm256_permute2x128_si256(u0, u4, 0x20), _mm256_permute2x128_si256(u1, u5, 0x20),
+                              _mm256_permute2x128_si256(u2, u6, 0x20), _mm256_permute2x128_si256(u3, u7, 0x20),
+                              _mm256_permute2x128_si256(u0, u4, 0x31), _mm256_permute2x128_si256(u1, u5, 0x31),
+                              _mm256_permute2x128_si256(u2, u6, 0x31), _mm256_permute2x128_si256(u3, u7, 0x31)};
+        for (int b = 0; b < 8; b++) _mm256_storeu_si256(reinterpret_cast<__m256i *>(out + 16 * b + 8 * half), r[b]);
+    }
+}
+#endif
+
 struct Rng {
     uint32_t st[16];
-    uint32_t buf[16];
-    int pos = 16;
+    uint32_t buf[128];                                // up to 8 blocks of keystream
+    int pos = 0, have = 0;                            // 32-bit words consumed / available
     Rng() { std::memset(st, 0, sizeof(st)); }
     Rng(const ChaKey &k, uint64_t stream, uint32_t domain) {
         st[0] = 0x61707865; st[1] = 0x3320646e; st[2] = 0x79622d32; st[3] = 0x6b206574;   // "expand 32-byte k"
@@ -52,6 +101,15 @@ struct Rng {
         x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
     }
     void refill() {
+#if defined(__x86_64__)
+        static const bool avx2 = __builtin_cpu_supports("avx2");
+        if (avx2 && st[12] <= 0xFFFFFFF0u) {          // (the counter's carry into the nonce word stays on the scalar path)
+            chacha20_blocks8(st, buf);
+            st[12] += 8;
+            pos = 0; have = 128;
+            return;
+        }
+#endif
         uint32_t x[16];
         std::memcpy(x, st, sizeof(x));
         for (int r = 0; r < 10; r++) {
@@ -60,13 +118,21 @@ struct Rng {
         }
         for (int i = 0; i < 16; i++) buf[i] = x[i] + st[i];
         if (++st[12] == 0) st[13] += 0x100;           // counter overflow spills above the domain byte
-        pos = 0;
+        pos = 0; have = 16;
     }
     uint64_t next() {
-        if (pos > 14) refill();
+        if (pos + 2 > have) refill();
         const uint64_t v = (uint64_t)buf[pos] | ((uint64_t)buf[pos + 1] << 32);
         pos += 2;
         return v;
+    }
+    void fill(uint64_t *out, size_t n) {              // n draws, same stream as n calls of next()
+        while (n) {
+            if (pos + 2 > have) refill();
+            const size_t k = std::min<size_t>(n, (size_t)(have - pos) / 2);
+            std::memcpy(out, buf + pos, k * 8);       // little-endian host: two 32-bit words = one draw, low word first
+            pos += (int)(2 * k); out += k; n -= k;
+        }
     }
     double unit() { return ((double)(next() >> 11) + 1.0) * (1.0 / 9007199254740992.0); }
     uint64_t noise(double std_frac) {
@@ -205,11 +271,10 @@ void keygen_mb2(fhs_client *ck) {
 }
 
 void encrypt_block(fhs_client *ck, uint64_t m, uint64_t *ct) {
+    ck->enc_mask.fill(ct, BIG_N);
     uint64_t acc = 0;
-    for (int j = 0; j < BIG_N; j++) {
-        ct[j] = ck->enc_mask.next();
-        acc += ct[j] * ck->glwe_sk[j];
-    }
+    const uint64_t *sk = ck->glwe_sk.data();
+    for (int j = 0; j < BIG_N; j++) acc += ct[j] & ((uint64_t)0 - sk[j]);   // binary key
     ct[BIG_N] = acc + ck->enc_noise.noise(GLWE_NOISE) + (m << DELTA_LOG);
 }
 uint64_t decrypt_block(const fhs_client *ck, const uint64_t *ct) {
@@ -242,6 +307,14 @@ void fhs_chacha20_block(const uint32_t key[8], uint32_t counter, const uint32_t 
     r.st[12] = counter; r.st[13] = nonce[0]; r.st[14] = nonce[1]; r.st[15] = nonce[2];
     r.refill();
     for (int i = 0; i < 16; i++) out[i] = r.buf[i];
+}
+// diagnostic: n 64-bit draws of the generator from that state (the keystream in order, whichever block routine made it)
+void fhs_chacha20_stream(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3], uint64_t *out, size_t n) {
+    ChaKey k;
+    for (int i = 0; i < 8; i++) k.w[i] = key[i];
+    Rng r(k, 0, 0);
+    r.st[12] = counter; r.st[13] = nonce[0]; r.st[14] = nonce[1]; r.st[15] = nonce[2];
+    for (size_t i = 0; i < n; i++) out[i] = r.next();
 }
 int fhs_client_create(fhs_client **out) {   // MyClientKey::from_params (client_key.rs:30-35): OS-seeded CSPRNG
     if (!out) return FHS_ERR_ARG;

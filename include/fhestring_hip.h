@@ -374,6 +374,9 @@ int fhs_client_create(fhs_client **out);                                 /* from
 int fhs_client_create_insecure_seeded(uint64_t seed, fhs_client **out);
 /* Diagnostic: one block of the generator's ChaCha20 (RFC 8439 2.3.2 known-answer test in tests/test_cabi.py). */
 void fhs_chacha20_block(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3], uint32_t out[16]);
+/* Diagnostic: n 64-bit draws from that state, i.e. the keystream of consecutive blocks in order (the generator makes
+ * eight blocks at a time with AVX2 where the CPU has it: same stream as the scalar block function). */
+void fhs_chacha20_stream(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3], uint64_t *out, size_t n);
 void fhs_client_destroy(fhs_client *ck);
 const uint64_t *fhs_client_bsk(const fhs_client *ck);                    /* get_server_key :37-39 */
 const uint64_t *fhs_client_ksk(const fhs_client *ck);
