@@ -24,8 +24,11 @@ namespace fhs {
 namespace {
 using namespace fftdev;
 
-constexpr int F4_WAVE_BYTES = 8704;                 // 544 slots of 16 B per wavefront (4 x 8704 = 34 816 B per WG)
-__device__ __forceinline__ int pslot(int n) { return n + (n >> 4); }     // n < 512 -> < 544
+// One pad slot after every 8 points: layout A' puts consecutive lanes on consecutive slots, B' (72 a + 9 r + b) too, and
+// C' becomes 9 lane + c -- every group of 8 lanes covers all banks with its 16-byte accesses.  (With a pad every 16
+// points C' was 8 lane + c + (lane >> 1): two lanes per bank group; 22 % of the LDS-active cycles were bank conflicts.)
+constexpr int F4_WAVE_BYTES = 9216;                 // 576 slots of 16 B per wavefront (4 x 9216 = 36 864 B per WG)
+__device__ __forceinline__ int pslot(int n) { return n + (n >> 3); }     // n < 512 -> < 576
 
 typedef const __attribute__((address_space(1))) double *gdptr_t;
 struct tw_t { double r, i; };
@@ -75,7 +78,7 @@ template <bool INV> __device__ __forceinline__ void stagesA(cplx (&z)[8], tw_t w
 
 // one ciphertext on the 4 wavefronts of the calling workgroup.
 // WIDE: four separate LDS areas per workgroup (accumulator staging | cross-half exchange | private transposes | published
-// transform; 4 x 34 816 B, one workgroup per CU) instead of one area reused for everything.  Half of the 8 workgroup
+// transform; 4 x 36 864 B, one workgroup per CU) instead of one area reused for everything.  Half of the 8 workgroup
 // barriers per iteration only kept a reader ahead of the NEXT writer of a shared area; with an area of its own every
 // exchange is rewritten only after a later barrier that all its readers have passed, and 4 barriers remain (staged
 // accumulator visible, forward cross stage visible, transform published, inverse cross stage visible).  A lone
@@ -111,7 +114,8 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
     const tw_t t4 = ld_tw(weff0, 128 + eC), t2 = ld_tw(weff0, 256 + 2 * eC);
     const tw_t t1a = ld_tw(weff0, 512 + 4 * eC), t1b = ld_tw(weff0, 512 + 4 * eC + 2);
 
-    // acc[r]: coefficient k(r) = 512 h + lane + 64 (r & 7) + 1024 (r >> 3) of polynomial j
+    // acc[r]: coefficient k(r) = 512 h + lane + 64 (r & 7) + 1024 (r >> 3) of polynomial j, MINUS ONE (the offset makes
+    // the rotate-and-subtract exact in five operations, fft_device.h: rot_sub_hi_compl)
     const uint32_t k0 = 512 * h + lane;
     uint64_t acc[16];
     {
@@ -128,12 +132,13 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
                 v = lut[(n - s) & (POLY_N - 1)];
                 if ((n < s) != neg) v = (uint64_t)0 - v;
             }
-            acc[r] = v;
+            acc[r] = v - 1;
         }
     }
 #pragma unroll
     for (int r = 0; r < 16; r++) stage[64 + k0 + 64 * (r & 7) + 1024 * (r >> 3)] = acc[r];
     if (h == 1) stage[lane] = acc[15];                // row 31 again in front of row 0 (see the rotated read)
+    else stage[64 + 2048 + lane] = acc[0];            // and row 0 again behind row 31: rows are read in pairs
 
     // the mask element of the NEXT iteration is requested one iteration ahead (ks[LWE_N], the body, is a valid address):
     // for a lone ciphertext its global-memory round trip at the top of every iteration was pure latency
@@ -154,23 +159,33 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         // register; this wave's register r is row 8 h + (r & 7) + 16 (r >> 3)), borrowing lanes one row lower
         const uint32_t sl = s & 63, sh = s >> 6;
         const bool borrow = (uint32_t)lane < sl;
-        const uint64_t negmask = neg ? ~0ull : 0ull;
+        const uint64_t keep_unless_wrapped = neg ? 0ull : ~0ull;
         const uint64_t *vbase = stage + (((uint32_t)lane - sl) & 63) + (borrow ? 0 : 64);
         // as in fft_kernels.hip: the index wrapped where 64 row + lane < s (one vector compare per row against a per-lane
         // threshold), and the reads run RW rows ahead of their use instead of paying one LDS round trip each
         const int32_t thr = (int32_t)s - lane;
+        // rows in pairs (one address, ds_read2st64_b64): this wave's register pair (r, r + 1) is two consecutive rows
         constexpr int RW = 8;
         uint64_t vq[RW];
 #pragma unroll
-        for (int k = 0; k < RW; k++) vq[k] = vbase[64 * ((8 * h + (k & 7) + 16 * (k >> 3) - sh) & 31)];
+        for (int k = 0; k < RW; k += 2) {
+            const uint64_t *pb = vbase + 64 * ((8 * h + (k & 7) + 16 * (k >> 3) - sh) & 31);
+            vq[k] = pb[0];
+            vq[k + 1] = pb[64];
+        }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = 8 * h + (r & 7) + 16 * (r >> 3);
             const uint64_t v = vq[r % RW];
-            if (r + RW < 16) vq[r % RW] = vbase[64 * ((8 * h + ((r + RW) & 7) + 16 * ((r + RW) >> 3) - sh) & 31)];
+            if ((r & 1) && r + RW - 1 < 16) {
+                const int q = r + RW - 1;
+                const uint64_t *pb = vbase + 64 * ((8 * h + (q & 7) + 16 * (q >> 3) - sh) & 31);
+                vq[(r - 1) % RW] = pb[0];
+                vq[r % RW] = pb[64];
+            }
             const uint64_t wrapmask = __builtin_amdgcn_ballot_w64(64 * row < thr);
-            const uint32_t dhi = rot_sub_hi(v, acc[r], wrapmask ^ negmask);
-            const int32_t dig = (int32_t)(dhi + 0x100u) >> 9;
+            const uint32_t nhi = rot_sub_hi_compl(v, acc[r], wrapmask ^ keep_unless_wrapped);
+            const int32_t dig = (int32_t)(0xFFu - nhi) >> 9;
             if (r < 8) z[r].r = (double)dig; else z[r - 8].i = (double)dig;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -212,9 +227,9 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         for (int r = 0; r < 8; r++) mine[pslot(lane + 64 * r)] = z[r];
         __builtin_amdgcn_wave_barrier();
         {
-            const cplx *rd = mine + pslot(64 * (lane >> 3)) + (lane & 7);     // pslot(64 a + 8 r + b) = 68 a + 8 r + (r >> 1) + b
+            const cplx *rd = mine + pslot(64 * (lane >> 3)) + (lane & 7);     // pslot(64 a + 8 r + b) = 72 a + 9 r + b
 #pragma unroll
-            for (int r = 0; r < 8; r++) z[r] = rd[8 * r + (r >> 1)];
+            for (int r = 0; r < 8; r++) z[r] = rd[9 * r];
         }
         __builtin_amdgcn_wave_barrier();
         {
@@ -225,11 +240,11 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         {
             cplx *wr = mine + pslot(64 * (lane >> 3)) + (lane & 7);
 #pragma unroll
-            for (int r = 0; r < 8; r++) wr[8 * r + (r >> 1)] = z[r];
+            for (int r = 0; r < 8; r++) wr[9 * r] = z[r];
         }
         __builtin_amdgcn_wave_barrier();
         {
-            const cplx *rd = mine + 8 * lane + (lane >> 1);                   // pslot(8 lane + c) = 8 lane + c + (lane >> 1)
+            const cplx *rd = mine + 9 * lane;                                 // pslot(8 lane + c) = 9 lane + c
 #pragma unroll
             for (int c = 0; c < 8; c++) z[c] = rd[c];
         }
@@ -267,7 +282,7 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
             stage8<true, 4>(z, t4, t4);
         }
         {
-            cplx *wr = mine + 8 * lane + (lane >> 1);
+            cplx *wr = mine + 9 * lane;
 #pragma unroll
             for (int c = 0; c < 8; c++) wr[c] = z[c];
         }
@@ -275,7 +290,7 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         {
             const cplx *rd = mine + pslot(64 * (lane >> 3)) + (lane & 7);
 #pragma unroll
-            for (int r = 0; r < 8; r++) z[r] = rd[8 * r + (r >> 1)];
+            for (int r = 0; r < 8; r++) z[r] = rd[9 * r];
         }
         __builtin_amdgcn_wave_barrier();
         {
@@ -286,7 +301,7 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         {
             cplx *wr = mine + pslot(64 * (lane >> 3)) + (lane & 7);
 #pragma unroll
-            for (int r = 0; r < 8; r++) wr[8 * r + (r >> 1)] = z[r];
+            for (int r = 0; r < 8; r++) wr[9 * r] = z[r];
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -317,6 +332,7 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
             stage[64 + k0 + 64 * r] = acc[r];
             acc[r + 8] += to_torus(z[r].i);
             stage[64 + k0 + 64 * r + 1024] = acc[r + 8];
+            if (r == 0 && h == 0) stage[64 + 2048 + lane] = acc[0];
             if (r == 7 && h == 1) stage[lane] = acc[15];
         }
     }
@@ -326,11 +342,11 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int n = k0 + 64 * (r & 7) + 1024 * (r >> 3);
-            if (n == 0) out[0] = acc[r];
-            else out[POLY_N - n] = (uint64_t)0 - acc[r];
+            if (n == 0) out[0] = acc[r] + 1;
+            else out[POLY_N - n] = (uint64_t)0 - (acc[r] + 1);
         }
     } else if (k0 == 0) {
-        out[BIG_N] = acc[0];
+        out[BIG_N] = acc[0] + 1;
     }
 }
 

@@ -26,6 +26,7 @@ for B in [int(a) for a in args] or [64, 512, 1024, 2048]:
         ctx.pbs_batch(cts, idx, luts)
     wall = (time.time() - t) / 3
     kt = ctx.kernel_timing(reset=True)
-    print("B=%5d  blind_rotate %.2f ms  keyswitch %.3f ms  wall %.1f ms  -> %.0f PBS/s (kernels)" % (
-        B, kt["blind_rotate_ms"], kt["keyswitch_ms"], wall * 1e3,
-        B / ((kt["blind_rotate_ms"] + kt["keyswitch_ms"]) * 1e-3)))
+    br = kt["blind_rotate_ms"] if kt["n_blind_rotate"] else kt["fft4_ms"]      # narrow batches run the 4-wavefront kernel
+    print("B=%5d  blind_rotate %.3f ms%s  keyswitch %.3f ms  wall %.1f ms  -> %.0f PBS/s (kernels)" % (
+        B, br, "" if kt["n_blind_rotate"] else " (fft4)", kt["keyswitch_ms"], wall * 1e3,
+        B / ((br + kt["keyswitch_ms"]) * 1e-3)))
