@@ -319,6 +319,12 @@ class FheAsciiChar:
         self.sk.ctx._check(self.sk.ctx._L.fhs_char_sum_c2(self.sk.ctx._h, self.h, C.byref(v)))
         return int(v.value)
 
+    def trivial_value(self):
+        """The byte if every block of the handle is a trivial ciphertext (what constant folding left), else None."""
+        t, v = C.c_int(0), C.c_uint8(0)
+        self.sk.ctx._check(self.sk.ctx._L.fhs_trivial_value(self.sk.ctx._h, self.h, C.byref(t), C.byref(v)))
+        return int(v.value) if t.value else None
+
     def download(self):
         out = np.zeros((4, BIG_CT), np.uint64)
         self.sk.flush()                      # (collective in level-parallel mode)

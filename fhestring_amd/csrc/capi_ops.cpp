@@ -443,6 +443,18 @@ int fhs_char_sum_c2(fhs_ctx *c, fhs_char_t h, uint64_t *out) {
     *out = (uint64_t)m;
     return FHS_OK;
 }
+int fhs_trivial_value(fhs_ctx *c, fhs_char_t h, int *is_trivial, uint8_t *value) {
+    if (!ok(c, h) || !is_trivial || !value) return bad(c);
+    const Bid *b = c->eng.char_blocks(h);
+    unsigned v = 0;
+    *is_trivial = 1;
+    for (int i = 0; i < 4; i++) {
+        if (!c->eng.is_triv(b[i])) { *is_trivial = 0; *value = 0; return FHS_OK; }
+        v += (unsigned)(c->eng.triv_val(b[i]) & 15) << (2 * i);      // carries add up like in a decryption
+    }
+    *value = (uint8_t)(v & 255);
+    return FHS_OK;
+}
 int fhs_level_widths(fhs_ctx *c, uint32_t *out, size_t cap, size_t *n) {
     if (!c || !n) return bad(c);
     const auto &w = c->eng.stats.level_widths;

@@ -359,6 +359,10 @@ int fhs_get_stats(fhs_ctx *ctx, fhs_stats *out);
  * refreshes a block above 4 by itself when its handle is used as an operand; a host that downloads such a block and
  * uploads it again (uploads count as 1) has to bootstrap it first -- this is the query for that. */
 int fhs_char_sum_c2(fhs_ctx *ctx, fhs_char_t h, uint64_t *out);
+/* Constant folding made visible: *is_trivial = 1 and *value = the byte if all four blocks of the handle are trivial
+ * (plaintext) ciphertexts -- what an operation on trivially encrypted inputs folds to, without a GPU (planner contexts
+ * included).  The CPU tests evaluate the re-associated DAGs on every byte pair this way. */
+int fhs_trivial_value(fhs_ctx *ctx, fhs_char_t h, int *is_trivial, uint8_t *value);
 /* Width (PBS count) of every dependency level executed since the last fhs_reset_stats, in execution order (the shape
  * of the levelized batches: what a CPU baseline has to run to do the same work).  *n = number of levels; out may be
  * NULL to query it. */

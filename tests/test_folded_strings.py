@@ -1,0 +1,189 @@
+"""The product's string layer evaluated on the CPU by constant folding (no GPU, no oracle in the product path).
+
+Trivially encrypted inputs make every bootstrap of a DAG fold to its look-up value (Engine::pbs on a trivial block,
+luts.h: lut_eval with the padding-bit rule) and every linear combination to a constant mod 32, so a planner context
+computes what the DAG means.  `fhs_trivial_value` reads the result.  That checks the LOGIC of both formulations --
+weights, look-up tables, trees, the negacyclic tricks -- against
+
+* the reference's own test literals (tests/golden/ref_tests.json), both modes, and
+* the loop-for-loop restatement of the reference on the clear-u8 char model (oracle/strings.py with ClearChar) on
+  random strings, patterns and paddings, and on every byte pair for the character-level formulations.
+
+Noise bookkeeping and the kernels are the GPU tests' business."""
+import random
+
+import pytest
+
+from oracle import strings as ostr
+from oracle.radix import ClearChar
+from golden_util import load_vectors, run_vector, check_vector
+
+VECTORS = load_vectors()
+WS = " \t\n\x0b\x0c\r"
+
+
+@pytest.fixture(scope="module")
+def folded():
+    from fhestring_amd.api import MyServerKey
+    sk = MyServerKey.planner()
+    sk.trivial_char = sk.trivial
+    yield sk
+    sk.close()
+
+
+def product_env(sk):
+    from fhestring_amd.api import FheString
+
+    def dec_c(c):
+        v = c.trivial_value()
+        assert v is not None, "the result did not fold to a constant"
+        return v
+    enc_s = lambda t, pad: FheString([sk.trivial(b) for b in ostr.pad_plain(t, pad)])
+    enc_p = lambda t: FheString([sk.trivial(b) for b in ostr.pad_plain(t, 0)])
+    dec_s = lambda s: ostr.truncate_plain([dec_c(c) for c in s.chars])
+    return sk, enc_s, enc_p, sk.trivial, dec_s, dec_c
+
+
+def clear_env():
+    ops = ostr.SplitOps(ClearChar)
+    ops.trivial_char = lambda v: ClearChar(v)
+    enc_s = lambda t, pad: [ClearChar(b) for b in ostr.pad_plain(t, pad)]
+    enc_p = lambda t: [ClearChar(b) for b in ostr.pad_plain(t, 0)]
+    return ops, enc_s, enc_p, ClearChar, lambda s: ostr.truncate_plain([c.v for c in s]), lambda c: c.v
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["as_written", "fused"])
+@pytest.mark.parametrize("v", VECTORS, ids=[v["name"] for v in VECTORS])
+def test_golden_vectors_by_constant_folding(folded, v, mode):
+    folded.set_mode(mode)
+    env = product_env(folded)
+    if "expected_panic" in v:
+        with pytest.raises(OverflowError, match=v["expected_panic"]):
+            run_vector(v, *env)
+        return
+    check_vector(v, run_vector(v, *env))
+    assert folded.stats(reset=True)["pbs_executed"] == 0         # everything folded: nothing was left pending
+
+
+def _rand_text(rnd, n, alphabet):
+    return "".join(rnd.choice(alphabet) for _ in range(n))
+
+
+def _cases(seed, count):
+    """Random vectors in the golden format: short strings over a small alphabet (so that patterns occur, repeat and
+    overlap), whitespace, upper / lower case, paddings 0-3."""
+    rnd = random.Random(seed)
+    abc = "abAB zZ\t_a"
+    out = []
+    for k in range(count):
+        n = rnd.randint(0, 9)
+        s = _rand_text(rnd, n, abc)
+        pad = rnd.randint(1, 3)
+        if s and rnd.random() < 0.6:
+            i = rnd.randrange(len(s))
+            p = s[i:i + rnd.randint(1, 3)]
+        else:
+            p = _rand_text(rnd, rnd.randint(1, 3), abc)
+        other = s if rnd.random() < 0.2 else (s.swapcase() if rnd.random() < 0.25 else _rand_text(rnd, rnd.randint(0, 9), abc))
+        if rnd.random() < 0.3 and s:
+            other = s[:rnd.randint(0, len(s))] + _rand_text(rnd, rnd.randint(0, 2), abc)
+        to = _rand_text(rnd, rnd.randint(0, 4), abc)
+        base = {"string": s, "pad": pad, "name": "rand%d" % k}
+        for op in ("contains", "starts_with", "ends_with", "find", "rfind"):
+            out.append(dict(base, op=op, pattern=p))
+        for op in ("to_upper", "to_lower", "trim_end", "trim_start", "trim", "is_empty", "len"):
+            out.append(dict(base, op=op))
+        for op in ("eq", "eq_ignore_case", "lt", "le", "gt", "ge", "concatenate"):
+            out.append(dict(base, op=op, other=other, other_pad=rnd.randint(1, 3)))
+        out.append(dict(base, op="replace", **{"from": p, "to": to}))
+        out.append(dict(base, op="replacen", n=rnd.randint(0, 3), **{"from": p, "to": to}))
+        out.append(dict(base, op="repeat", n=rnd.randint(0, 3)))
+        out.append(dict(base, op="strip_prefix", pattern=p))
+        out.append(dict(base, op="strip_suffix", pattern=p))
+    return out
+
+
+def _same(v, got, want):
+    assert got == want, (v["op"], {k: v[k] for k in v if k not in ("name",)}, "product", got, "reference model", want)
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["as_written", "fused"])
+def test_random_strings_against_the_clear_model(folded, mode):
+    """Both formulations mean what the reference's loops mean (oracle/strings.py on plain bytes), op by op."""
+    folded.set_mode(mode)
+    penv, cenv = product_env(folded), clear_env()
+    for v in _cases(20261004 + mode, 60 if mode == 1 else 12):   # as written is O(n^2) host work per op: fewer, same shapes
+        try:
+            want = run_vector(v, *cenv)
+        except OverflowError:
+            with pytest.raises(OverflowError):
+                run_vector(v, *penv)
+            continue
+        _same(v, run_vector(v, *penv), want)
+
+
+def test_split_family_against_the_clear_model(folded):
+    folded.set_mode(1)
+    penv, cenv = product_env(folded), clear_env()
+    rnd = random.Random(77)
+    for k in range(25):
+        s = _rand_text(rnd, rnd.randint(1, 9), "ab, a")
+        p = rnd.choice([",", " ", "a", "ab", ", "])
+        base = {"string": s, "pad": rnd.randint(1, 2), "name": "split%d" % k, "pattern": p}
+        for op in ("split", "split_inclusive", "split_terminator", "rsplit", "rsplit_terminator", "rsplit_once"):
+            if op == "rsplit_once" and p not in s:
+                continue
+            v = dict(base, op=op)
+            _same(v, run_vector(v, *penv), run_vector(v, *cenv))
+        for op in ("splitn", "rsplitn"):
+            v = dict(base, op=op, n=rnd.randint(1, 4))
+            _same(v, run_vector(v, *penv), run_vector(v, *cenv))
+        v = {"string": s.replace(",", " "), "pad": 1, "name": "ws%d" % k, "op": "split_ascii_whitespace"}
+        _same(v, run_vector(v, *penv), run_vector(v, *cenv))
+
+
+def test_every_byte_pair_of_the_character_level_formulations(folded):
+    """eq_ignore_case, the comparisons and eq on one-character buffers for all 65 536 byte pairs (NUL included: a
+    buffer may hold it); case folds, whitespace and NUL tests on all 256 bytes."""
+    from fhestring_amd.api import FheString
+    sk = folded
+    sk.set_mode(1)
+    tr = [sk.trivial(v) for v in range(256)]
+    low = lambda x: x + 32 if 0x41 <= x <= 0x5A else x
+    for a in range(256):
+        sa = FheString([tr[a]])
+        for b in range(256):
+            sb = FheString([tr[b]])
+            got = (sk.eq_ignore_case(sa, sb).trivial_value(), sk.le(sa, sb).trivial_value(), sk.gt(sa, sb).trivial_value(),
+                   sk.eq(sa, sb).trivial_value())
+            assert got == (int(low(a) == low(b)), int(a <= b), int(a > b), int(a == b)), (a, b, got)
+    for a in range(256):
+        s = FheString([tr[0x41], tr[a], tr[0x42]])
+        up, lo = sk.to_upper(s)[1].trivial_value(), sk.to_lower(s)[1].trivial_value()
+        assert up == (a - 32 if 0x61 <= a <= 0x7A else a) and lo == low(a), (a, up, lo)
+        # x?y: a NUL or whitespace byte in the middle is kept by the trims; at the end it is trimmed (NUL: it is padding)
+        t = FheString([tr[0x41], tr[a]])
+        got = [c.trivial_value() for c in sk.trim_end(t).chars]
+        assert got == ([0x41, 0] if (a == 0 or chr(a) in WS) else [0x41, a]), (a, got)
+        assert sk.len(t).trivial_value() == (1 if a == 0 else 2) and sk.is_empty(FheString([tr[a]])).trivial_value() == int(a == 0)
+
+
+def test_comparisons_follow_the_first_difference_on_long_buffers(folded):
+    """The three-state tree over many positions: the first differing nibble decides, buffers of different length compare
+    through the longer one's tail."""
+    from fhestring_amd.api import FheString
+    sk = folded
+    sk.set_mode(1)
+    rnd = random.Random(3)
+    for _ in range(40):
+        n, m = rnd.randint(1, 60), rnd.randint(1, 60)
+        a = [rnd.choice([0x61, 0x62, 0x7A]) for _ in range(n)]
+        b = list(a[:m]) + [rnd.choice([0x61, 0x62]) for _ in range(max(0, m - n))]
+        if rnd.random() < 0.7 and b:
+            b[rnd.randrange(len(b))] = rnd.choice([0x60, 0x63])
+        pa, pb = rnd.randint(0, 3), rnd.randint(0, 3)
+        sa = FheString([sk.trivial(v) for v in a + [0] * pa])
+        sb = FheString([sk.trivial(v) for v in b + [0] * pb])
+        ba, bb = bytes(a), bytes(b)
+        got = tuple(f(sa, sb).trivial_value() for f in (sk.lt, sk.le, sk.gt, sk.ge, sk.eq))
+        assert got == (int(ba < bb), int(ba <= bb), int(ba > bb), int(ba >= bb), int(ba == bb)), (a, b, pa, pb, got)
