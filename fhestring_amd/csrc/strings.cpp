@@ -781,9 +781,12 @@ std::vector<FStr> Strings::split_family(int kind, const FStr &s, const FStr &pat
 // log_15-depth AND/OR trees.  Decrypts identically to the as-written mode.
 // ---------------------------------------------------------------------------------------------
 static Ref sum_refs(Engine *e, const Ref *r, size_t n) {
-    Term tt[16];
+    // any length: the callers bound the VALUE of the sum (15 flags, one-hot picks, noise budget), not the number of
+    // terms -- trivial blocks carry no noise and fold into the constant, so a sum over a mostly plaintext string can be
+    // long (first_index on 256 trivial windows: 64 blocks; found by tests/test_folded_strings.py)
+    std::vector<Term> tt(n);
     for (size_t i = 0; i < n; i++) tt[i] = {1, r[i].id()};
-    return Ref(e, e->lin(tt, n, 0));
+    return Ref(e, e->lin(tt.data(), n, 0));
 }
 
 Ref Strings::and_tree(std::vector<Ref> f) {

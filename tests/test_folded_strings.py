@@ -187,3 +187,70 @@ def test_comparisons_follow_the_first_difference_on_long_buffers(folded):
         ba, bb = bytes(a), bytes(b)
         got = tuple(f(sa, sb).trivial_value() for f in (sk.lt, sk.le, sk.gt, sk.ge, sk.eq))
         assert got == (int(ba < bb), int(ba <= bb), int(ba > bb), int(ba >= bb), int(ba == bb)), (a, b, pa, pb, got)
+
+
+def test_find_at_every_position_of_a_256_char_string(folded):
+    """BASELINE config 3's shape: the thermometer index over 254 windows (17 chunks of the prefix-OR tree: the 16th chunk
+    takes its predecessor's prefix and total, the last positions sit there), a match planted at every position in turn,
+    a second match behind it, and the miss."""
+    from fhestring_amd.api import FheString
+    sk = folded
+    sk.set_mode(1)
+    pat = FheString([sk.trivial(ord(c)) for c in "wxyz"])
+    base = [ord("a") + (i % 3) for i in range(256)]
+    tr = {v: sk.trivial(v) for v in set(base) | set(b"wxyz") | {0}}
+    for pos in list(range(0, 253)) + [None]:
+        t = list(base)
+        if pos is not None:
+            t[pos:pos + 4] = b"wxyz"
+            if pos + 9 <= 252:
+                t[pos + 5:pos + 9] = b"wxyz"             # a later match must not disturb the first
+        s = FheString([tr[v] for v in t] + [tr[0]])
+        assert sk.find(s, pat).trivial_value() == (255 if pos is None else pos), pos
+    for pos in (0, 100, 239, 240, 252):                   # rfind: the last match
+        t = list(base)
+        t[pos:pos + 4] = b"wxyz"
+        if pos >= 8:
+            t[pos - 8:pos - 4] = b"wxyz"
+        s = FheString([tr[v] for v in t] + [tr[0]])
+        assert sk.rfind(s, pat).trivial_value() == pos, pos
+
+
+def test_compaction_against_the_bubble_on_strings_with_holes(folded):
+    """bubble_zeroes_right: the routing network (prefix counts, LSB-first conditional moves) against the reference's
+    bubble (utils.rs:28-46) on buffers with NULs anywhere, lengths across several powers of two."""
+    from fhestring_amd.api import FheString
+    sk = folded
+    sk.set_mode(1)
+    rnd = random.Random(11)
+    ops = clear_env()[0]
+    for n in (1, 2, 3, 7, 8, 9, 31, 33, 64, 100):
+        for density in (0.1, 0.5, 0.9):
+            vals = [0 if rnd.random() < density else rnd.randint(1, 255) for _ in range(n)]
+            got = [c.trivial_value() for c in sk.bubble_zeroes_right(FheString([sk.trivial(v) for v in vals])).chars]
+            want = [c.v for c in ops.bubble_zeroes_right([ClearChar(v) for v in vals])] if n <= 33 else \
+                [v for v in vals if v] + [0] * vals.count(0)
+            assert got == want, (n, vals, got)
+
+
+def test_long_equalities_and_case_insensitive_equalities(folded):
+    from fhestring_amd.api import FheString
+    sk = folded
+    sk.set_mode(1)
+    rnd = random.Random(19)
+    for _ in range(30):
+        n = rnd.randint(1, 80)
+        a = [rnd.choice(b"abcXYZ_ 09") for _ in range(n)]
+        b = list(a)
+        kind = rnd.random()
+        if kind < 0.3:
+            b = [v ^ 0x20 if chr(v).isalpha() and rnd.random() < 0.5 else v for v in b]    # case only
+        elif kind < 0.6:
+            b[rnd.randrange(n)] ^= 0x20                       # one byte: a letter's case, or '_' / ' ' / digit changed
+        elif kind < 0.8:
+            b = b[:rnd.randint(0, n)]                         # a prefix
+        sa = FheString([sk.trivial(v) for v in a + [0] * rnd.randint(0, 3)])
+        sb = FheString([sk.trivial(v) for v in b + [0] * rnd.randint(0, 3)])
+        ba, bb = bytes(a), bytes(b)
+        got = (sk.eq(sa, sb).trivial_value(), sk.ne(sa, sb).trivial_value(), sk.eq_ignore_case(sa, sb).trivial_value())
+        assert got == (int(ba == bb), int(ba != bb), int(ba.lower() == bb.lower())), (a, b, got)

@@ -131,6 +131,24 @@ int main() {
         for (fhs_char_t h : keep) CHECK(fhs_release(c, h) == FHS_OK);
         CHECK(fhs_set_tick_balance(c, 0) == FHS_OK);
     }
+    {   // all-trivial inputs: every bootstrap folds at recording time (the CPU truth-table tests live on this path)
+        CHECK(fhs_set_mode(c, 1) == FHS_OK);
+        std::vector<fhs_char_t> s, p;
+        for (int i = 0; i < 257; i++) s.push_back(fhs_trivial(c, i == 256 ? 0 : (uint8_t)('a' + i % 3)));
+        for (char ch : std::string("wxyz")) p.push_back(fhs_trivial(c, (uint8_t)ch));
+        fhs_char_t r = 0;
+        int triv = 0;
+        uint8_t val = 0;
+        CHECK(fhs_str_find(c, s.data(), s.size(), p.data(), p.size(), &r) == FHS_OK);
+        CHECK(fhs_trivial_value(c, r, &triv, &val) == FHS_OK && triv == 1 && val == 255);
+        CHECK(fhs_str_rfind(c, s.data(), s.size(), p.data(), p.size(), &r) == FHS_OK);
+        CHECK(fhs_trivial_value(c, r, &triv, &val) == FHS_OK && triv == 1 && val == 255);
+        std::vector<fhs_char_t> out(s.size());
+        CHECK(fhs_bubble_zeroes_right(c, s.data(), s.size(), out.data()) == FHS_OK);
+        CHECK(fhs_str_compare(c, s.data(), s.size(), s.data(), s.size() - 3, 1, &r) == FHS_OK);   // le: the longer buffer has a non-NUL tail
+        CHECK(fhs_trivial_value(c, r, &triv, &val) == FHS_OK && triv == 1 && val == 0);
+        CHECK(fhs_flush(c) == FHS_OK);
+    }
     fhs_stats st;
     CHECK(fhs_get_stats(c, &st) == FHS_OK && st.pbs_executed > 1000 && st.max_input_sum_c2 <= FHS_NOISE_BUDGET_SUM_C2);
     size_t w0, w1, c0, c1;
