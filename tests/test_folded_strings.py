@@ -305,3 +305,26 @@ def test_longer_random_strings_against_the_clear_model(folded):
               dict(base, op="eq_ignore_case", other=s.swapcase(), other_pad=2)]
         for v in vs:
             _same(v, run_vector(v, *penv), run_vector(v, *cenv))
+
+
+def test_position_sharded_comparison_partials_combine_to_the_whole(folded):
+    """Multi-GPU position sharding of lt / le / gt / ge (fhs_str_compare_partial per range, fhs_flags_first_decides over
+    the ranges): any split of two equally long buffers gives the verdict of the whole comparison."""
+    from fhestring_amd.api import FheString
+    sk = folded
+    sk.set_mode(1)
+    rnd = random.Random(8)
+    for _ in range(25):
+        n = rnd.randint(2, 40)
+        a = [rnd.choice(b"abc") for _ in range(n)]
+        b = list(a)
+        for _k in range(rnd.randint(0, 2)):
+            b[rnd.randrange(n)] = rnd.choice(b"abcd")
+        ta, tb = [sk.trivial(v) for v in a], [sk.trivial(v) for v in b]
+        cuts = sorted(rnd.sample(range(1, n), min(n - 1, rnd.randint(1, 4))))
+        ranges = list(zip([0] + cuts, cuts + [n]))
+        for cmp, py in ((0, bytes(a) < bytes(b)), (1, bytes(a) <= bytes(b)), (2, bytes(a) > bytes(b)), (3, bytes(a) >= bytes(b))):
+            parts = [sk.compare_partial(FheString(ta[lo:hi]), FheString(tb[lo:hi]), cmp) for lo, hi in ranges]
+            got = sk.flags_first_decides([p[0] for p in parts], [p[1] for p in parts], tie=cmp in (1, 3)).trivial_value()
+            whole = sk._compare(FheString(ta), FheString(tb), cmp).trivial_value()
+            assert got == whole == int(py), (a, b, ranges, cmp, got, whole)
