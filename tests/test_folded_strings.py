@@ -328,3 +328,34 @@ def test_position_sharded_comparison_partials_combine_to_the_whole(folded):
             got = sk.flags_first_decides([p[0] for p in parts], [p[1] for p in parts], tie=cmp in (1, 3)).trivial_value()
             whole = sk._compare(FheString(ta), FheString(tb), cmp).trivial_value()
             assert got == whole == int(py), (a, b, ranges, cmp, got, whole)
+
+
+def test_baseline_configs_at_full_size_by_folding(folded):
+    """BASELINE configs 3-5 at their sizes (256 / 1024 / 4096 characters), as plaintext through the re-associated DAGs:
+    the same DAGs the GPU tests run on ciphertexts (tests/test_gpu_fullsize.py), checked here against python."""
+    from fhestring_amd.api import FheString
+    sk = folded
+    sk.set_mode(1)
+    rnd = random.Random(2026)
+    enc = lambda t, pad=1: FheString([sk.trivial(ord(c)) for c in t] + [sk.trivial(0)] * pad)
+    dec = lambda s: ostr.truncate_plain([c.trivial_value() for c in s.chars])
+    # config 4: replace on 1024 characters, from / to of 5, overlapping candidates, `to` with the pattern's prefix inside
+    text = list(_rand_text(rnd, 1024, "abc"))
+    for pos in (0, 7, 12, 500, 503, 1019):                 # 500 / 503 overlap: the earlier match wins, like str.replace
+        text[pos:pos + 5] = "xyxyz" if pos != 503 else "yzxyz"
+    text = "".join(text)
+    for frm, to in (("xyxyz", "xyQRS"), ("xyxyz", "q"), ("yz", "yzyz")):
+        assert dec(sk.replace(enc(text), enc(frm, 0), enc(to, 0))) == text.replace(frm, to), (frm, to)
+    # config 5: eq_ignore_case and <= on 4096 characters, equal up to case / differing at one late position / a prefix
+    a = _rand_text(rnd, 4096, "abcXYZ019 _")
+    for b in (a.swapcase(), a[:4000] + ("b" if a[4000] != "b" else "c") + a[4001:], a[:4095], a):
+        got = (sk.eq_ignore_case(enc(a), enc(b)).trivial_value(), sk.le(enc(a), enc(b)).trivial_value(),
+               sk.ge(enc(a), enc(b, 3)).trivial_value(), sk.eq(enc(a), enc(b, 2)).trivial_value())
+        assert got == (int(a.lower() == b.lower()), int(a <= b), int(a >= b), int(a == b)), (b[:8], got)
+    # config 2 at several sizes: contains with clear and with encrypted patterns, hit in the last window and miss
+    for n in (64, 65, 300):
+        t = _rand_text(rnd, n, "ab")
+        for p in (t[-4:], "abba" * 2, "c"):
+            assert sk.contains(enc(t), enc(p, 0)).trivial_value() == int(p in t), (n, p)
+            assert sk.contains_clear(enc(t), p).trivial_value() == int(p in t), (n, p)
+    assert sk.len(enc("x" * 300)).trivial_value() == 300 % 256
