@@ -789,6 +789,21 @@ static Ref sum_refs(Engine *e, const Ref *r, size_t n) {
     return Ref(e, e->lin(tt.data(), n, 0));
 }
 
+// Flags that are the SAME block (one bootstrap shared by several windows of a mostly plaintext string: the engine's
+// common-subexpression table hands out one node) count once in an AND / OR -- summed, they would come back as ONE term
+// with a coefficient of up to 15, i.e. 225 times the variance of a flag.
+static void distinct_flags(std::vector<Ref> &f) {
+    std::vector<Ref> out;
+    out.reserve(f.size());
+    std::vector<Bid> seen;
+    for (Ref &x : f) {
+        if (std::find(seen.begin(), seen.end(), x.id()) != seen.end()) continue;
+        seen.push_back(x.id());
+        out.push_back(x);
+    }
+    f.swap(out);
+}
+
 Ref Strings::and_tree(std::vector<Ref> f) {
     std::vector<Ref> cur;
     for (Ref &x : f) {
@@ -798,6 +813,8 @@ Ref Strings::and_tree(std::vector<Ref> f) {
     }
     if (cur.empty()) return trivial_block(e_, 1);
     while (cur.size() > 1) {
+        distinct_flags(cur);
+        if (cur.size() == 1) break;
         std::vector<Ref> nxt;
         for (size_t i = 0; i < cur.size(); i += 15) {
             const size_t n = std::min<size_t>(15, cur.size() - i);
@@ -818,6 +835,8 @@ Ref Strings::or_tree(std::vector<Ref> f) {
     }
     if (cur.empty()) return trivial_block(e_, 0);
     while (cur.size() > 1) {
+        distinct_flags(cur);
+        if (cur.size() == 1) break;
         std::vector<Ref> nxt;
         for (size_t i = 0; i < cur.size(); i += 15) {
             const size_t n = std::min<size_t>(15, cur.size() - i);
@@ -929,7 +948,11 @@ std::vector<Ref> Strings::prefix_or(const std::vector<Ref> &f) {
     std::vector<Ref> q, any;                 // q: exclusive prefix OR over whole chunks, any: the chunks' totals
     if (nchunks > 1) {
         any.resize(nchunks - 1);             // the last chunk's total is never needed
-        for (size_t j = 0; j + 1 < nchunks; j++) any[j] = pbs(sum_refs(e_, &f[15 * j], 15), LUT_NZ);
+        for (size_t j = 0; j + 1 < nchunks; j++) {
+            std::vector<Ref> grp(f.begin() + 15 * j, f.begin() + 15 * j + 15);
+            distinct_flags(grp);                              // an OR: a flag that occurs twice counts once (noise)
+            any[j] = pbs(sum_refs(e_, grp.data(), grp.size()), LUT_NZ);
+        }
         any.push_back(trivial_block(e_, 0));
         q = prefix_or(any);
     } else {
@@ -938,23 +961,22 @@ std::vector<Ref> Strings::prefix_or(const std::vector<Ref> &f) {
     auto depth = [&](const Ref &r) { return e_->node(r.id()).level; };
     for (size_t i = 0; i < n; i++) {
         const size_t j = i / 15, k = i % 15;
-        Term tt[16];
-        size_t m = 0;
-        for (size_t u = 0; u < k; u++) tt[m++] = {1, f[15 * j + u].id()};
+        std::vector<Ref> terms(f.begin() + 15 * j, f.begin() + 15 * j + k);
         // the 16th chunk's prefix is the OR of 16 totals, one level deeper than its neighbours': the previous chunk's
         // prefix and total say the same one level earlier (find on 256 characters ends one launch sooner)
         if (j >= 1 && k >= 1 && k <= 13 && depth(q[j]) > std::max(depth(q[j - 1]), depth(any[j - 1]))) {
-            tt[m++] = {1, q[j - 1].id()};
-            tt[m++] = {1, any[j - 1].id()};
-            p[i] = pbs(Ref(e_, e_->lin(tt, m, 0)), LUT_NZ);
+            terms.push_back(q[j - 1]);
+            terms.push_back(any[j - 1]);
+            distinct_flags(terms);
+            p[i] = pbs(sum_refs(e_, terms.data(), terms.size()), LUT_NZ);
             continue;
         }
-        tt[m++] = {1, q[j].id()};
         const bool q0 = e_->is_triv(q[j].id()) && e_->triv_val(q[j].id()) == 0;
         if (k == 0) { p[i] = q[j]; continue; }               // nothing of this chunk yet: the flag itself, no bootstrap
         if (k == 1 && q0) { p[i] = f[15 * j]; continue; }    // OR of one 0/1 flag
-        Ref sm(e_, e_->lin(tt, m, 0));       // <= 14 + 1
-        p[i] = pbs(sm, LUT_NZ);              // folds to a constant when everything is trivial
+        terms.push_back(q[j]);
+        distinct_flags(terms);               // an OR: the same flag twice counts once (<= 14 + 1 terms)
+        p[i] = pbs(sum_refs(e_, terms.data(), terms.size()), LUT_NZ);   // folds to a constant when everything is trivial
     }
     return p;
 }
@@ -1003,25 +1025,29 @@ FChar Strings::first_index(const std::vector<Ref> &before, const Ref &found) {
         }
         // add the blocks up within the noise budget: while the whole sum (+ the `absent` term) would pass it, merge
         // neighbours up to sum c^2 <= 60 and refresh each merged group (one value in 0..3: at most one block is non-zero)
+        // (variances are those of the SUMS: blocks of a mostly plaintext string share bootstrap outputs, their
+        // coefficients add up inside a sum)
+        auto var_of = [&](const std::vector<Ref> &v) {
+            return v.empty() ? (int64_t)0 : e_->sum_c2(v.size() == 1 ? v[0].id() : sum_refs(e_, v.data(), v.size()).id());
+        };
         for (;;) {
-            int64_t c2 = 0;
-            for (const Ref &b : blocks) c2 += e_->sum_c2(b.id());
-            if (blocks.size() <= 1 || c2 + 9 <= 48) break;
+            if (blocks.size() <= 1 || var_of(blocks) + 9 <= 48) break;
             std::vector<Ref> nxt, grp;
-            int64_t g2 = 0;
             auto close = [&] {
                 if (grp.empty()) return;
                 nxt.push_back(pbs(grp.size() == 1 ? grp[0] : sum_refs(e_, grp.data(), grp.size()), LUT_MSG));
                 grp.clear();
-                g2 = 0;
             };
             for (const Ref &b : blocks) {
-                const int64_t w = e_->sum_c2(b.id());
-                if (g2 + w > 60) close();
                 grp.push_back(b);
-                g2 += w;
+                if (grp.size() > 1 && var_of(grp) > 60) {     // b does not fit: close the group without it
+                    grp.pop_back();
+                    close();
+                    grp.push_back(b);
+                }
             }
             close();
+            if (nxt.size() >= blocks.size()) { blocks.swap(nxt); break; }   // every block on its own already: no progress to make
             blocks.swap(nxt);
         }
         Ref digit = blocks.empty() ? trivial_block(e_, 0) : (blocks.size() == 1 ? blocks[0] : sum_refs(e_, blocks.data(), blocks.size()));
@@ -1206,6 +1232,18 @@ Ref Strings::char_significant(const FChar &c) {
 FChar Strings::position_of(const std::vector<Ref> &pick, size_t off, const Ref *absent_flag, int absent_value) {
     const size_t W = pick.size();
     FChar r;
+    // At most one pick is set.  A block that serves as the pick of TWO positions (mostly plaintext strings: one shared
+    // bootstrap) can therefore never be set and is left out -- summed, its digits would add up to one large coefficient.
+    std::vector<bool> twice(W, false);
+    {
+        std::vector<std::pair<Bid, size_t>> ids;
+        ids.reserve(W);
+        for (size_t i = 0; i < W; i++)
+            if (!e_->is_triv(pick[i].id())) ids.push_back({pick[i].id(), i});
+        std::sort(ids.begin(), ids.end());
+        for (size_t a = 0; a + 1 < ids.size(); a++)
+            if (ids[a].first == ids[a + 1].first) twice[ids[a].second] = twice[ids[a + 1].second] = true;
+    }
     for (int blk = 0; blk < 4; blk++) {
         std::vector<Ref> cur;
         {
@@ -1221,6 +1259,7 @@ FChar Strings::position_of(const std::vector<Ref> &pick, size_t off, const Ref *
             };
             for (size_t i = 0; i < W; i++) {
                 const int dig = (int)(((i + off) >> (2 * blk)) & 3);
+                if (twice[i]) continue;
                 if (!dig || e_->is_triv(pick[i].id())) {
                     if (dig && e_->triv_val(pick[i].id())) {                                    // folds into the constant
                         if (m == 64) close();               // tt is full: never write tt[64] (either branch may fill it)
