@@ -305,3 +305,22 @@ def test_string_upload_in_one_staged_copy(oracle_gpu):
             assert all(np.array_equal(k.download(), chars[3 * i]) for i, k in enumerate(keep))
     one = rng.integers(0, 2**63, size=(4, BIG_CT), dtype=np.uint64)
     assert np.array_equal(sk.upload_char(one).download(), one)
+
+
+def test_plaintext_text_with_encrypted_pattern(product):
+    """A trivially encrypted (plaintext) string searched for an ENCRYPTED pattern: windows over identical plaintext share
+    their bootstraps, the trees count a shared block once (noise) -- and the answers are still the string's."""
+    from fhestring_amd.api import FheString
+    ck, sk = product
+    sk.set_mode(1)
+    text = "abcabcabcabcabxabcabcabcabcabcabcabcabc"
+    s = FheString([sk.trivial(ord(c)) for c in text] + [sk.trivial(0)])
+    for pat in ("abx", "bca", "zzz", "abc"):
+        p = ck.encrypt_no_padding(pat, sk)
+        sk.stats(reset=True)
+        got = (ck.decrypt_char(sk.contains(s, p)), ck.decrypt_char(sk.find(s, p)), ck.decrypt_char(sk.rfind(s, p)),
+               ck.decrypt_char(sk.ends_with(s, p)), ck.decrypt_char(sk.starts_with(s, p)))
+        want = (int(pat in text), text.find(pat) if pat in text else 255, text.rfind(pat) if pat in text else 255,
+                int(text.endswith(pat)), int(text.startswith(pat)))
+        assert got == want, (pat, got, want)
+        assert sk.stats()["max_input_sum_c2"] <= 64, sk.stats()
