@@ -359,3 +359,31 @@ def test_baseline_configs_at_full_size_by_folding(folded):
             assert sk.contains(enc(t), enc(p, 0)).trivial_value() == int(p in t), (n, p)
             assert sk.contains_clear(enc(t), p).trivial_value() == int(p in t), (n, p)
     assert sk.len(enc("x" * 300)).trivial_value() == 300 % 256
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["as_written", "fused"])
+def test_empty_strings_empty_patterns_and_zero_padding(folded, mode):
+    """The grid of small edge cases (empty string, empty pattern, pattern longer than the string, no padding) through
+    every method: same answers -- and the same panics -- as the clear-model restatement of the reference."""
+    import itertools
+    folded.set_mode(mode)
+    penv, cenv = product_env(folded), clear_env()
+    strings, pats = ["", "a", "ab", " a ", "aaa", "abab"], ["", "a", "ab", "aa", "abc", "abababab"]
+    for s, p, pad in itertools.product(strings, pats, (0, 1, 2)):
+        base = {"string": s, "pad": pad, "name": "edge"}
+        vs = [dict(base, op=op, pattern=p) for op in ("contains", "starts_with", "ends_with", "find", "rfind", "strip_prefix", "strip_suffix")]
+        vs += [dict(base, op=op) for op in ("to_upper", "trim", "trim_start", "trim_end", "is_empty", "len")]
+        vs += [dict(base, op=op, other=p, other_pad=pad) for op in ("eq", "eq_ignore_case", "lt", "le", "gt", "ge", "concatenate")]
+        vs += [dict(base, op="replace", **{"from": p, "to": t}) for t in ("", "x", "xyz")]
+        vs += [dict(base, op="replacen", n=k, **{"from": p, "to": "x"}) for k in (0, 1, 2)]
+        vs += [dict(base, op="repeat", n=k) for k in (0, 1, 2)]
+        if p:
+            vs += [dict(base, op=op, pattern=p) for op in ("split", "rsplit", "split_terminator", "split_inclusive", "rsplit_terminator")]
+            vs += [dict(base, op=op, pattern=p, n=2) for op in ("splitn", "rsplitn")]
+        for v in vs:
+            def outcome(env):
+                try:
+                    return ("ok", run_vector(v, *env))
+                except Exception as exc:                      # the reference panics here: the product raises the same kind
+                    return ("raises", type(exc).__name__)
+            _same(v, outcome(penv), outcome(cenv))
