@@ -387,3 +387,24 @@ def test_empty_strings_empty_patterns_and_zero_padding(folded, mode):
                 except Exception as exc:                      # the reference panics here: the product raises the same kind
                     return ("raises", type(exc).__name__)
             _same(v, outcome(penv), outcome(cenv))
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["as_written", "fused"])
+def test_character_operators_on_byte_pairs(folded, mode):
+    """FheAsciiChar's operators (fheasciichar.rs:35-168) by constant folding: eq / ne / le / lt / ge / gt / bitand / bitor
+    / add / sub / if_then_else on a grid of byte pairs (every b for every 8th a, every 5th b otherwise), the three class
+    tests and flip on all bytes."""
+    sk = folded
+    sk.set_mode(mode)
+    tr = [sk.trivial(v) for v in range(256)]
+    for a in range(256):
+        ca = tr[a]
+        for b in range(0, 256, 1 if a % 8 == 0 else 5):
+            cb = tr[b]
+            got = tuple(x.trivial_value() for x in (ca.eq(cb), ca.ne(cb), ca.le(cb), ca.lt(cb), ca.ge(cb), ca.gt(cb), ca.bitand(cb),
+                                                      ca.bitor(cb), ca.add(cb), ca.sub(cb), ca.if_then_else(cb, ca)))
+            assert got == (int(a == b), int(a != b), int(a <= b), int(a < b), int(a >= b), int(a > b), a & b, a | b,
+                           (a + b) & 255, (a - b) & 255, b if a else a), (a, b, got)
+        got = (ca.is_whitespace().trivial_value(), ca.is_uppercase().trivial_value(), ca.is_lowercase().trivial_value())
+        assert got == (int(a in (32, 9, 10, 11, 12, 13)), int(0x41 <= a <= 0x5A), int(0x61 <= a <= 0x7A)), (a, got)
+    assert (tr[0].flip().trivial_value(), tr[1].flip().trivial_value()) == (1, 0)
