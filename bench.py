@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--watchdog", type=float, default=900.0,
                     help="multi-GPU runs: seconds the legs AFTER the timed measurement may take before rank 0 prints the "
                          "headline line it already has and every rank exits (0 = off)")
+    ap.add_argument("--inject-fault", choices=["raise", "hang"], default=None, help=argparse.SUPPRESS)   # tests only:
+    # the last rank fails / hangs right after the timed measurement (tests/test_gpu_bench_contract.py)
     a = ap.parse_args()
     if a.scaling is None:
         a.scaling = "weak" if a.op == "contains" else "strong"
@@ -87,7 +89,6 @@ def parse():
     if a.strings is None:
         a.strings = 8 if a.op == "contains" else 1
     if a.pipelines is None:
-        world = int(os.environ.get("WORLD_SIZE", "1"))
         a.pipelines = 0 if a.op == "contains" else 1
     return a
 
@@ -349,9 +350,13 @@ def main():
     """Runs the bench; in a multi-GPU run a failure (or a hang) AFTER the contract's timed measurement costs the extra
     legs, not the headline line (see `safety` in _main)."""
     import traceback
+    args = parse()
+    rc = launch_ranks_if_needed(args)
+    if rc is not None:
+        sys.exit(rc)
     safety = {}
     try:
-        _main(safety)
+        _main(safety, args)
     except Exception as exc:
         if not safety.get("bail"):
             raise
@@ -359,11 +364,55 @@ def main():
         safety["bail"]("%s: %s" % (type(exc).__name__, exc))
 
 
-def _main(safety):
-    args = parse()
+EXIT_WORLD_MISMATCH = 2      # --gpus N and the launcher's WORLD_SIZE disagree: nothing was measured
+EXIT_INCOMPLETE = 3          # the contract's line was printed (marked "incomplete") but a later leg failed or hung
+
+
+def launch_ranks_if_needed(args):
+    """`python bench.py --gpus N` (N > 1) with no launcher around it: start the N ranks ourselves, exactly as the driver
+    would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), as a CHILD
+    process -- this parent has made no GPU call and imported neither torch nor the library, so nothing here is an exec
+    from a process that has touched the GPU -- relay its stdout (the one JSON line) and return its exit code.
+    Under a launcher (WORLD_SIZE set) return None and let _main run as one rank; a WORLD_SIZE that differs from --gpus
+    is refused before anything touches the GPU: the line would otherwise carry an n_gpus nobody asked for."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            if int(os.environ.get("RANK", "0")) == 0:
+                sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s rank(s); refusing to "
+                                 "measure a configuration other than the one asked for\n" % (args.gpus, ws))
+            return EXIT_WORLD_MISMATCH
+        return None
+    if args.gpus <= 1:
+        return None
+    import socket
+    import subprocess
+    with socket.socket() as s:                   # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    n_json = 0
+    for line in child.stdout:                    # relay as it comes; stderr goes straight through
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        n_json += line.lstrip().startswith("{")
+    rc = child.wait()
+    if rc == 0 and n_json != 1:
+        sys.stderr.write("bench.py: the %d-rank run exited 0 but printed %d JSON lines\n" % (args.gpus, n_json))
+        rc = 1
+    return rc
+
+
+def _main(safety, args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    stage = safety.setdefault("stage", ["start"])          # what this rank was doing, for bail() and the watchdog
     import torch
     dist = None
     if world > 1:
@@ -378,8 +427,7 @@ def _main(safety):
         else:
             local_rank = 0
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    assert args.gpus == world                    # launch_ranks_if_needed() refused anything else
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -551,24 +599,43 @@ def _main(safety):
                     "ms_per_op": h_dt / args.steps / wl.n_strings * 1e3, "roofline": roof_h}
 
         def bail(reason):
+            """The timed measurement is complete, a later leg is not: rank 0 prints the line it has, marked incomplete
+            with the reason and the leg every rank reports for itself on stderr, and every rank leaves with
+            EXIT_INCOMPLETE -- non-zero, so that the launcher and the driver see that a GPU process failed or hung
+             -- without collective clean-up (another rank may be stuck in one)."""
             try:
+                where = "rank %d during '%s'" % (rank, stage[0])
                 if rank == 0:
-                    print(json.dumps(dict(head, incomplete=reason)))
+                    print(json.dumps(dict(head, incomplete="%s [%s]" % (reason, where), incomplete_stage=stage[0])))
                     sys.stdout.flush()
-                sys.stderr.write("bench.py rank %d: leaving after the timed measurement: %s\n" % (rank, reason))
+                sys.stderr.write("bench.py %s: leaving after the timed measurement: %s\n" % (where, reason))
                 sys.stderr.flush()
             finally:
-                os._exit(0)                 # no collective clean-up: another rank may be stuck in one
+                os._exit(EXIT_INCOMPLETE)
 
         safety["bail"] = bail
+        # A rank that leaves non-zero makes torch.distributed.run send SIGTERM to the others -- possibly to rank 0 before
+        # it has printed anything.  The C-level handler writes to a wake-up pipe at once, whatever the main thread is
+        # blocked in (a collective, a stream synchronize); a helper thread reads it and prints the line through bail().
+        import signal
+        rfd, wfd = os.pipe()
+        os.set_blocking(wfd, False)
+        signal.signal(signal.SIGTERM, lambda *_: None)
+        signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
+
+        def on_sigterm():
+            os.read(rfd, 1)
+            bail("SIGTERM from the launcher (another rank failed or the run was cancelled)")
+        th = threading.Thread(target=on_sigterm, daemon=True)
+        th.start()
         if args.watchdog > 0:
             safety["timer"] = threading.Timer(args.watchdog + (0 if rank == 0 else 5), bail,
                                               ["watchdog: the legs after the timed measurement did not finish in %.0f s" % args.watchdog])
             safety["timer"].daemon = True
             safety["timer"].start()
-        fault = os.environ.get("FHS_BENCH_FAULT")    # test hook (tests/test_gpu_bench_contract.py): fail / hang on the last rank
-        if fault and rank == world - 1:
-            if fault == "raise":
+        stage[0] = "after the timed measurement"
+        if args.inject_fault and rank == world - 1:  # tests only (hidden flag): fail / hang on the last rank
+            if args.inject_fault == "raise":
                 raise RuntimeError("injected failure after the timed measurement")
             time.sleep(10 ** 6)
     exchange = None
@@ -580,6 +647,7 @@ def _main(safety):
                             "on the context's stream and the bytes this rank contributed"}
 
     # median of >= 5 repeats of a shorter run (SURVEY 8d timing protocol), outside the contract's timed region
+    stage[0] = "repeats (median protocol)"
     rep_ms = []
     n_rep_steps = 6 if SKEW else max(P, min(args.steps, 2 * P))
     for _ in range(args.repeats):
@@ -588,6 +656,7 @@ def _main(safety):
 
     # one op on one string: latency, level shape, end-to-end (encrypt + upload + op + download + decrypt, like the
     # reference's own timer src/main.rs:103-114), and the as-written (reference-order) DAG of the same op
+    stage[0] = "single-op latency"
     single = None
     if rank == 0 and world == 1 and not args.skip_single_op:
         sk = sks[0]
@@ -665,6 +734,7 @@ def _main(safety):
             single["cfg2_variants"] = variants
 
     # the other arithmetic on the same workload (secondary figure, fewer steps)
+    stage[0] = "the other arithmetic (timed steps + barrier)"
     secondary = None
     if not args.skip_secondary:
         other = "exact" if args.arith == "fft" else "fft"
@@ -678,6 +748,7 @@ def _main(safety):
         set_arith(args.arith)
 
     # the same workload in the two-bits-per-product arithmetic (default run only; its own object in the JSON line)
+    stage[0] = "two-bit arithmetic"
     multi_bit = None
     if args.arith == "fft" and want_mb2:
         set_arith("mb2")
@@ -729,6 +800,7 @@ def _main(safety):
     if args.op == "contains" and not args.skip_extras and args.mode == "fused":
         extras = {}
         for op in ("find_enc", "replace", "eq_ignore_case", "le"):
+            stage[0] = "configs 3-5: %s (sharded exchange + barrier)" % op
             w = Workload(args, ck, sks[:1], dists[:1], rank, world, op=op, chars=FIXED[op], strings=1)
             lp = op == "replace" and world > 1
             if lp:
@@ -805,6 +877,7 @@ def _main(safety):
         pk.close()
 
     pbs_local = st["pbs_executed"]
+    stage[0] = "final all_reduce of the figures"
     if dist is not None:
         vec = [dt, float(pbs_local)] + ([secondary["dt"], secondary["pbs_local"]] if secondary else [0.0, 0.0])
         vec += rep_ms + [0.0] * (args.repeats - len(rep_ms))
@@ -976,12 +1049,19 @@ def _main(safety):
     safety["bail"] = None                    # the line is out: from here on failures are ordinary
     if dist is not None:
         import threading
-        last = threading.Timer(120.0, lambda: os._exit(0))   # ... and a shutdown that hangs in a collective is cut short
+        def cut_short():                         # the line is out, but a rank that hangs while shutting down is a hang:
+            sys.stderr.write("bench.py rank %d: shutdown did not finish in 120 s (during '%s')\n" % (rank, stage[0]))
+            sys.stderr.flush()                   # say where, leave non-zero
+            os._exit(EXIT_INCOMPLETE)
+        last = threading.Timer(120.0, cut_short)
         last.daemon = True
         last.start()
+        stage[0] = "shutdown: barrier"
         dist.barrier()
+        stage[0] = "shutdown: fhs_dist_shutdown"
         for D in dists:
             D.shutdown()
+        stage[0] = "shutdown: destroy_process_group"
         dist.destroy_process_group()
     for x in sks:
         x.close()

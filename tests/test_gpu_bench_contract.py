@@ -110,21 +110,44 @@ def test_bench_two_ranks_on_one_gpu(extra):
     assert ex["transport"] == "host" and ex["allgather_calls_per_step"] > 0 and ex["bytes_sent_per_rank_per_step"] > 0
 
 
+def test_bench_starts_its_own_ranks_for_gpus_2():
+    """plain `python bench.py --gpus 2` (the form of the driver's 1-GPU command, no launcher around
+    it) starts the two ranks itself as a child torch.distributed.run and relays the ONE line: n_gpus 2, exchanges
+    counted.  Two ranks share this GPU, so the library's all-gathers go through the host transport (gloo)."""
+    env = dict(os.environ, FHS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--cpu-pbs", "0", "--skip-secondary", "--skip-extras", "--repeats", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 1000
+    assert d["config"]["exchange"]["allgather_calls_per_step"] > 0
+    assert "torch.distributed.run" in out.stderr           # ... and says on stderr what it started
+
+
 @pytest.mark.parametrize("fault", ["raise", "hang"])
 def test_bench_keeps_the_headline_when_a_later_leg_fails_on_one_rank(fault):
     """Multi-GPU safety net: the legs after the contract's timed measurement (repeats, the other arithmetic, configs 3-5
     in their sharded formulations) have never run over real xGMI.  If one rank raises there, or hangs in a collective,
-    rank 0 still prints ONE line with the measured figures, marked incomplete, and the launcher sees exit code 0."""
-    env = dict(os.environ, FHS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", FHS_BENCH_FAULT=fault)
+    rank 0 still prints ONE line with the measured figures, marked incomplete with the leg it was in -- and every rank
+    leaves NON-ZERO (a GPU process that failed or hung must not look like a clean run to the launcher)."""
+    env = dict(os.environ, FHS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29573", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--cpu-pbs", "0", "--skip-secondary", "--skip-extras", "--repeats", "1", "--watchdog", "25"]
+           "--cpu-pbs", "0", "--skip-secondary", "--skip-extras", "--repeats", "1", "--watchdog", "25",
+           "--inject-fault", fault]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.returncode != 0, out.stdout[-2000:]
+    assert "exitcode: 3" in out.stderr or "exitcode  : 3" in out.stderr, out.stderr[-3000:]     # bench.py's EXIT_INCOMPLETE
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 1000 and d["steps"] == 4 and d["unit"] == "PBS/s"
     # the reason rank 0 gives: its watchdog (hang), or whatever its next collective raised once the peer was gone (raise)
     assert isinstance(d["incomplete"], str) and d["incomplete"] and (fault != "hang" or "watchdog" in d["incomplete"])
+    assert "rank 0 during" in d["incomplete"] and d["incomplete_stage"]
     assert d["roofline"] and d["roofline"]["frac"] > 0
