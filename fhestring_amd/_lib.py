@@ -259,6 +259,8 @@ def _declare(L):
     L.fhs_get_stats.restype = i
     L.fhs_char_sum_c2.argtypes = [vp, C.c_uint64, vp]
     L.fhs_char_sum_c2.restype = i
+    L.fhs_char_set_noise.argtypes = [vp, C.c_uint64, C.c_uint64]
+    L.fhs_char_set_noise.restype = i
     L.fhs_trivial_value.argtypes = [vp, C.c_uint64, vp, vp]
     L.fhs_trivial_value.restype = i
     L.fhs_reset_stats.argtypes = [vp]

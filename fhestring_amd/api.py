@@ -314,10 +314,16 @@ class FheAsciiChar:
 
     def sum_c2(self):
         """Noise of the handle in bootstrap-output variances (fhs_char_sum_c2): results come back at <= 4 except find's
-        index (<= 57); above 4 a downloaded block must be bootstrapped before it is uploaded again."""
+        index (<= 57).  The figure stays with the handle across a download; a ciphertext that leaves the library takes
+        it along (`download()` + `sum_c2()`), and `set_noise()` declares it after the upload on the other side."""
         v = C.c_uint64(0)
         self.sk.ctx._check(self.sk.ctx._L.fhs_char_sum_c2(self.sk.ctx._h, self.h, C.byref(v)))
         return int(v.value)
+
+    def set_noise(self, sum_c2):
+        """fhs_char_set_noise: this uploaded ciphertext is a result that was handed out at `sum_c2` (uploads count as 1)."""
+        self.sk.ctx._check(self.sk.ctx._L.fhs_char_set_noise(self.sk.ctx._h, self.h, int(sum_c2)))
+        return self
 
     def trivial_value(self):
         """The byte if every block of the handle is a trivial ciphertext (what constant folding left), else None."""

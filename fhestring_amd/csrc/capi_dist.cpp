@@ -47,7 +47,14 @@ struct FusedScope {
     ~FusedScope() { e.mode = saved; }
 };
 // gathers k blocks per rank; out[r][j] = block j of rank r
-int gather(Engine &e, const std::vector<Ref> &local, std::vector<std::vector<Ref>> &out) {
+// The receivers book every imported block as ONE bootstrap output (they cannot know a sender's figure without a host
+// round trip), so that is what a sender hands over: a block that is a sum of several outputs is refreshed first.  The
+// partials of the sharded operations are single outputs already (found / match flags, refreshed position digits,
+// 1 - same); this only bites for caller-supplied handles of fhs_dist_allgather_flags / _chars.
+int gather(Engine &e, const std::vector<Ref> &local_in, std::vector<std::vector<Ref>> &out) {
+    std::vector<Ref> local = local_in;
+    for (Ref &x : local)
+        if (e.sum_c2(x.id()) > 1) x = pbs(x, LUT_MSG);
     std::vector<Bid> ids(local.size()), got;
     for (size_t i = 0; i < local.size(); i++) ids[i] = local[i].id();
     int rc = e.gather_blocks(ids.data(), ids.size(), got);

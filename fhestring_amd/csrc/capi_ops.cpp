@@ -443,6 +443,13 @@ int fhs_char_sum_c2(fhs_ctx *c, fhs_char_t h, uint64_t *out) {
     *out = (uint64_t)m;
     return FHS_OK;
 }
+int fhs_char_set_noise(fhs_ctx *c, fhs_char_t h, uint64_t sum_c2) {
+    if (!ok(c, h)) return bad(c);
+    const Bid *b = c->eng.char_blocks(h);
+    for (int i = 0; i < 4; i++)
+        if (int rc = c->eng.set_var(b[i], sum_c2)) return rc;
+    return FHS_OK;
+}
 int fhs_trivial_value(fhs_ctx *c, fhs_char_t h, int *is_trivial, uint8_t *value) {
     if (!ok(c, h) || !is_trivial || !value) return bad(c);
     const Bid *b = c->eng.char_blocks(h);

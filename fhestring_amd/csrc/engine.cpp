@@ -259,10 +259,19 @@ Bid Engine::lin(const Term *terms, size_t n, int konst) {
 int64_t Engine::sum_c2(Bid b) const {
     const BlockNode &n = nodes_[b];
     if (n.kind == BlockNode::TRIV) return 0;
+    if (n.kind == BlockNode::MAT) return n.var;
     if (n.kind != BlockNode::LIN) return 1;
     int64_t c2 = 0;
-    for (const Term &t : n.terms) c2 += t.coef * t.coef;
+    for (const Term &t : n.terms) c2 += t.coef * t.coef * term_var(t.blk);
     return c2;
+}
+
+int Engine::set_var(Bid b, uint64_t v) {
+    BlockNode &n = nodes_[b];
+    if (n.kind == BlockNode::TRIV) return 0;                  // a plaintext block carries no noise whatever is declared
+    if (n.kind != BlockNode::MAT) return ctx.fail(-1, "noise can only be declared for uploaded ciphertexts");
+    n.var = (uint16_t)std::min<uint64_t>(std::max<uint64_t>(v, 1), 65535);
+    return 0;
 }
 
 Bid Engine::pbs(Bid x, int lut) {
@@ -440,7 +449,7 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                 tl.terms.push_back({s.dev, 1});
                 d.n_terms = 1;
                 need = std::max(need, s.ready_tick);
-                c2 = 1;
+                c2 = s.var;
             } else if (s.kind == BlockNode::LIN) {
                 for (const Term &t : s.terms) {
                     const BlockNode &tb = nodes_[t.blk];
@@ -448,7 +457,7 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                         return ctx.fail(-3, "internal: lincomb term not materialised at its level");
                     tl.terms.push_back({tb.dev, t.coef});
                     need = std::max(need, tb.ready_tick);
-                    c2 += t.coef * t.coef;
+                    c2 += t.coef * t.coef * tb.var;
                 }
                 d.n_terms = (uint32_t)s.terms.size();
                 d.konst_body = (uint64_t)(s.konst & 31) << DELTA_LOG;
@@ -459,6 +468,11 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                                         std::to_string(s.level) + " refs " + std::to_string(s.refs) + ")");
             }
             stats.max_input_sum_c2 = std::max<uint64_t>(stats.max_input_sum_c2, (uint64_t)c2);
+            if (c2 > 64 && std::getenv("FHS_DEBUG_C2")) {
+                std::fprintf(stderr, "c2=%lld lut=%d terms:", (long long)c2, (int)n.lut);
+                for (const Term &t : s.terms) std::fprintf(stderr, " %lld*b%u", (long long)t.coef, t.blk);
+                std::fprintf(stderr, "\n");
+            }
             tl.descs.push_back(d);
             tl.lut.push_back(n.lut);
             uint64_t *o = alloc_block();
@@ -806,8 +820,8 @@ int Engine::plan_flush() {
             {   // noise bookkeeping: sum of squared coefficients of the (flattened) linear combination entering this
                 // bootstrap, i.e. its noise variance in units of one bootstrap output's (uploads counted like outputs)
                 int64_t c2 = 0;
-                if (s.kind == BlockNode::LIN) for (const Term &t : s.terms) c2 += t.coef * t.coef;
-                else c2 = 1;
+                if (s.kind == BlockNode::LIN) for (const Term &t : s.terms) c2 += t.coef * t.coef * term_var(t.blk);
+                else c2 = s.var;
                 stats.max_input_sum_c2 = std::max<uint64_t>(stats.max_input_sum_c2, (uint64_t)c2);
                 if (c2 > 64 && std::getenv("FHS_DEBUG_C2")) {
                     std::fprintf(stderr, "c2=%lld lut=%d terms:", (long long)c2, (int)n.lut);
@@ -968,9 +982,13 @@ int Engine::materialize_lin(Bid b) {
                        reinterpret_cast<const LinTerm *>(plan_buf_.as<uint8_t>() + sizeof(LinDesc)), o, 1,
                        ctx.stream);
     if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
+    // the materialised block IS the linear combination: it keeps its noise (a download followed by further use of the
+    // same handle must not look like a fresh bootstrap output to the bookkeeping)
+    const int64_t v = sum_c2(b);
     std::vector<Term> old;
     old.swap(n.terms);
     n.kind = BlockNode::MAT;
+    n.var = (uint16_t)std::min<int64_t>(std::max<int64_t>(v, 1), 65535);
     n.dev = o;
     n.level = 0;
     for (const Term &t : old) release(t.blk);

@@ -29,6 +29,9 @@ struct BlockNode {
     Kind kind = FREE;
     uint8_t triv = 0;        // TRIV: value mod 32
     uint16_t lut = 0;        // PBS
+    uint16_t var = 1;        // MAT: noise variance in units of one bootstrap output's (1 = a bootstrap output or a fresh
+                             // upload; more for a linear combination that was materialised for a download / an export,
+                             // or an upload declared noisier with fhs_char_set_noise)
     int32_t konst = 0;       // LIN: constant (mod 32)
     uint32_t level = 0;      // PBS depth since the last flush
     uint32_t refs = 0;
@@ -75,6 +78,8 @@ class Engine {
     // sum of squared coefficients of a block as a combination of bootstrap outputs / uploads (its noise variance in
     // units of one bootstrap output's): 0 trivial, 1 materialised or pending bootstrap, sum c^2 for a linear combination
     int64_t sum_c2(Bid b) const;
+    int64_t term_var(Bid b) const { return nodes_[b].kind == BlockNode::MAT ? nodes_[b].var : 1; }   // of a flattened term
+    int set_var(Bid b, uint64_t v);                         // MAT blocks only (fhs_char_set_noise)
 
     int flush();
     // ---- level-skewed batching of independent jobs (fhs_submit / fhs_pump) ----------------------------------------

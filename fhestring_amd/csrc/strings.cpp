@@ -792,14 +792,30 @@ static Ref sum_refs(Engine *e, const Ref *r, size_t n) {
 // Flags that are the SAME block (one bootstrap shared by several windows of a mostly plaintext string: the engine's
 // common-subexpression table hands out one node) count once in an AND / OR -- summed, they would come back as ONE term
 // with a coefficient of up to 15, i.e. 225 times the variance of a flag.
-static void distinct_flags(std::vector<Ref> &f) {
+// "The same" is structural: a flag may be a linear form over a block (1 - bad of char_significant, 1 - same ...), a new
+// node every time it is built, so two nodes are the same flag when they are the same block or the same constant + terms
+// (a string that holds one ciphertext several times -- `repeat`, a caller's own FheString -- produces those).
+static bool same_flag(const Engine *e, Bid a, Bid b) {
+    if (a == b) return true;
+    const BlockNode &x = e->node(a), &y = e->node(b);
+    if (x.kind != BlockNode::LIN || y.kind != BlockNode::LIN) return false;
+    if (x.konst != y.konst || x.terms.size() != y.terms.size()) return false;
+    auto key = [](const Term &t) { return std::make_pair(t.blk, t.coef); };
+    std::vector<std::pair<Bid, int64_t>> ta, tb;
+    for (const Term &t : x.terms) ta.push_back(key(t));
+    for (const Term &t : y.terms) tb.push_back(key(t));
+    std::sort(ta.begin(), ta.end());
+    std::sort(tb.begin(), tb.end());
+    return ta == tb;
+}
+static void distinct_flags(const Engine *e, std::vector<Ref> &f) {
     std::vector<Ref> out;
     out.reserve(f.size());
-    std::vector<Bid> seen;
     for (Ref &x : f) {
-        if (std::find(seen.begin(), seen.end(), x.id()) != seen.end()) continue;
-        seen.push_back(x.id());
-        out.push_back(x);
+        bool dup = false;
+        for (const Ref &y : out)
+            if (same_flag(e, x.id(), y.id())) { dup = true; break; }
+        if (!dup) out.push_back(x);
     }
     f.swap(out);
 }
@@ -813,7 +829,7 @@ Ref Strings::and_tree(std::vector<Ref> f) {
     }
     if (cur.empty()) return trivial_block(e_, 1);
     while (cur.size() > 1) {
-        distinct_flags(cur);
+        distinct_flags(e_, cur);
         if (cur.size() == 1) break;
         std::vector<Ref> nxt;
         for (size_t i = 0; i < cur.size(); i += 15) {
@@ -835,7 +851,7 @@ Ref Strings::or_tree(std::vector<Ref> f) {
     }
     if (cur.empty()) return trivial_block(e_, 0);
     while (cur.size() > 1) {
-        distinct_flags(cur);
+        distinct_flags(e_, cur);
         if (cur.size() == 1) break;
         std::vector<Ref> nxt;
         for (size_t i = 0; i < cur.size(); i += 15) {
@@ -950,7 +966,7 @@ std::vector<Ref> Strings::prefix_or(const std::vector<Ref> &f) {
         any.resize(nchunks - 1);             // the last chunk's total is never needed
         for (size_t j = 0; j + 1 < nchunks; j++) {
             std::vector<Ref> grp(f.begin() + 15 * j, f.begin() + 15 * j + 15);
-            distinct_flags(grp);                              // an OR: a flag that occurs twice counts once (noise)
+            distinct_flags(e_, grp);                              // an OR: a flag that occurs twice counts once (noise)
             any[j] = pbs(sum_refs(e_, grp.data(), grp.size()), LUT_NZ);
         }
         any.push_back(trivial_block(e_, 0));
@@ -967,7 +983,7 @@ std::vector<Ref> Strings::prefix_or(const std::vector<Ref> &f) {
         if (j >= 1 && k >= 1 && k <= 13 && depth(q[j]) > std::max(depth(q[j - 1]), depth(any[j - 1]))) {
             terms.push_back(q[j - 1]);
             terms.push_back(any[j - 1]);
-            distinct_flags(terms);
+            distinct_flags(e_, terms);
             p[i] = pbs(sum_refs(e_, terms.data(), terms.size()), LUT_NZ);
             continue;
         }
@@ -975,7 +991,7 @@ std::vector<Ref> Strings::prefix_or(const std::vector<Ref> &f) {
         if (k == 0) { p[i] = q[j]; continue; }               // nothing of this chunk yet: the flag itself, no bootstrap
         if (k == 1 && q0) { p[i] = f[15 * j]; continue; }    // OR of one 0/1 flag
         terms.push_back(q[j]);
-        distinct_flags(terms);               // an OR: the same flag twice counts once (<= 14 + 1 terms)
+        distinct_flags(e_, terms);               // an OR: the same flag twice counts once (<= 14 + 1 terms)
         p[i] = pbs(sum_refs(e_, terms.data(), terms.size()), LUT_NZ);   // folds to a constant when everything is trivial
     }
     return p;
@@ -1030,6 +1046,7 @@ FChar Strings::first_index(const std::vector<Ref> &before, const Ref &found) {
         auto var_of = [&](const std::vector<Ref> &v) {
             return v.empty() ? (int64_t)0 : e_->sum_c2(v.size() == 1 ? v[0].id() : sum_refs(e_, v.data(), v.size()).id());
         };
+        bool stalled_before = false;
         for (;;) {
             if (blocks.size() <= 1 || var_of(blocks) + 9 <= 48) break;
             std::vector<Ref> nxt, grp;
@@ -1047,8 +1064,13 @@ FChar Strings::first_index(const std::vector<Ref> &before, const Ref &found) {
                 }
             }
             close();
-            if (nxt.size() >= blocks.size()) { blocks.swap(nxt); break; }   // every block on its own already: no progress to make
+            // A pass that merged nothing still REFRESHED every block (each was too noisy to share a group): the fresh
+            // blocks merge in the next pass (64 refreshed blocks + 9 = 73 used to leave here un-merged).  Only
+            // a second pass in a row without progress -- fresh blocks that are one shared node, say -- ends the loop.
+            const bool stalled = nxt.size() >= blocks.size();
             blocks.swap(nxt);
+            if (stalled && stalled_before) break;
+            stalled_before = stalled;
         }
         Ref digit = blocks.empty() ? trivial_block(e_, 0) : (blocks.size() == 1 ? blocks[0] : sum_refs(e_, blocks.data(), blocks.size()));
         // 255 = 3,3,3,3 when absent.  The digit is a sum of at most 48 + 9 bootstrap-output variances, inside the budget of
@@ -1203,12 +1225,16 @@ Ref Strings::char_nonzero(const FChar &c) { return char_zero_test(c, false); }
 // bootstrap outputs are refreshed first only if together they would leave the noise budget.
 Ref Strings::char_zero_test(const FChar &c_in, bool want_zero) {
     FChar c = c_in;
-    int64_t c2 = 0;
-    for (int k = 0; k < 4; k++) c2 += e_->sum_c2(c.b[k].id());
-    if (c2 > FHS_NOISE_BUDGET_SUM_C2)
+    // measured on the FLATTENED sum, like block_eq_flags: the four digits of a selected character share the select's
+    // flag outputs (sel / covered of f_replace_expand: one bootstrap output in all four digits), whose coefficients add
+    // up BEFORE squaring -- per-block sums under-count that (120 for replace with an 8-character `from`)
+    Ref d = lin(e_, {{1, &c.b[0]}, {1, &c.b[1]}, {1, &c.b[2]}, {1, &c.b[3]}});
+    if (e_->sum_c2(d.id()) > FHS_NOISE_BUDGET_SUM_C2) {
         for (int k = 0; k < 4; k++)
             if (e_->sum_c2(c.b[k].id()) > 1) c.b[k] = pbs(c.b[k], LUT_MSG);
-    return pbs(lin(e_, {{1, &c.b[0]}, {1, &c.b[1]}, {1, &c.b[2]}, {1, &c.b[3]}}), want_zero ? LUT_IS0 : LUT_NZ);
+        d = lin(e_, {{1, &c.b[0]}, {1, &c.b[1]}, {1, &c.b[2]}, {1, &c.b[3]}});
+    }
+    return pbs(d, want_zero ? LUT_IS0 : LUT_NZ);
 }
 
 // NUL = 0x00, whitespace = 0x20, 0x09..0x0D (fheasciichar.rs:106-130): high nibble 0 with low nibble in
@@ -1347,12 +1373,17 @@ FStr Strings::f_replace_expand(const FStr &s_in, const FStr &from, const FStr &t
     FStr s = s_in;
     s.push_back(zero);                                       // :898
     const size_t n = s.size(), m = from.size(), L = to.size();
-    std::vector<Ref> sel(n), covered(n);
+    std::vector<Ref> sel(n), covered(n), keep_flag(n);
     Ref state = trivial_block(e_, 0);                        // positions still blocked by the last match
+    // 1 - sel - covered is a sum of m outputs and enters the select below with weight 4: 16 m + 1 > 64 from m = 4 on.
+    // The same flag is [countdown == 0 and no match here] = [v == 0], one more look-up on the state machine's own input
+    // (same dependency level, sum c^2 = 5), used from the pattern length on where the linear form leaves the budget.
+    const bool keep_by_lut = 16 * (int64_t)m + 1 > FHS_NOISE_BUDGET_SUM_C2;
     for (size_t i = 0; i < n; i++) {
         Ref f = i + m <= n ? window_match(s, i, from) : trivial_block(e_, 0);
         Ref v = lin(e_, {{2, &state}, {1, &f}});
         sel[i] = pbs(v, LUT_GREEDY_SEL);
+        if (keep_by_lut) keep_flag[i] = pbs(v, LUT_IS0);
         state = pbs(v, LUT_GREEDY_NEXT0 + (int)(m - 1));     // selected ? m - 1 : max(countdown - 1, 0)
     }
     for (size_t i = 0; i < n; i++) {
@@ -1365,7 +1396,7 @@ FStr Strings::f_replace_expand(const FStr &s_in, const FStr &from, const FStr &t
     FStr slots;
     slots.reserve(n * L);
     for (size_t i = 0; i < n; i++) {
-        Ref keep = lin(e_, {{1, &one}, {-1, &sel[i]}, {-1, &covered[i]}});
+        Ref keep = keep_by_lut ? keep_flag[i] : lin(e_, {{1, &one}, {-1, &sel[i]}, {-1, &covered[i]}});
         for (size_t j = 0; j < L; j++) {
             FChar c;
             for (int b = 0; b < 4; b++) {
@@ -1459,6 +1490,22 @@ std::vector<Strings::Num> Strings::num_exclusive_scan(const std::vector<Num> &x,
     return out;
 }
 
+// The number of set flags among k <= 15 as a base-4 number (low digit, high digit, zeros): two look-ups on their sum.
+// Flags that are ONE block (the same character twice in a string: `repeat`; NUL tests of identical neighbourhoods of a
+// mostly plaintext string, shared by the common-subexpression table) come back from the sum as one term with their
+// multiplicity as coefficient -- a count of k equal flags IS k times the flag -- and 9 of them already pass the noise
+// budget (81 > 64).  Then the flags are counted in two halves and the halves added as numbers.
+Strings::Num Strings::count_digits(const Ref *flags, size_t k, size_t D) {
+    Ref sum = k ? sum_refs(e_, flags, k) : trivial_block(e_, 0);
+    if (k > 1 && e_->sum_c2(sum.id()) > FHS_NOISE_BUDGET_SUM_C2) {
+        Num a = count_digits(flags, k / 2, D), b = count_digits(flags + k / 2, k - k / 2, D);
+        return num_add({&a, &b}, D);
+    }
+    Num v(D);
+    for (size_t d = 0; d < D; d++) v[d] = d == 0 ? pbs(sum, LUT_MSG) : (d == 1 ? pbs(sum, LUT_CARRY) : trivial_block(e_, 0));
+    return v;
+}
+
 // Exclusive prefix counts of 0/1 flags as base-4 numbers: chunks of 15 flags give a (low, high) digit pair each, an
 // exclusive scan over the chunk totals (4-ary, log depth) and one add per position.
 std::vector<Strings::Num> Strings::flag_prefix_counts(const std::vector<Ref> &z, size_t D) {
@@ -1466,17 +1513,12 @@ std::vector<Strings::Num> Strings::flag_prefix_counts(const std::vector<Ref> &z,
     std::vector<Num> out(n);
     if (n == 0) return out;
     const size_t nch = (n + 14) / 15;
-    auto digits_of = [&](const Ref &sum) {
-        Num v(D);
-        for (size_t d = 0; d < D; d++) v[d] = d == 0 ? pbs(sum, LUT_MSG) : (d == 1 ? pbs(sum, LUT_CARRY) : trivial_block(e_, 0));
-        return v;
-    };
     std::vector<Num> tot(nch);
-    for (size_t j = 0; j < nch; j++) tot[j] = digits_of(sum_refs(e_, &z[15 * j], std::min<size_t>(15, n - 15 * j)));
+    for (size_t j = 0; j < nch; j++) tot[j] = count_digits(&z[15 * j], std::min<size_t>(15, n - 15 * j), D);
     std::vector<Num> offs = num_exclusive_scan(tot, D);
     for (size_t i = 0; i < n; i++) {
         const size_t j = i / 15, k = i % 15;
-        Num loc = digits_of(k ? sum_refs(e_, &z[15 * j], k) : trivial_block(e_, 0));
+        Num loc = count_digits(&z[15 * j], k, D);
         out[i] = num_add({&offs[j], &loc}, D);
     }
     return out;
@@ -1569,8 +1611,14 @@ FChar Strings::count_flags(std::vector<Ref> flags) {
         const size_t n = std::min<size_t>(15, flags.size() - i);
         Ref s = sum_refs(e_, &flags[i], n);
         FChar c;
-        c.b[0] = pbs(s, LUT_MSG);
-        c.b[1] = n >= 4 ? pbs(s, LUT_CARRY) : trivial_block(e_, 0);
+        if (e_->sum_c2(s.id()) > FHS_NOISE_BUDGET_SUM_C2) {  // the same flag many times over (`repeat`): count in halves
+            Num v = count_digits(&flags[i], n, 2);
+            c.b[0] = v[0];
+            c.b[1] = v[1];
+        } else {
+            c.b[0] = pbs(s, LUT_MSG);
+            c.b[1] = n >= 4 ? pbs(s, LUT_CARRY) : trivial_block(e_, 0);
+        }
         c.b[2] = trivial_block(e_, 0);
         c.b[3] = trivial_block(e_, 0);
         nums.push_back(c);

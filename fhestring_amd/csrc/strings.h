@@ -96,6 +96,7 @@ class Strings {
     typedef std::vector<Ref> Num;   // little-endian base-4 digits, clean (<= 3)
     std::vector<Num> flag_prefix_counts(const std::vector<Ref> &flags, size_t digits);   // exclusive
     Num num_add(const std::vector<const Num *> &ops, size_t digits);
+    Num count_digits(const Ref *flags, size_t k, size_t digits);   // sum of <= 15 flags as a base-4 number, within the noise budget
     std::vector<Num> num_exclusive_scan(const std::vector<Num> &x, size_t digits);
     FStr f_compact(const FStr &s);
     FChar ite_flag(const Ref &flag, const FChar &t, const FChar &f);

@@ -356,9 +356,14 @@ int fhs_get_stats(fhs_ctx *ctx, fhs_stats *out);
 /* Noise of a handle in the same unit: the largest sum of squared coefficients over its four blocks (0 trivial, 1 a
  * bootstrap output or an upload).  Results are handed back at <= 4 except the index of find / find_clear, whose digits
  * are sums of up to 57 bootstrap outputs (inside the decryption margin; saves one dependency level).  The library
- * refreshes a block above 4 by itself when its handle is used as an operand; a host that downloads such a block and
- * uploads it again (uploads count as 1) has to bootstrap it first -- this is the query for that. */
+ * refreshes a block above 4 by itself when its handle is used as an operand, also after a download (a linear
+ * combination materialised for fhs_download / fhs_export_device keeps its figure).  A ciphertext that LEAVES the library
+ * has to carry the figure with it, like the noise_level of a tfhe-rs shortint ciphertext travels in its serialised form
+ * (tfhe 0.5.2, Cargo.lock:416-433): query it here before the download ... */
 int fhs_char_sum_c2(fhs_ctx *ctx, fhs_char_t h, uint64_t *out);
+/* ... and declare it after fhs_upload / fhs_upload_string of such a ciphertext (uploads count as 1 otherwise, the
+ * figure of a fresh client encryption -- fheasciichar.rs:27-29).  Handles of uploaded (or trivial) blocks only. */
+int fhs_char_set_noise(fhs_ctx *ctx, fhs_char_t h, uint64_t sum_c2);
 /* Constant folding made visible: *is_trivial = 1 and *value = the byte if all four blocks of the handle are trivial
  * (plaintext) ciphertexts -- what an operation on trivially encrypted inputs folds to, without a GPU (planner contexts
  * included).  The CPU tests evaluate the re-associated DAGs on every byte pair this way. */

@@ -324,3 +324,40 @@ def test_plaintext_text_with_encrypted_pattern(product):
                 int(text.endswith(pat)), int(text.startswith(pat)))
         assert got == want, (pat, got, want)
         assert sk.stats()["max_input_sum_c2"] <= 64, sk.stats()
+
+
+def test_round4_noise_fixes_keep_the_results(product):
+    """The three constructs round 4 re-formulated for the noise budget (tests/test_planner.py has the bookkeeping), run
+    on ciphertexts: (a) replace with a 4-character `from` and a longer `to` -- the keep flag is a look-up on the state
+    machine's own input instead of 1 - sel - covered; (b) strings that hold ONE ciphertext many times: the prefix counts
+    of the compaction and `len` count a chunk in halves when its flags are one shared block, OR trees over `1 - flag`
+    forms count a block once; (c) a find index that left the library and came back is refreshed like the library's own."""
+    from fhestring_amd.api import FheString
+    ck, sk = product
+    sk.set_mode(1)
+    sk.stats(reset=True)
+    for s, frm, to in (("abcdabcdxabcd", "abcd", "vwxyz"), ("aaaaaaaaa", "aaaa", "bbbbbb"), ("hello world", "o wo", "[0-W0]")):
+        out = sk.replace(ck.encrypt(s, 1, None, sk), ck.encrypt_no_padding(frm, sk), ck.encrypt_no_padding(to, sk))
+        assert ck.decrypt(out) == s.replace(frm, to), (s, frm, to)
+    # (b) the same ciphertexts 12 times over, NULs and blanks in between
+    x, blank, nul, y = (ck.encrypt_char(v, sk) for v in (ord("x"), 0x20, 0, ord("y")))
+    chars = [blank] * 3 + [nul] * 2 + [x] * 12 + [nul] * 9 + [y] + [blank] * 11 + [nul]
+    plain = "".join(chr(ck.decrypt_char(c)) for c in chars)
+    s = FheString(chars)
+    want = plain.replace("\0", "")
+    assert ck.decrypt_char(sk.len(s)) == len(want)
+    assert [ck.decrypt_char(c) for c in sk.bubble_zeroes_right(chars).chars] == [ord(c) for c in want] + [0] * 12
+    # trim_start / trim see the buffer up to its first NUL like the reference (client_key.rs:99-105 stops there)
+    t = FheString([blank] * 9 + [x] * 12 + [blank] * 10 + [nul])
+    assert ck.decrypt(sk.trim_start(t)) == "x" * 12 + " " * 10
+    assert ck.decrypt(sk.trim(t)) == "x" * 12
+    assert ck.decrypt_char(sk.len(sk.repeat_clear(FheString([x, x, nul]), 16))) == 32
+    # (c)
+    text = "b" * 150 + "needle" + "c" * 40
+    idx = sk.find(ck.encrypt(text, 1, None, sk), ck.encrypt_no_padding("needle", sk))
+    c2 = idx.sum_c2()
+    raw = idx.download()
+    assert ck.decrypt_char(idx) == 150 and idx.sum_c2() == c2 > 4        # the download did not launder the figure
+    back = sk.upload_char(raw).set_noise(c2)
+    assert ck.decrypt_char(back.eq(sk.trivial(150))) == 1 and ck.decrypt_char(back.add(ck.encrypt_char(7, sk))) == 157
+    assert sk.stats()["max_input_sum_c2"] <= 64

@@ -252,8 +252,9 @@ def test_noise_budget_on_mostly_plaintext_strings(sk):
     flags and picks of identical plaintext neighbourhoods are ONE shared bootstrap, and a sum over them is one term with
     a large coefficient unless the trees count a block once (and_tree / or_tree / prefix_or), group by the variance of
     the SUM (first_index) and leave out picks that serve two positions (position_of).  Before round 3 this shape reached
-    sum c^2 = 225 in contains / find and 1 353 in rfind.  What is left above the budget: counts over repeated flags in the
-    compaction of a replace and in split (a count of k equal flags IS k times the flag): <= 160, +1.5 % variance."""
+    sum c^2 = 225 in contains / find and 1 353 in rfind.  Round 3 left replace (longer `from`) and split at <= 160; the
+    cause was the NUL test of the compaction adding its four digits' figures instead of measuring their SUM (digits of a
+    selected character share the select's flag outputs): round 4 measures the flattened sum and every method holds 64."""
     from fhestring_amd.api import FheString
     sk.set_mode(1)
     sk.set_auto_flush(0)
@@ -274,7 +275,6 @@ def test_noise_budget_on_mostly_plaintext_strings(sk):
         "replace": lambda s, p, o, to: sk.replace(s, p, to), "replace_longer_from": lambda s, p, o, to: sk.replace(s, to, p),
         "concatenate": lambda s, p, o, to: sk.concatenate(s, o), "split": lambda s, p, o, to: sk.split(s, p),
     }
-    loose = {"replace_longer_from", "split"}
     for n, every, pat_every in ((14, 5, 2), (40, 9, 7), (200, 50, 7), (254, 300, 2)):
         for name, fn in ops.items():
             if n > 60 and name == "split":
@@ -284,6 +284,102 @@ def test_noise_budget_on_mostly_plaintext_strings(sk):
             keep = fn(s, p, o, to)
             sk.flush()
             c2 = sk.stats()["max_input_sum_c2"]
-            assert c2 <= (160 if name in loose else BUDGET), (name, n, every, c2)
+            assert c2 <= BUDGET, (name, n, every, c2)
             del keep
+    sk.set_auto_flush(8192)
+
+
+def test_noise_budget_of_replace_with_a_shorter_to(sk):
+    """replace with |from| > |to| on ENCRYPTED inputs goes through f_replace_expand's
+    sel / covered flags; the NUL test of the compaction that follows summed its four digits per block (each within the
+    budget) while its ONE bootstrap takes b0 + b1 + b2 + b3, where the shared flag outputs add up before squaring: 120
+    for |from| = 8, |to| = 1.  The flattened sum is measured now."""
+    sk.set_mode(1)
+    sk.set_auto_flush(0)
+    worst = 0
+    for n in (17, 65):
+        for m in (5, 6, 7, 8):
+            for k in (1, 2, 3):
+                sk.stats(reset=True)
+                keep = sk.replace(sk.dummy_string(n), sk.dummy_string(m), sk.dummy_string(k))
+                sk.flush()
+                c2 = sk.stats()["max_input_sum_c2"]
+                assert c2 <= BUDGET, (n, m, k, c2)
+                worst = max(worst, c2)
+                del keep
+    assert worst > 16                    # the bookkeeping saw the weighted sums at all
+    sk.set_auto_flush(8192)
+
+
+def test_noise_budget_fuzz_over_mixed_trivial_and_encrypted_operands(sk):
+    """Every string method on random mixtures of plaintext (trivial) and encrypted characters, in strings, patterns and
+    replacements alike: whatever folds, shares or survives, no bootstrap takes more than the budget.  Round 4 found and
+    closed with it: 65 in replace with a 4-character `from` and a longer `to` (1 - sel - covered entering a select with
+    weight 4), 75 in the compaction's prefix counts of a mostly plaintext string (8 copies of one shared NUL flag in a
+    chunk of 15), up to 171 in trim / trim_start of strings that repeat one ciphertext (OR trees over `1 - flag` forms that
+    are distinct nodes over one block)."""
+    import random
+    from fhestring_amd.api import FheString
+    rnd = random.Random(20261004)
+    sk.set_mode(1)
+    sk.set_auto_flush(0)
+
+    def mixed(n, p_enc):
+        d = sk.dummy_string(max(n, 1))
+        rep = rnd.random() < 0.4         # ... and strings that hold ONE ciphertext several times (what `repeat` produces)
+        return FheString([(d[0] if rep and rnd.random() < 0.7 else d[i]) if rnd.random() < p_enc
+                          else sk.trivial(rnd.choice(b"ab A\0z")) for i in range(n)])
+    ops = {
+        "contains": lambda s, p, o, to: sk.contains(s, p), "starts_with": lambda s, p, o, to: sk.starts_with(s, p),
+        "ends_with": lambda s, p, o, to: sk.ends_with(s, p), "find": lambda s, p, o, to: sk.find(s, p),
+        "rfind": lambda s, p, o, to: sk.rfind(s, p), "len": lambda s, p, o, to: sk.len(s),
+        "is_empty": lambda s, p, o, to: sk.is_empty(s), "eq": lambda s, p, o, to: sk.eq(s, o),
+        "ne": lambda s, p, o, to: sk.ne(s, o), "eq_ignore_case": lambda s, p, o, to: sk.eq_ignore_case(s, o),
+        "lt": lambda s, p, o, to: sk.lt(s, o), "ge": lambda s, p, o, to: sk.ge(s, o),
+        "to_lower": lambda s, p, o, to: sk.to_lower(s), "to_upper": lambda s, p, o, to: sk.to_upper(s),
+        "trim": lambda s, p, o, to: sk.trim(s), "trim_start": lambda s, p, o, to: sk.trim_start(s),
+        "strip_prefix": lambda s, p, o, to: sk.strip_prefix(s, p), "strip_suffix": lambda s, p, o, to: sk.strip_suffix(s, p),
+        "replace": lambda s, p, o, to: sk.replace(s, p, to), "replacen": lambda s, p, o, to: sk.replacen(s, p, to, sk.trivial(2)),
+        "concatenate": lambda s, p, o, to: sk.concatenate(s, o), "repeat": lambda s, p, o, to: sk.repeat_clear(s, 2),
+        "split": lambda s, p, o, to: sk.split(s, p), "rsplit": lambda s, p, o, to: sk.rsplit(s, p),
+        "split_terminator": lambda s, p, o, to: sk.split_terminator(s, p),
+    }
+    for trial in range(60):
+        n = rnd.choice((6, 11, 19, 33))
+        p_enc = rnd.choice((0.1, 0.5, 0.9))
+        s, o = mixed(n, p_enc), mixed(rnd.choice((n, n - 2, n + 3)), p_enc)
+        p, to = mixed(rnd.randint(1, 4), rnd.choice((0.0, 0.5, 1.0))), mixed(rnd.randint(1, 6), rnd.choice((0.0, 0.5, 1.0)))
+        for name, fn in ops.items():
+            if n > 19 and name in ("split", "rsplit", "split_terminator"):
+                continue
+            sk.stats(reset=True)
+            keep = fn(s, p, o, to)
+            sk.flush()
+            c2 = sk.stats()["max_input_sum_c2"]
+            assert c2 <= BUDGET, (name, trial, n, p_enc, len(p), len(to), c2)
+            del keep
+    sk.set_auto_flush(8192)
+
+
+def test_noise_figure_stays_with_a_handle_and_can_be_declared(sk):
+    """find hands its index back as sums of up to 57 bootstrap outputs; an uploaded ciphertext counts as 1.  A result
+    that left the library and came back is declared with fhs_char_set_noise, and from then on the library treats it
+    like its own handle: refreshed on the way into the next operator."""
+    sk.set_mode(1)
+    sk.set_auto_flush(0)
+    idx = sk.find(sk.dummy_string(200), sk.dummy_string(3))
+    sk.flush()
+    assert 4 < idx.sum_c2() <= 57
+    back = sk.dummy_string(1)[0]                 # stands for: download idx, ship it, upload it again
+    assert back.sum_c2() == 1
+    back.set_noise(idx.sum_c2())
+    assert back.sum_c2() == idx.sum_c2()
+    other = sk.dummy_string(1)[0]
+    for c in (idx, back):
+        sk.stats(reset=True)
+        keep = c.eq(other)                       # weights 1, 4 on its digits: 17 x 57 without the refresh
+        sk.flush()
+        st = sk.stats()
+        assert st["max_input_sum_c2"] <= BUDGET and st["pbs_executed"] >= 4 + 2     # 4 refreshes + the comparison
+        del keep
     sk.set_auto_flush(8192)
