@@ -72,6 +72,11 @@ def parse():
                     help="level-skewed batching without round alignment of the launch groups (fhs_set_tick_balance off)")
     ap.add_argument("--skip-single-op", action="store_true", help="skip single-op latency / end-to-end / as-written")
     ap.add_argument("--skip-extras", action="store_true", help="skip the configs 3-5 section of the default run")
+    ap.add_argument("--as-written-fullsize", action="store_true",
+                    help="also RUN the reference-order (as written) DAGs of configs 3-5 at full size on the GPU -- find 256, "
+                         "eq_ignore_case 4096, le 4096, replace 256: about two minutes -- and compare with the fused results; "
+                         "without it the line quotes the figures recorded in profiles/r04_as_written_fullsize.json")
+    ap.add_argument("--skip-sweep", action="store_true", help="skip the contains sweep over 64 / 256 / 1024 / 4096 characters")
     ap.add_argument("--watchdog", type=float, default=900.0,
                     help="multi-GPU runs: seconds the legs AFTER the timed measurement may take before rank 0 prints the "
                          "headline line it already has and every rank exits (0 = off)")
@@ -306,11 +311,18 @@ def load_counters():
     """Hardware-counted figures of the committed kernels (rocprofv3 --pmc passes of THIS bench command, profiles/README.md):
     round 3's for the kernels re-profiled this round, round 2's for the others."""
     out = {}
-    for name in ("r02_counters.json", "r03_counters.json"):
+    for name in ("r02_counters.json", "r03_counters.json", "r04_counters.json"):
         try:
             out.update(json.load(open(os.path.join(ROOT, "profiles", name))))
         except Exception:
             pass
+    # The figures describe the kernel that was PROFILED: tools/pmc_to_json.py recorded the git blob hashes of the sources
+    # it was compiled from; a kernel whose sources have changed since keeps its live timing but loses the counted
+    # figures (roofline.counters_stale, VERDICT r3 item 6) until it is profiled again.
+    from fhestring_amd.kernel_sources import stale_sources
+    for kernel, e in out.items():
+        if isinstance(e, dict):
+            e["_stale_files"] = stale_sources(kernel, e.get("source_blobs"))
     return out
 
 
@@ -323,12 +335,20 @@ def roofline_for(kernel, pbs_per_launch, launch_ms, n_launches, counters, traffi
     r = {"bound": "fp64_valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
          "traffic": traffic, "kernel": kernel, "avg_launch_ms": launch_ms, "launches": n_launches,
          "avg_pbs_per_launch": pbs_per_launch}
-    if flop and launch_ms > 0:
+    stale = c.get("_stale_files")
+    r["counters_stale"] = bool(stale)
+    if stale:
+        r["counters_stale_files"] = stale
+        r["counters_stale_note"] = ("the kernel's sources changed after profiles/*_counters.json was taken: the hardware-"
+                                    "counted flop per PBS is not quoted for code it does not describe (re-run the --pmc "
+                                    "passes of profiles/README.md and tools/pmc_to_json.py)")
+    elif flop and launch_ms > 0:
         r["achieved"] = pbs_per_launch * flop / (launch_ms * 1e-3) / 1e12
         r["frac"] = r["achieved"] / FP64_VALU_PEAK_TFLOPS
-    r["counters"] = {k: c.get(k) for k in ("fp64_flop_per_pbs", "valu_insts_per_pbs", "fp64_insts_per_pbs",
+    r["counters"] = {k: (None if stale else c.get(k)) for k in ("fp64_flop_per_pbs", "valu_insts_per_pbs", "fp64_insts_per_pbs",
                                            "valu_busy_frac_of_simd", "lds_array_busy_frac", "wave_wait_frac",
                                            "wave_issue_stall_frac", "clock_ghz", "l1_hit_frac", "l2_hit_frac", "profile")}
+    r["counters"]["source_rev"] = c.get("source_rev")
     if launch_ms > 0:
         # keys streamed once per launch at least: Fourier-domain BSK (pair key: 371 x 12 polynomials x 16 KiB) + KSK planes
         key_bytes = {"blind_rotate_mb2_kernel": 371 * 12 * 16384 + 2048 * 5 * 743 * 8,
@@ -848,6 +868,68 @@ def _main(safety, args):
             cfg4_scaling[str(n)] = {"ms_per_op": best[0] * 1e3, "pbs": best[1]["pbs_executed"], "levels": best[1]["levels"]}
             del keep, w
 
+    # north_star's size range for contains: ONE contains_clear, m = 4, hit, on 64 / 256 /
+    # 1024 / 4096 characters (src/server_key/mod.rs:151-182, :198-211) -- a single request, nothing batched around it
+    contains_sweep = None
+    if extras is not None and world == 1 and not args.skip_sweep:
+        stage[0] = "contains sweep"
+        contains_sweep = {}
+        for n in (64, 256, 1024, 4096):
+            w = Workload(args, ck, sks[:1], [None], 0, 1, op="contains", chars=n, strings=1)
+            keep = w.step(0); sks[0].flush(); sync()
+            best = None
+            for _ in range(3):
+                sks[0].stats(reset=True)
+                t0 = time.perf_counter()
+                keep = w.step(0); sks[0].flush(); sync()
+                d = time.perf_counter() - t0
+                if best is None or d < best[0]:
+                    best = (d, sks[0].stats(), sks[0].level_widths())
+            w.check(keep)
+            contains_sweep[str(n)] = {"ms_per_op": best[0] * 1e3, "pbs": best[1]["pbs_executed"], "levels": best[1]["levels"],
+                                      "pbs_per_s": best[1]["pbs_executed"] / best[0], "pattern_len": w.m, "found": 1,
+                                      "level_widths": [int(x) for x in best[2]][:16]}
+            del keep, w
+        contains_sweep["note"] = ("one contains_clear (m = 4, hit) alone on the GPU, best of 3; find / find_clear stop at "
+                                  "254 + m characters: the reference panics beyond a u8 index (mod.rs:1025-1027), so "
+                                  "find has no 1024 / 4096 rows")
+
+    # the reference-order DAGs of configs 3-5 EXECUTED at full size: measured ms beside the planner's
+    # shapes below, each result compared with the fused DAG's on the same ciphertexts and with Python
+    aw_full = None
+    if args.as_written_fullsize and world == 1 and rank == 0:
+        aw_full = {}
+        sk0 = sks[0]
+        for name, op, n in (("cfg3_find_encrypted_256", "find_enc", 256), ("cfg4_replace_256", "replace", 256),
+                            ("cfg5_eq_ignore_case_4096", "eq_ignore_case", 4096), ("cfg5_le_4096", "le", 4096)):
+            stage[0] = "as written at full size: " + name
+            w = Workload(args, ck, [sk0], [None], 0, 1, op=op, chars=n, strings=1)
+            dec = (lambda o: ck.decrypt(o[0])) if op == "replace" else (lambda o: ck.decrypt_char(o[0]))
+            sk0.set_mode(1)
+            fused = w.step(0); sk0.flush(); sync()
+            t0 = time.perf_counter()
+            fused = w.step(0); sk0.flush(); sync()
+            fused_ms = (time.perf_counter() - t0) * 1e3
+            v_fused = dec(fused)
+            sk0.set_mode(0)
+            sk0.stats(reset=True)
+            t0 = time.perf_counter()
+            out = w.step(0); sk0.flush(); sync()
+            ms = (time.perf_counter() - t0) * 1e3
+            stw = sk0.stats()
+            sk0.set_mode(1)
+            w.check(out)                                                  # against Python
+            v_aw = dec(out)
+            aw_full[name] = {"ms": ms, "pbs": stw["pbs_executed"], "pbs_constant_folded": stw["pbs_folded"],
+                             "levels": stw["levels"], "pbs_per_s": stw["pbs_executed"] / (ms * 1e-3),
+                             "fused_ms": fused_ms, "matches_fused": bool(v_aw == v_fused),
+                             "matches_python": True, "workload": w.describe()}
+            sys.stderr.write("as written, full size: %s %.1f ms, %d PBS, %d levels (fused %.1f ms)\n" % (
+                name, ms, stw["pbs_executed"], stw["levels"], fused_ms))
+            sys.stderr.flush()
+            assert v_aw == v_fused, ("as-written and fused results differ", name, v_aw, v_fused)
+            del fused, out, w
+
     # the as-written (reference op order) DAGs of configs 3-5: recorded and levelised by a planner context, nothing runs
     as_written_shapes = None
     if extras is not None and rank == 0:
@@ -873,8 +955,20 @@ def _main(safety, args):
                     "reference's own cost model gives 36.9 M PBS / 16 413 levels (SURVEY 8a: its radix ops cost 13-15 "
                     "PBS where this build's cost 7-11)" % (b["pbs"] / a["pbs"], b["levels"] / a["levels"])}
         as_written_shapes["note"] = ("FHS_MODE_AS_WRITTEN through fhs_ctx_create_planner: the reference's op order with "
-                                     "this build's radix decompositions; executed + constant-folded = the op count")
+                                     "this build's radix decompositions; executed + constant-folded = the op count; "
+                                     "`measured` = the same DAG executed at full size on one MI355X")
         pk.close()
+        # measured beside the shapes: this run's (--as-written-fullsize) or the recorded ones of that same leg
+        measured, src = aw_full, "this run (--as-written-fullsize)"
+        if measured is None:
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", "r04_as_written_fullsize.json")))
+                measured, src = rec["as_written_fullsize"], "recorded: profiles/r04_as_written_fullsize.json (%s)" % rec.get("command", "")
+            except Exception:
+                measured = None
+        for k, v in (measured or {}).items():
+            if k in as_written_shapes:
+                as_written_shapes[k]["measured"] = dict(v, source=src)
 
     pbs_local = st["pbs_executed"]
     stage[0] = "final all_reduce of the figures"
@@ -945,6 +1039,9 @@ def _main(safety, args):
                        "exchange": exchange},
             "ms_per_op": dt / args.steps / wl.n_strings * 1e3,
             "median_ms_per_step": statistics.median(rep_ms) if rep_ms else None,
+            # the SURVEY 8(d) protocol's figure (median of >= 5 repeats of `repeat_steps` steps: the narrow-level drain is amortised
+            # over fewer steps than in the contract's K-step region, so it reads lower than `value`)
+            "value_median_protocol": (pbs_total / args.steps / (statistics.median(rep_ms) * 1e-3)) if rep_ms else None,
             "repeat_ms_per_step": rep_ms,
             "repeat_steps": n_rep_steps,
             "pbs_per_op": pbs_total / args.steps / wl.n_strings,
@@ -1012,6 +1109,10 @@ def _main(safety, args):
                 "kernel is FP64-issue-bound, see frac")
         if larger:
             line["larger_batch"] = larger
+        if contains_sweep:
+            line["contains_sweep"] = contains_sweep
+        if aw_full:
+            line["as_written_fullsize"] = aw_full
         if cfg4_scaling:
             line["cfg4_replace_scaling"] = cfg4_scaling
         if as_written_shapes:

@@ -20,6 +20,7 @@ SEED = 0xF5E57121
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: minutes of GPU time (still part of -m gpu)")
 
 
 @pytest.fixture(scope="session")

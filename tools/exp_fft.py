@@ -11,7 +11,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "fhestring_amd", "csrc")
-OUT = os.path.join(ROOT, "tools", "ablate_build")
+# round 3 built into tools/ablate_build (now in .gpurunignore: 20 stale libraries travelled with every push); variants
+# that have to reach the GPU box go to tools/exp_build (git-ignored, NOT gpurun-ignored) and are deleted after the run
+OUT = os.environ.get("FHS_EXP_OUT", os.path.join(ROOT, "tools", "exp_build"))
 FILES = ["fft_kernels.hip", "fft_transform.h", "fft_device.h"]
 
 K, T, D = FILES
@@ -82,6 +84,76 @@ ACC52 = {
 }
 
 
+# ---- TIMING ONLY (round 4): one LDS transpose per transform replaced by gfx950's permlane swaps ----
+# The stages on index bits 5 and 4 stay in layout A: v_permlane32_swap_b32 / v_permlane16_swap_b32 exchange lane bit 5 / 4
+# with a register bit (2 x 32 instructions per transform: 16 points x 4 dwords, two registers per instruction), so only
+# the transpose that brings bits 3..0 into the registers is left.  Same butterflies and twiddle products as the product
+# kernel, one transpose (16 ds_write_b128 + 16 ds_read_b128 + 2 wave barriers) less per transform; the VALUES are wrong
+# (the twiddles are not re-derived for the new layout) -- this variant only answers what the instruction mix costs.
+_SWAP_HELPER = (
+    "// per-lane twiddle bases: rows (re, im) x {B: G=1,2,4,8; C: G=4,8}\n",
+    "template <int W, int DST> __device__ __forceinline__ void swap_round(cplx (&z)[16]) {\n"
+    "#pragma unroll\n"
+    "    for (int p = 0; p < 16; p++) {\n"
+    "        if (p & DST) continue;\n"
+    "        double *a[2] = {&z[p].r, &z[p].i}, *b[2] = {&z[p + DST].r, &z[p + DST].i};\n"
+    "#pragma unroll\n"
+    "        for (int h = 0; h < 2; h++) {\n"
+    "            const uint64_t x = __builtin_bit_cast(uint64_t, *a[h]), y = __builtin_bit_cast(uint64_t, *b[h]);\n"
+    "            uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32), yl = (uint32_t)y, yh = (uint32_t)(y >> 32);\n"
+    "            if (W == 32) {\n"
+    "                auto l = __builtin_amdgcn_permlane32_swap(xl, yl, false, false); xl = l[0]; yl = l[1];\n"
+    "                auto u = __builtin_amdgcn_permlane32_swap(xh, yh, false, false); xh = u[0]; yh = u[1];\n"
+    "            } else {\n"
+    "                auto l = __builtin_amdgcn_permlane16_swap(xl, yl, false, false); xl = l[0]; yl = l[1];\n"
+    "                auto u = __builtin_amdgcn_permlane16_swap(xh, yh, false, false); xh = u[0]; yh = u[1];\n"
+    "            }\n"
+    "            *a[h] = __builtin_bit_cast(double, ((uint64_t)xh << 32) | xl);\n"
+    "            *b[h] = __builtin_bit_cast(double, ((uint64_t)yh << 32) | yl);\n"
+    "        }\n"
+    "    }\n"
+    "}\n"
+    "// per-lane twiddle bases: rows (re, im) x {B: G=1,2,4,8; C: G=4,8}\n")
+PERMLANE = {T: [
+    _SWAP_HELPER,
+    ("    stages_uniform<false>(z, store_hook{slotA(lds, lane), z, 68, 0});             // slot A of register r: 68 r\n"
+     "    __builtin_amdgcn_wave_barrier();\n"
+     "    {\n"
+     "        const cplx *rd = slotB(lds, lane);\n"
+     "#pragma unroll\n"
+     "        for (int q = 0; q < 16; q++) {                    // in the order stage t = 32 pairs them: (p, p + 8)\n"
+     "            const int p = (q >> 1) + 8 * (q & 1);\n"
+     "            z[p] = rd[4 * p + (p >> 2)];\n"
+     "        }\n"
+     "    }\n"
+     "    __builtin_amdgcn_wave_barrier();\n"
+     "    stage_lane<false, 8>(z, tw.re[0], tw.im[0]);\n",
+     "    stages_uniform<false>(z, no_hook());\n"
+     "    swap_round<32, 8>(z);\n"
+     "    stage_lane<false, 8>(z, tw.re[0], tw.im[0]);\n"
+     "    swap_round<16, 4>(z);\n"),
+    ("    stage_lane<true, 8>(z, tw.re[0], tw.im[0], store_hook{slotB(lds, lane), z, 4, 1});\n"
+     "    __builtin_amdgcn_wave_barrier();\n"
+     "    {\n"
+     "        const cplx *rd = slotA(lds, lane);\n"
+     "#pragma unroll\n"
+     "        for (int r = 0; r < 16; r++) z[r] = rd[68 * r];\n"
+     "    }\n"
+     "    __builtin_amdgcn_wave_barrier();\n",
+     "    swap_round<16, 4>(z);\n"
+     "    stage_lane<true, 8>(z, tw.re[0], tw.im[0]);\n"
+     "    swap_round<32, 8>(z);\n"),
+]}
+# the same with only ONE of the two swap rounds per transform (32 instead of 64 swap instructions): what the second costs
+PERMLANE_HALF = {T: [PERMLANE[T][0],
+                     (PERMLANE[T][1][0], PERMLANE[T][1][1].replace("    swap_round<16, 4>(z);\n", "")),
+                     (PERMLANE[T][2][0], PERMLANE[T][2][1].replace("    swap_round<16, 4>(z);\n", ""))]}
+# ... and with NO swap at all: the ceiling of removing one transpose per transform for free
+PERMLANE_FREE = {T: [PERMLANE[T][0],
+                     (PERMLANE[T][1][0], PERMLANE[T][1][1].replace("    swap_round<16, 4>(z);\n", "").replace("    swap_round<32, 8>(z);\n", "")),
+                     (PERMLANE[T][2][0], PERMLANE[T][2][1].replace("    swap_round<16, 4>(z);\n", "").replace("    swap_round<32, 8>(z);\n", ""))]}
+
+
 def merge(*vs):
     out = {}
     for v in vs:
@@ -117,6 +189,9 @@ VARIANTS = {
     "acc52": ACC52,
     "inv6_acc52": merge(INV6, ACC52),
     "all3": merge(ONE_BARRIER, INV6, ACC52),
+    "permlane": PERMLANE,
+    "permlane_half": PERMLANE_HALF,
+    "permlane_free": PERMLANE_FREE,
 }
 VARIANTS.update(TUNE)
 

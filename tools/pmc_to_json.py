@@ -3,13 +3,24 @@
     python tools/pmc_to_json.py OUT.json DIR [DIR ...]        (each DIR = one rocprofv3 -d output of the SAME command)
 
 Per kernel: dispatches, average duration, and counters averaged per dispatch; derived figures per PBS assume the PBS
-count of the wide launch given by --pbs (default 3968 = the bench's 8 x 64-char contains level)."""
+count of the wide launch given by --pbs (default 3968 = the bench's 8 x 64-char contains level).  Every kernel's entry
+records the git blob hashes of the sources it was compiled from (`source_blobs`, fhestring_amd/kernel_sources.py): run
+this from the tree that was profiled.
+
+    python tools/pmc_to_json.py --stamp REV FILE.json [kernel ...]
+
+stamps an EXISTING counters file with the hashes the sources had at git revision REV (the commit the profile was taken
+from), for files written before the hashes were recorded."""
 import csv
 import glob
 import json
+import os
 import sqlite3
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fhestring_amd.kernel_sources import source_blobs          # noqa: E402
 
 
 def kname(n):
@@ -32,7 +43,23 @@ def rows(d):
             yield kname(r["Kernel_Name"]), r["Counter_Name"], float(r["Counter_Value"]), (f, r["Dispatch_Id"]), dur
 
 
+def stamp(rev, path, only):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = lambda name: subprocess.check_output(["git", "-C", root, "show", "%s:fhestring_amd/csrc/%s" % (rev, name)])
+    full = subprocess.check_output(["git", "-C", root, "rev-parse", rev], text=True).strip()
+    d = json.load(open(path))
+    for k, e in d.items():
+        if only and k not in only:
+            continue
+        e["source_blobs"] = source_blobs(k, read)
+        e["source_rev"] = full
+    json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[1] == "--stamp":
+        return stamp(sys.argv[2], sys.argv[3], sys.argv[4:])
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     pbs = 3968
     for a in sys.argv[1:]:
@@ -97,6 +124,8 @@ def main():
             e["pbs_per_dispatch_assumed"] = n
         e["profile"] = "rocprofv3 --kernel-trace --pmc ... -- python3 bench.py --steps 3 --warmup 1 --cpu-pbs 0 " \
                        "--skip-single-op --skip-secondary --skip-extras --pipelines 1 (separate passes; tools/pmc_to_json.py)"
+        # what was compiled when these counters were taken: bench.py drops the figures when the tree has moved on
+        e["source_blobs"] = source_blobs(short)
         res[short] = e
     json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "per_dispatch"} for k, v in res.items()}, indent=1))
