@@ -840,6 +840,30 @@ def _main(safety, args):
                 dists[0].level_parallel(False)
             extras[op] = {"ms_local": d * 1e3, "pbs_local": float(s2["pbs_executed"]), "levels": s2["levels"],
                           "workload": w.describe(), "parallelism": w.parallelism()}
+            if op == "find_enc" and world == 1:
+                # requests streaming in (level-skewed batching): one fhs_submit + one fhs_pump per find, so
+                # the five narrow tail levels of find k ride in the launch groups of finds k+1 .. k+5 instead of paying
+                # one bootstrap latency each on an idle chip -- what a server under load sees per request
+                n_req = 12
+                sync()
+                sks[0].stats(reset=True)
+                t0 = time.perf_counter()
+                outs_s = []
+                for _ in range(n_req):
+                    outs_s.append(w.step(0))
+                    sks[0].submit()
+                    sks[0].pump(1)
+                sks[0].flush(wait=False)
+                sync()
+                ds = time.perf_counter() - t0
+                st_s = sks[0].stats()
+                for o in outs_s:
+                    w.check(o)
+                extras[op]["streamed"] = {"requests": n_req, "ms_per_op": ds / n_req * 1e3,
+                                          "pbs_per_s": st_s["pbs_executed"] / ds,
+                                          "note": "12 finds submitted back to back, one launch group pumped per request "
+                                                  "(fhs_submit / fhs_pump); ms_per_op above is ONE find alone"}
+                del outs_s
             if multi_bit is not None:                     # the same op once more in the two-bit f64 arithmetic
                 set_arith("mb2")
                 keep = w.step(0); sks[0].flush(); sync()
@@ -1127,6 +1151,8 @@ def _main(safety, args):
                                               "workload": e["workload"], "parallelism": e["parallelism"]}
                 if "ms_two_bit" in e:
                     line["configs"][names[op]]["ms_per_op_multi_bit"] = e["ms_two_bit"]
+                if "streamed" in e:
+                    line["configs"][names[op]]["streamed"] = e["streamed"]
         if args.cpu_pbs != 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_pbs, single["level_widths"] if single else None)
             if extras:

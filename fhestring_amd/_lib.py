@@ -211,6 +211,8 @@ def _declare(L):
     L.fhs_dist_init_host_transport.restype = i
     L.fhs_dist_shutdown.argtypes = [vp]
     L.fhs_dist_shutdown.restype = i
+    L.fhs_dist_abort.argtypes = [vp]
+    L.fhs_dist_abort.restype = i
     L.fhs_dist_rank.argtypes = [vp]
     L.fhs_dist_rank.restype = i
     L.fhs_dist_world.argtypes = [vp]

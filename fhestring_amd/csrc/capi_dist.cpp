@@ -102,6 +102,13 @@ int fhs_dist_init_host_transport(fhs_ctx *c, int rank, int world, fhs_allgather_
     return c->eng.ctx.dist.init_host(rank, world, fn, user, c->eng.ctx.err);
 }
 
+int fhs_dist_abort(fhs_ctx *c) {
+    if (!c) return FHS_ERR_ARG;
+    c->eng.level_parallel = false;
+    c->eng.ctx.dist.shutdown(true);                          // no flush, no stream wait, no collective teardown
+    return FHS_OK;
+}
+
 int fhs_dist_shutdown(fhs_ctx *c) {
     if (!c) return FHS_ERR_ARG;
     if (int rc = c->eng.flush()) return rc;

@@ -92,8 +92,30 @@ int Context::init(int device_id) {
         return fail(-2, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
     HIP_TRY(prepare_device_for_kernels(), "hipFuncSetAttribute (dynamic LDS)");
     HIP_TRY(prepare_device_for_fft4(), "hipFuncSetAttribute (dynamic LDS, 4-wavefront kernel)");
-    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
-    wg_slots = 4 * prop.multiProcessorCount;
+    // FHS_STREAM_CU_MASK=<hex word>[,<hex word>...] (32 CUs per word, lowest CUs first): this context's stream only
+    // runs on the compute units of the mask (hipExtStreamCreateWithCUMask) and the persistent kernels size their grid for
+    // them.  An experiment switch (tools/exp_cumask.py, DESIGN.md section 5d: a narrow dependency level of one request on
+    // a slice of the chip beside another request's wide level), not a tuning knob of the product.
+    int cus = prop.multiProcessorCount;
+    if (const char *m = std::getenv("FHS_STREAM_CU_MASK")) {
+        std::vector<uint32_t> mask;
+        int bits = 0;
+        for (const char *q = m; *q;) {
+            char *end = nullptr;
+            const unsigned long w = std::strtoul(q, &end, 16);
+            if (end == q) break;
+            mask.push_back((uint32_t)w);
+            bits += __builtin_popcount((uint32_t)w);
+            q = *end == ',' ? end + 1 : end;
+            if (*end != ',') break;
+        }
+        if (mask.empty() || bits == 0 || bits > cus) return fail(-1, "FHS_STREAM_CU_MASK: expected hex words selecting 1.." + std::to_string(cus) + " CUs");
+        HIP_TRY(hipExtStreamCreateWithCUMask(&stream, (uint32_t)mask.size(), mask.data()), "hipExtStreamCreateWithCUMask");
+        cus = bits;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+    }
+    wg_slots = 4 * cus;
     // two-bit f64 kernel: one round of resident workgroups per launch (its 73 MB key only stays inside the L2 window
     // while the workgroups walk it together; consecutive launches overlap at the seams): 202 k instead of 183 k PBS/s at
     // 4096 rows, 214 k instead of 152 k at 14 336.  The classic f64 kernel (48 MB key) does not care below 4096 rows.

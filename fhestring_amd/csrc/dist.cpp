@@ -16,6 +16,7 @@ struct Rccl {
     int (*GetUniqueId)(UniqueId *) = nullptr;
     int (*CommInitRank)(void **comm, int nranks, UniqueId id, int rank) = nullptr;
     int (*CommDestroy)(void *comm) = nullptr;
+    int (*CommAbort)(void *comm) = nullptr;               // optional
     int (*AllGather)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t s) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     std::string load_error;
@@ -35,6 +36,7 @@ Rccl &rccl() {
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
         if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
@@ -123,8 +125,13 @@ int Dist::all_gather(const void *d_send, void *d_recv, size_t bytes, hipStream_t
     return 0;
 }
 
-void Dist::shutdown() {
-    if (comm_) (void)rccl().CommDestroy(comm_);
+void Dist::shutdown(bool abort) {
+    // ncclCommDestroy is collective-ish (it flushes outstanding work and may wait for the peers); after a bring-up that
+    // failed on SOME ranks the communicator is half-formed and a destroy can block for good: there the
+    // communicator is aborted -- ncclCommAbort frees it without talking to anyone -- or, without that entry point, left
+    // to the process exit.
+    if (comm_ && !abort) (void)rccl().CommDestroy(comm_);
+    else if (comm_ && rccl().CommAbort) (void)rccl().CommAbort(comm_);
     comm_ = nullptr;
     host_fn_ = nullptr;
     if (h_send_) (void)hipHostFree(h_send_);

@@ -27,7 +27,7 @@ class Dist {
     // d_send: bytes_per_rank bytes, d_recv: world * bytes_per_rank bytes (rank-major).  RCCL: enqueued on `s`;
     // host transport: synchronises `s`, stages through pinned host memory, calls back, uploads.
     int all_gather(const void *d_send, void *d_recv, size_t bytes_per_rank, hipStream_t s, std::string &err);
-    void shutdown();
+    void shutdown(bool abort = false);
     // exchange counters since init: calls of all_gather with a non-empty payload, bytes this rank contributed
     unsigned long long n_gathers = 0, bytes_sent = 0;
 

@@ -92,7 +92,9 @@ class Dist:
                 self.transport = "rccl"
             else:
                 if ok and sk.ctx._L.fhs_dist_world(sk.ctx._h) > 1:
-                    self.shutdown()
+                    # ncclCommInitRank succeeded HERE and failed on another rank: the communicator is half-formed, a
+                    # destroy may wait for peers that never joined -- abort it (no exchange with anyone)
+                    sk.ctx._check(sk.ctx._L.fhs_dist_abort(sk.ctx._h))
                 self.init_host_transport(lambda send: _torch_device_all_gather(dist, torch, send, world))
                 self.transport = "torch.distributed (fallback: the library's RCCL communicator did not come up)"
         else:

@@ -265,6 +265,10 @@ int fhs_dist_init(fhs_ctx *ctx, int rank, int world, const void *nccl_unique_id 
 typedef int (*fhs_allgather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
 int fhs_dist_init_host_transport(fhs_ctx *ctx, int rank, int world, fhs_allgather_fn fn, void *user);
 int fhs_dist_shutdown(fhs_ctx *ctx);
+/* Teardown after a bring-up that did not succeed on EVERY rank (fhs_dist_init returned 0 here and an error elsewhere):
+ * the half-formed communicator is aborted (ncclCommAbort: no exchange with the peers) instead of destroyed, nothing is
+ * flushed or waited for.  fhs_dist_shutdown on such a communicator may block. */
+int fhs_dist_abort(fhs_ctx *ctx);
 /* 1 if librccl.so.1 can be loaded with every entry point used here (dlopen + dlsym only: no communicator is made, no
  * GPU is touched).  ncclCommInitRank is collective: agree on this among ALL ranks before any of them calls
  * fhs_dist_init, or the ranks that could load it block forever waiting for the one that could not. */

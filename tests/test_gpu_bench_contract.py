@@ -97,9 +97,11 @@ def test_bench_json_line_contract():
     assert 0.5 * d["value"] < d["value_median_protocol"] < 1.2 * d["value"]
     assert abs(d["value_median_protocol"] * d["median_ms_per_step"] * 1e-3 - d["pbs_per_op"] * 8) < 1.0
     assert r["counters_stale"] is False and set(r["counters"]) >= {"source_rev"}
+    f3 = d["configs"]["cfg3_find_encrypted_256"]            # requests streaming in: the narrow tail rides along
+    assert f3["streamed"]["requests"] >= 8 and f3["streamed"]["ms_per_op"] < 0.9 * f3["ms_per_op"]
     m = aw["cfg5_le_4096"].get("measured")                  # recorded by bench.py --as-written-fullsize, or this run's
     if m is not None:
-        assert m["matches_fused"] and abs(m["levels"] - aw["cfg5_le_4096"]["levels"]) <= 4 and m["ms"] > 1000
+        assert m["matches_fused"] and abs(m["levels"] - aw["cfg5_le_4096"]["levels"]) <= 0.01 * m["levels"] and m["ms"] > 1000
 
 
 @pytest.mark.parametrize("op", ["find_enc", "eq_ignore_case"])
@@ -188,6 +190,6 @@ def test_as_written_dags_at_full_size_match_the_fused_ones():
     full, shapes = d["as_written_fullsize"], d["as_written_dag_shapes"]
     for k in ("cfg3_find_encrypted_256", "cfg4_replace_256", "cfg5_eq_ignore_case_4096", "cfg5_le_4096"):
         assert full[k]["matches_fused"] and full[k]["matches_python"]
-        assert full[k]["pbs"] == shapes[k]["pbs"] and abs(full[k]["levels"] - shapes[k]["levels"]) <= 4   # the planner's DAG ran
+        assert full[k]["pbs"] == shapes[k]["pbs"] and abs(full[k]["levels"] - shapes[k]["levels"]) <= 0.01 * full[k]["levels"] + 2   # the planner's DAG ran (round alignment may add launches)
         assert shapes[k]["measured"]["source"].startswith("this run")
         assert full[k]["ms"] > 5 * full[k]["fused_ms"]

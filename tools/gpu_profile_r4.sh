@@ -1,0 +1,40 @@
+#!/bin/bash
+# round-4 profile recipe (ONE gpurun call): every blind-rotation kernel on launches of a FIXED width through fhs_pbs_batch
+# (per-PBS figures need a known width) -- kernel stats, three SQ passes (<= 8 counters each), L2 / L1 hit counters and
+# fabric traffic one TCC/TCP-derived counter per pass; then the default bench under --kernel-trace --stats and its
+# FETCH_SIZE / WRITE_SIZE passes.  tools/pmc_to_json.py stamps every kernel's entry with the hashes of its sources.
+set -o pipefail
+O=gpurun_out/profile_r4
+mkdir -p $O
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+run() { name=$1; shift; timeout -k 10 240 "$@" > $O/$name.log 2> $O/$name.err; echo "$name rc=$?" | tee -a $O/status.txt; }
+SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS"
+SQ2="SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL GRBM_GUI_ACTIVE"
+SQ3="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"
+for A in 1 0 2 3; do          # f64 FFT (headline), exact NTT, two-bit f64, two-bit exact
+  W=3968; [ $A = 2 ] && W=4096        # the two-bit f64 kernel is launched in chunks of 1024 rows: 4 whole launches
+  PB="python3 tools/time_mb2.py --profile --arith=$A $W"
+  run a${A}_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/a${A}_stats -- $PB
+  run a${A}_pmc1 rocprofv3 --kernel-trace --output-format csv --pmc $SQ1 -d $O/a${A}_pmc1 -- $PB
+  run a${A}_pmc2 rocprofv3 --kernel-trace --output-format csv --pmc $SQ2 -d $O/a${A}_pmc2 -- $PB
+  run a${A}_pmc3 rocprofv3 --kernel-trace --output-format csv --pmc $SQ3 -d $O/a${A}_pmc3 -- $PB
+  if [ $A = 1 ]; then
+    for C in TCC_HIT_sum TCC_MISS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum FETCH_SIZE WRITE_SIZE; do
+      run a1_$C rocprofv3 --kernel-trace --output-format csv --pmc $C -d $O/a1_$C -- $PB
+    done
+  fi
+done
+# the narrow-level kernel on 64-row launches
+PB="python3 tools/time_mb2.py --profile --arith=1 64"
+run n64_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/n64_stats -- $PB
+run n64_pmc1 rocprofv3 --kernel-trace --output-format csv --pmc $SQ1 -d $O/n64_pmc1 -- $PB
+run n64_pmc3 rocprofv3 --kernel-trace --output-format csv --pmc $SQ3 -d $O/n64_pmc3 -- $PB
+# the default bench: kernel stats of the same command the driver runs (minus the side legs), and its fabric traffic
+BB="python3 bench.py --steps 20 --warmup 3 --cpu-pbs 0 --skip-single-op --skip-secondary --skip-extras --repeats 0"
+run bench_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- $BB
+run bench_fetch rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/bench_fetch -- $BB
+run bench_write rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/bench_write -- $BB
+find $O -name "*kernel_trace.csv" -size +1M -delete
+find $O -name "*agent_info.csv" -delete
+cat $O/status.txt
