@@ -12,7 +12,10 @@ run() { name=$1; shift; timeout -k 10 240 "$@" > $O/$name.log 2> $O/$name.err; e
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS"
 SQ2="SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL GRBM_GUI_ACTIVE"
 SQ3="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"
-for A in 1 0 2 3; do          # f64 FFT (headline), exact NTT, two-bit f64, two-bit exact
+# two gpurun calls (each well inside the 20-minute limit): PART=1 f64 FFT (headline) + exact NTT, PART=2 the rest
+PART=${PART:-1}
+if [ $PART = 1 ]; then ARITHS="1 0"; else ARITHS="2 3"; fi
+for A in $ARITHS; do          # f64 FFT (headline), exact NTT, two-bit f64, two-bit exact
   W=3968; [ $A = 2 ] && W=4096        # the two-bit f64 kernel is launched in chunks of 1024 rows: 4 whole launches
   PB="python3 tools/time_mb2.py --profile --arith=$A $W"
   run a${A}_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/a${A}_stats -- $PB
@@ -25,6 +28,7 @@ for A in 1 0 2 3; do          # f64 FFT (headline), exact NTT, two-bit f64, two-
     done
   fi
 done
+if [ $PART = 2 ]; then
 # the narrow-level kernel on 64-row launches
 PB="python3 tools/time_mb2.py --profile --arith=1 64"
 run n64_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/n64_stats -- $PB
@@ -35,6 +39,7 @@ BB="python3 bench.py --steps 20 --warmup 3 --cpu-pbs 0 --skip-single-op --skip-s
 run bench_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- $BB
 run bench_fetch rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/bench_fetch -- $BB
 run bench_write rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/bench_write -- $BB
+fi
 find $O -name "*kernel_trace.csv" -size +1M -delete
 find $O -name "*agent_info.csv" -delete
 cat $O/status.txt
