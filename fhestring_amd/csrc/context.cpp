@@ -92,6 +92,7 @@ int Context::init(int device_id) {
         return fail(-2, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
     HIP_TRY(prepare_device_for_kernels(), "hipFuncSetAttribute (dynamic LDS)");
     HIP_TRY(prepare_device_for_fft4(), "hipFuncSetAttribute (dynamic LDS, 4-wavefront kernel)");
+    HIP_TRY(prepare_device_for_keyswitch(), "hipFuncSetAttribute (dynamic LDS, wide keyswitch kernel)");
     // FHS_STREAM_CU_MASK=<hex word>[,<hex word>...] (32 CUs per word, lowest CUs first): this context's stream only
     // runs on the compute units of the mask (hipExtStreamCreateWithCUMask) and the persistent kernels size their grid for
     // them.  An experiment switch (tools/exp_cumask.py, DESIGN.md section 5d: a narrow dependency level of one request on

@@ -126,8 +126,125 @@ __global__ __launch_bounds__(256) void keyswitch_mfma_kernel(const int8_t *__res
     }
 }
 
+// Wide batches (round 4).  The kernel above is LATENCY-bound, not MFMA- or bandwidth-bound: one fragment set (9 KB) in
+// flight per wavefront, two wavefronts per SIMD, 8 matrix instructions (256 cycles) between round trips to the L2 --
+// 12 % of the i8 matrix peak at 3968 rows.  Here
+//  * a wavefront owns 64 ciphertexts x 32 columns x 8 planes: 16 accumulators = 256 registers, the accumulation half of
+//    the unified register file (one wavefront per SIMD), and every key fragment feeds two matrix instructions;
+//  * the operands reach the matrix cores through an LDS ring of KS2_DEPTH k-steps filled by direct global -> LDS loads
+//    (global_load_lds_dwordx4: a wave-wide 1-KB fragment lands in LDS in fragment order, no registers held while it
+//    flies): the 8 key fragments of a k-step are loaded ONCE per workgroup and read by its 4 wavefronts, each wavefront
+//    adds its own two digit fragments -- 16 KB per k-step and workgroup, KS2_DEPTH - 1 k-steps in flight behind 512 cycles
+//    of matrix work per k-step and wavefront;
+//  * workgroup -> tile mapping is XCD-aware: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an
+//    L2), so XCD x takes column tiles 3x .. 3x + 2 for every ciphertext group -- each 4 MB L2 streams 3 of the 24 key
+//    column tiles (7.9 MB) to all its workgroups instead of all 24.
+constexpr int KS2_DEPTH = 8;
+constexpr int KS2_GROUP = 256;                  // ciphertexts per workgroup
+constexpr int KS2_MIN_BATCH = 1281;             // below: the split-K kernel above (fills the chip with small batches)
+constexpr int KS2_STAGE_BYTES = 16 * 1024;      // [8 key fragments][4 wavefronts x 2 digit fragments] of 1 KB
+constexpr int KS2_LDS_BYTES = KS2_DEPTH * KS2_STAGE_BYTES;
+
+namespace {
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+// one wave-wide 1-KB fragment: lane l's 16 bytes at g + l * 16 go to lds + l * 16
+__device__ __forceinline__ void frag_to_lds(const char *g_uniform, uint32_t lane_off, char *lds_uniform) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(g_uniform + lane_off), (lptr_t)lds_uniform, 16, 0, 0);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void keyswitch_mfma2_kernel(const int8_t *__restrict__ dig, const int8_t *__restrict__ planes,
+                                                                 const uint64_t *__restrict__ in, uint64_t *__restrict__ ks_out,
+                                                                 int B, int n_groups) {
+    extern __shared__ __attribute__((aligned(16))) char ks2_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int cg = xcd * 3 + idx % 3;                      // 32 columns
+    const int g = idx / 3;                                 // 256 ciphertexts
+    if (g >= n_groups) return;
+    const int tile0 = (g * 4 + wave) * 2;                  // two tiles of 32 ciphertexts
+    // what THIS wavefront brings in per k-step: key planes 2 wave, 2 wave + 1 (shared) and its own two digit fragments
+    const char *src[4];
+    src[0] = reinterpret_cast<const char *>(planes) + ((size_t)(2 * wave) * KS_COL_TILES + cg) * KS_STEPS * 1024;
+    src[1] = reinterpret_cast<const char *>(planes) + ((size_t)(2 * wave + 1) * KS_COL_TILES + cg) * KS_STEPS * 1024;
+    src[2] = reinterpret_cast<const char *>(dig) + (size_t)tile0 * KS_STEPS * 1024;
+    src[3] = src[2] + (size_t)KS_STEPS * 1024;
+    const int dst[4] = {(2 * wave) * 1024, (2 * wave + 1) * 1024, (8 + 2 * wave) * 1024, (9 + 2 * wave) * 1024};
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    auto fetch = [&](int ks, int ring) {                   // k-step ks -> ring slot `ring` % KS2_DEPTH
+        char *slot = ks2_smem + (ring % KS2_DEPTH) * KS2_STAGE_BYTES;
+#pragma unroll
+        for (int f = 0; f < 4; f++) frag_to_lds(src[f], lane_off + (uint32_t)ks * 1024u, slot + dst[f]);
+    };
+
+    v16i acc[2][KS_PLANES];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int b = 0; b < KS_PLANES; b++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[t][b][e] = 0;
+
+#pragma unroll
+    for (int d = 0; d < KS2_DEPTH - 1; d++) fetch(d, d);
+    for (int ks = 0; ks < KS_STEPS; ks++) {
+        // this wavefront's fragments of k-step ks have landed when at most the 4 x (KS2_DEPTH - 2) younger ones are
+        // still in flight; the barrier extends that to the other wavefronts' -- and says every wavefront is done reading
+        // the slot of k-step ks - 1, which the fetch below overwrites
+        // (a bare s_barrier: __syncthreads() would add a fence that waits for EVERY outstanding load, vmcnt(0))
+        // lgkmcnt(0): this wavefront's LDS reads of the previous k-step have RETURNED before it tells the others (by
+        // arriving) that the slot may be overwritten
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (KS2_DEPTH - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const int nx = ks + KS2_DEPTH - 1;
+        fetch(nx < KS_STEPS ? nx : KS_STEPS - 1, nx);      // tail: the in-flight count stays constant (the last k-step again, into a dead slot)
+        const char *slot = ks2_smem + (ks % KS2_DEPTH) * KS2_STAGE_BYTES + lane_off;
+        const v4i a0 = *reinterpret_cast<const v4i *>(slot + (8 + 2 * wave) * 1024);
+        const v4i a1 = *reinterpret_cast<const v4i *>(slot + (9 + 2 * wave) * 1024);
+#pragma unroll
+        for (int b = 0; b < KS_PLANES; b++) {
+            const v4i kb = *reinterpret_cast<const v4i *>(slot + b * 1024);
+            acc[0][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, kb, acc[0][b], 0, 0, 0);
+            acc[1][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, kb, acc[1][b], 0, 0, 0);
+        }
+    }
+
+    const int col = cg * 32 + (lane & 31);
+    if (col >= SMALL_CT) return;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        // pin the second tile's accumulators to the accumulation registers while the first tile is written out: read
+        // into vector registers all at once (what the register allocator does at the loop exit) the 256 of them spill
+        // into the main loop
+#pragma unroll
+        for (int b = 0; b < KS_PLANES; b++) asm volatile("" : "+a"(acc[1][b]));
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int ct = (tile0 + t) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            // straight-line arithmetic, one output at a time (scheduling barriers): hoisted above per-output branches the
+            // 256 accumulator reads would all be live at once and spill into the main loop
+            uint64_t v = 0;
+#pragma unroll
+            for (int b = 0; b < KS_PLANES; b++) v += (uint64_t)(int64_t)acc[t][b][e] << (8 * b);
+            uint64_t o = (uint64_t)0 - v;
+            const int ctc = ct < B ? ct : B - 1;          // rows >= B: computed on zero digits, never stored
+            if (col == LWE_N) o += in[(size_t)ctc * BIG_CT + BIG_N];
+            __builtin_amdgcn_sched_barrier(0);
+            if (ct < B) ks_out[(size_t)ct * SMALL_CT + col] = o;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+hipError_t prepare_device_for_keyswitch() {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(keyswitch_mfma2_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, KS2_LDS_BYTES);
+}
+
 size_t ks_planes_bytes() { return (size_t)KS_PLANES * KS_COL_TILES * KS_STEPS * 1024; }
-size_t ks_digits_bytes(int B) { return (size_t)((B + 127) / 128) * 4 * KS_STEPS * 1024; }   // whole groups of 4 tiles
+size_t ks_digits_bytes(int B) { return (size_t)((B + 255) / 256) * 8 * KS_STEPS * 1024; }   // whole groups of 8 tiles
 
 hipError_t launch_ksk_to_planes(const uint64_t *d_ksk, int8_t *d_planes, hipStream_t s) {
     hipLaunchKernelGGL(ksk_to_planes_kernel, dim3(KS_K), dim3(256), 0, s, d_ksk, d_planes);
@@ -138,9 +255,17 @@ hipError_t launch_keyswitch_mfma(const uint64_t *d_in, const int8_t *d_planes, i
                                  hipStream_t s) {
     if (B <= 0) return hipSuccess;
     const int tiles = (B + 31) / 32;
-    hipLaunchKernelGGL(ks_digits_kernel, dim3(((tiles + 3) / 4) * 128), dim3(256), 0, s, d_in, d_dig, B);
+    const bool wide = B >= KS2_MIN_BATCH;
+    hipLaunchKernelGGL(ks_digits_kernel, dim3(wide ? ((B + KS2_GROUP - 1) / KS2_GROUP) * KS2_GROUP : ((tiles + 3) / 4) * 128),
+                       dim3(256), 0, s, d_in, d_dig, B);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (wide) {
+        const int n_groups = (B + KS2_GROUP - 1) / KS2_GROUP;
+        hipLaunchKernelGGL(keyswitch_mfma2_kernel, dim3(KS_COL_TILES * n_groups), dim3(256), KS2_LDS_BYTES, s, d_dig, d_planes,
+                           d_in, d_ks_out, B, n_groups);
+        return hipGetLastError();
+    }
     int splits = 1;                                   // fill the 256 CUs when the batch is small
     const int tgroups = (tiles + 3) / 4;
     while (splits < 16 && tgroups * KS_COL_TILES * splits < 256) splits *= 2;

@@ -115,6 +115,7 @@ hipError_t launch_blind_rotate_mb2(const BlindRotateMb2Params &p, hipStream_t s)
 hipError_t launch_blind_rotate_ntt_mb2(const BlindRotateNttMb2Params &p, hipStream_t s);   // 4 wavefronts per ciphertext
 hipError_t prepare_device_for_ntt_mb2();
 hipError_t prepare_device_for_fft4();
+hipError_t prepare_device_for_keyswitch();      // > 64 KB dynamic LDS opt-in of the wide keyswitch kernel, per device
 // the scalar twiddle literals baked into fft_kernels.hip: W[16] (index 1 and even indices used), U[3]
 void fft_uniform_consts(double *w_re, double *w_im, double *u_re, double *u_im);
 // matrix-core keyswitch (ks_kernels.hip): KSK as 8 planes of balanced signed bytes in MFMA fragment order
