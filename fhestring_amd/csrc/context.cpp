@@ -249,7 +249,8 @@ int Context::keyswitch(const uint64_t *d_in, size_t B, hipStream_t s) {
         HIP_TRY(dig_buf.reserve(ks_digits_bytes((int)B)), "hipMalloc digits");
     }
     timer.begin(1, B, s);
-    hipError_t e = launch_keyswitch_mfma(d_in, d_ksk_planes, dig_buf.as<int8_t>(), ks_buf.as<uint64_t>(), (int)B, s);
+    hipError_t e = launch_keyswitch_mfma(d_in, d_ksk_planes, dig_buf.as<int8_t>(), ks_buf.as<uint64_t>(), (int)B, s,
+                                         wg_slots / 4);
     timer.end(s);
     if (e != hipSuccess) return hip_fail(e, "keyswitch launch");
     return 0;

@@ -12,6 +12,8 @@
 // ([tile][k-step][lane][16 bytes]) so that every operand load is one coalesced 1-KB access and no LDS is
 // needed; the 4 wavefronts of a workgroup share the key fragments through L1.
 // Replaces tfhe's keyswitch inside shortint::ServerKey::apply_lookup_table.
+#include <cstdlib>
+
 #include "pbs_kernels.h"
 
 namespace fhs {
@@ -53,6 +55,53 @@ __global__ __launch_bounds__(256) void ks_digits_kernel(const uint64_t *__restri
         }
 #pragma unroll
         for (int l = 0; l < KS_LEVEL; l++) dst[frag_off(r, i * KS_LEVEL + l)] = (int8_t)d[l];
+    }
+}
+
+// The same digits, one workgroup per TILE of 32 ciphertexts (round 4): lane = 32 * (k half) + row assembles the 16 bytes
+// of its fragment slot in registers, so a wavefront writes each 1-KB fragment with ONE coalesced 16-byte store per lane
+// (the kernel above writes single bytes, 16-byte runs 512 bytes apart: 0.13 ms per 3968 rows where 40 MB of output
+// should take 0.03).  A lane's 16 digits of k-step ks, half h are k = 32 ks + 16 h .. + 15, i.e. digits of the
+// coefficients (32 ks + 16 h) / 5 .. (32 ks + 16 h + 15) / 5 -- four of them, re-read from L1 by the next k-step.
+constexpr int KS_DIG_CHUNKS = 8;
+__global__ __launch_bounds__(256) void ks_digits_tile_kernel(const uint64_t *__restrict__ in, int8_t *__restrict__ dig, int B) {
+    const int tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int ct = tile * 32 + r;
+    const uint64_t *row = in + (size_t)(ct < B ? ct : 0) * BIG_CT;
+    v4i *dst = reinterpret_cast<v4i *>(dig + (size_t)tile * KS_STEPS * 1024) + lane;
+    // blockIdx.y = one of KS_DIG_CHUNKS slices of the 320 k-steps: ~1 000 workgroups for 3968 rows instead of 124
+    const int ks_begin = blockIdx.y * (KS_STEPS / KS_DIG_CHUNKS), ks_end = ks_begin + KS_STEPS / KS_DIG_CHUNKS;
+    for (int ks = ks_begin + wave; ks < ks_end; ks += 4) {
+        const int k0 = ks * 32 + h * 16;
+        const int i0 = k0 / KS_LEVEL, l0 = k0 - i0 * KS_LEVEL;     // first coefficient and its first level in this slot
+        uint32_t w[4] = {0, 0, 0, 0};
+        int pos = -l0;                                             // byte position of level 0 of coefficient i0 + c
+#pragma unroll
+        for (int c = 0; c < 4; c++, pos += KS_LEVEL) {
+            const int i = i0 + c;
+            int d[KS_LEVEL] = {0, 0, 0, 0, 0};
+            if (ct < B && i < BIG_N) {
+                const uint64_t a = row[i];
+                uint32_t v = (uint32_t)((a + (1ull << 48)) >> 49);   // closest representable on 15 bits
+#pragma unroll
+                for (int l = KS_LEVEL - 1; l >= 0; l--) {            // least significant level first
+                    int x = (int)(v & 7u);
+                    v >>= 3;
+                    if (x >= 4) { x -= 8; v += 1; }
+                    d[l] = x;
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < KS_LEVEL; l++) {
+                const int p = pos + l;
+                if (p >= 0 && p < 16) w[p >> 2] |= (uint32_t)(uint8_t)(int8_t)d[l] << (8 * (p & 3));
+            }
+        }
+        v4i o;
+        o.x = (int)w[0]; o.y = (int)w[1]; o.z = (int)w[2]; o.w = (int)w[3];
+        dst[(size_t)ks * 64] = o;
     }
 }
 
@@ -141,7 +190,7 @@ __global__ __launch_bounds__(256) void keyswitch_mfma_kernel(const int8_t *__res
 //    column tiles (7.9 MB) to all its workgroups instead of all 24.
 constexpr int KS2_DEPTH = 8;
 constexpr int KS2_GROUP = 256;                  // ciphertexts per workgroup
-constexpr int KS2_MIN_BATCH = 1281;             // below: the split-K kernel above (fills the chip with small batches)
+constexpr int KS2_MIN_BATCH = 129;              // below: the split-K kernel above (57 against 72 us at 64 rows; 89 against 76 at 256; FHS_KS_OLD_BELOW=n overrides for A/B runs)
 constexpr int KS2_STAGE_BYTES = 16 * 1024;      // [8 key fragments][4 wavefronts x 2 digit fragments] of 1 KB
 constexpr int KS2_LDS_BYTES = KS2_DEPTH * KS2_STAGE_BYTES;
 
@@ -156,11 +205,23 @@ __device__ __forceinline__ void frag_to_lds(const char *g_uniform, uint32_t lane
 
 __global__ __launch_bounds__(256, 1) void keyswitch_mfma2_kernel(const int8_t *__restrict__ dig, const int8_t *__restrict__ planes,
                                                                  const uint64_t *__restrict__ in, uint64_t *__restrict__ ks_out,
-                                                                 int B, int n_groups) {
+                                                                 int B, int n_groups, int full_blocks, int rem_tiles,
+                                                                 int rem_slices) {
     extern __shared__ __attribute__((aligned(16))) char ks2_smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    // 24 n_groups tiles on 256 CUs: the tiles beyond the last whole round (rem_tiles of them) are cut into rem_slices
+    // slices of K each, so that they fill ONE partial round instead of costing a whole one (3072 rows: 288 tiles = one
+    // round + 32 tiles x 8 slices); the slices add into rows the host zeroed (64-bit atomics, exact: wrapping sums)
+    int bid = blockIdx.x, ks_begin = 0, ks_end = KS_STEPS;
+    const bool sliced = bid >= full_blocks;
+    if (sliced) {
+        const int j = bid - full_blocks, slice = j / rem_tiles;
+        bid = full_blocks + j % rem_tiles;
+        ks_begin = slice * (KS_STEPS / rem_slices);
+        ks_end = ks_begin + KS_STEPS / rem_slices;
+    }
+    const int xcd = bid & 7, idx = bid >> 3;
     const int cg = xcd * 3 + idx % 3;                      // 32 columns
     const int g = idx / 3;                                 // 256 ciphertexts
     if (g >= n_groups) return;
@@ -188,8 +249,8 @@ __global__ __launch_bounds__(256, 1) void keyswitch_mfma2_kernel(const int8_t *_
             for (int e = 0; e < 16; e++) acc[t][b][e] = 0;
 
 #pragma unroll
-    for (int d = 0; d < KS2_DEPTH - 1; d++) fetch(d, d);
-    for (int ks = 0; ks < KS_STEPS; ks++) {
+    for (int d = 0; d < KS2_DEPTH - 1; d++) fetch(ks_begin + d, ks_begin + d);
+    for (int ks = ks_begin; ks < ks_end; ks++) {
         // this wavefront's fragments of k-step ks have landed when at most the 4 x (KS2_DEPTH - 2) younger ones are
         // still in flight; the barrier extends that to the other wavefronts' -- and says every wavefront is done reading
         // the slot of k-step ks - 1, which the fetch below overwrites
@@ -199,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void keyswitch_mfma2_kernel(const int8_t *_
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (KS2_DEPTH - 2)) : "memory");
         __builtin_amdgcn_s_barrier();
         const int nx = ks + KS2_DEPTH - 1;
-        fetch(nx < KS_STEPS ? nx : KS_STEPS - 1, nx);      // tail: the in-flight count stays constant (the last k-step again, into a dead slot)
+        fetch(nx < ks_end ? nx : ks_end - 1, nx);          // tail: the in-flight count stays constant (the last k-step again, into a dead slot)
         const char *slot = ks2_smem + (ks % KS2_DEPTH) * KS2_STAGE_BYTES + lane_off;
         const v4i a0 = *reinterpret_cast<const v4i *>(slot + (8 + 2 * wave) * 1024);
         const v4i a1 = *reinterpret_cast<const v4i *>(slot + (9 + 2 * wave) * 1024);
@@ -230,9 +291,12 @@ __global__ __launch_bounds__(256, 1) void keyswitch_mfma2_kernel(const int8_t *_
             for (int b = 0; b < KS_PLANES; b++) v += (uint64_t)(int64_t)acc[t][b][e] << (8 * b);
             uint64_t o = (uint64_t)0 - v;
             const int ctc = ct < B ? ct : B - 1;          // rows >= B: computed on zero digits, never stored
-            if (col == LWE_N) o += in[(size_t)ctc * BIG_CT + BIG_N];
+            if (col == LWE_N && ks_begin == 0) o += in[(size_t)ctc * BIG_CT + BIG_N];
             __builtin_amdgcn_sched_barrier(0);
-            if (ct < B) ks_out[(size_t)ct * SMALL_CT + col] = o;
+            if (ct < B) {
+                if (sliced) atomicAdd(reinterpret_cast<unsigned long long *>(ks_out + (size_t)ct * SMALL_CT + col), (unsigned long long)o);
+                else ks_out[(size_t)ct * SMALL_CT + col] = o;
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -252,18 +316,37 @@ hipError_t launch_ksk_to_planes(const uint64_t *d_ksk, int8_t *d_planes, hipStre
 }
 
 hipError_t launch_keyswitch_mfma(const uint64_t *d_in, const int8_t *d_planes, int8_t *d_dig, uint64_t *d_ks_out, int B,
-                                 hipStream_t s) {
+                                 hipStream_t s, int n_cus) {
     if (B <= 0) return hipSuccess;
     const int tiles = (B + 31) / 32;
-    const bool wide = B >= KS2_MIN_BATCH;
-    hipLaunchKernelGGL(ks_digits_kernel, dim3(wide ? ((B + KS2_GROUP - 1) / KS2_GROUP) * KS2_GROUP : ((tiles + 3) / 4) * 128),
-                       dim3(256), 0, s, d_in, d_dig, B);
+    static const int old_below = [] { const char *v = std::getenv("FHS_KS_OLD_BELOW"); return v ? std::atoi(v) : KS2_MIN_BATCH; }();
+    const bool wide = B >= old_below;
+    if (wide)
+        hipLaunchKernelGGL(ks_digits_tile_kernel, dim3(((B + KS2_GROUP - 1) / KS2_GROUP) * (KS2_GROUP / 32), KS_DIG_CHUNKS),
+                           dim3(256), 0, s, d_in, d_dig, B);
+    else
+        hipLaunchKernelGGL(ks_digits_kernel, dim3(((tiles + 3) / 4) * 128), dim3(256), 0, s, d_in, d_dig, B);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (wide) {
         const int n_groups = (B + KS2_GROUP - 1) / KS2_GROUP;
-        hipLaunchKernelGGL(keyswitch_mfma2_kernel, dim3(KS_COL_TILES * n_groups), dim3(256), KS2_LDS_BYTES, s, d_dig, d_planes,
-                           d_in, d_ks_out, B, n_groups);
+        const int tiles2 = KS_COL_TILES * n_groups, slots = n_cus > 0 ? n_cus : 256;   // one workgroup per CU
+        int full = tiles2 / slots * slots, rem = tiles2 - full, slices = 1;
+        if (rem > 0)
+            for (int c : {8, 4, 2})
+                if (rem * c <= slots) { slices = c; break; }
+        if (slices == 1) { full = tiles2; rem = 0; }
+        else {
+            // rows of the groups that own a sliced tile: zeroed, then overwritten by their unsliced tiles and added to
+            // by the slices (stream order: memset, then the one kernel)
+            const size_t row0 = (size_t)(full / 8 / 3) * KS2_GROUP;
+            if (row0 < (size_t)B) {
+                e = hipMemsetAsync(d_ks_out + row0 * SMALL_CT, 0, ((size_t)B - row0) * SMALL_CT * 8, s);
+                if (e != hipSuccess) return e;
+            }
+        }
+        hipLaunchKernelGGL(keyswitch_mfma2_kernel, dim3(full + rem * slices), dim3(256), KS2_LDS_BYTES, s, d_dig, d_planes,
+                           d_in, d_ks_out, B, n_groups, full, rem > 0 ? rem : 1, slices);
         return hipGetLastError();
     }
     int splits = 1;                                   // fill the 256 CUs when the batch is small

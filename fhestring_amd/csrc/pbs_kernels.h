@@ -123,7 +123,7 @@ size_t ks_planes_bytes();
 size_t ks_digits_bytes(int B);
 hipError_t launch_ksk_to_planes(const uint64_t *d_ksk, int8_t *d_planes, hipStream_t s);
 hipError_t launch_keyswitch_mfma(const uint64_t *d_in /*[B][2049]*/, const int8_t *d_planes, int8_t *d_dig /*scratch*/,
-                                 uint64_t *d_ks_out /*[B][743]*/, int B, hipStream_t s);
+                                 uint64_t *d_ks_out /*[B][743]*/, int B, hipStream_t s, int n_cus = 256);
 hipError_t launch_modswitch(const uint64_t *d_ks, uint32_t *d_ms /*[B][743]*/, int B, hipStream_t s);
 hipError_t launch_lincomb(const LinDesc *d_desc, const LinTerm *d_terms, uint64_t *d_out /*[n][2049]*/,
                           int n, hipStream_t s);

@@ -71,8 +71,13 @@ def oracle_ks_all(oracle_sk, wide_inputs):
         return np.stack(list(ex.map(oracle_sk.keyswitch_modswitch, cts)))
 
 
-@pytest.mark.parametrize("B", [1281, 3968, 4096])
+@pytest.mark.parametrize("B", [129, 256, 513, 600, 1024, 1281, 2048, 3072, 3329, 3968, 4096])
 def test_keyswitch_every_row_at_bench_width(exact_ctx, wide_inputs, oracle_ks_all, B):
+    """Every row against the oracle on every launch shape of the wide keyswitch kernel (round 4: LDS ring, 64 ciphertexts
+    per wavefront, tiles beyond the last whole round of 256 workgroups cut into K slices that add with 64-bit atomics):
+    129 / 256 = 24 tiles x 8 slices, 513 / 600 / 1024 = every tile sliced (72 / 72 / 96 tiles x 2), 1281 = 144 tiles unsliced, 2048 = 192 unsliced,
+    3072 = one round + 32 tiles x 8 slices, 3329 = 14 groups: 336 tiles = one round + 80 x 2, 3968 / 4096 = one round +
+    128 x 2; 3329 and 3968 also end inside a group of 256 (rows >= B are computed on zero digits and never stored)."""
     _, cts = wide_inputs
     got = exact_ctx.keyswitch_modswitch_batch(cts[:B])
     bad = np.nonzero((got != oracle_ks_all[:B]).any(axis=1))[0]
