@@ -14,7 +14,12 @@ SQ2="SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_I
 SQ3="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"
 # two gpurun calls (each well inside the 20-minute limit): PART=1 f64 FFT (headline) + exact NTT, PART=2 the rest
 PART=${PART:-1}
-if [ $PART = 1 ]; then ARITHS="1 0"; else ARITHS="2 3"; fi
+# PART=3: after the keyswitch rewrite late in the round -- kernel stats of the 3968-wide launches and the bench command again
+if [ $PART = 1 ]; then ARITHS="1 0"; elif [ $PART = 2 ]; then ARITHS="2 3"; else ARITHS=""; O=gpurun_out/profile_r4ks; mkdir -p $O; fi
+if [ $PART = 3 ]; then
+  run a1_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/a1_stats -- python3 tools/time_mb2.py --profile --arith=1 3968
+  run ks_pmc rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $O/ks_pmc -- python3 tools/time_mb2.py --profile --arith=1 3968
+fi
 for A in $ARITHS; do          # f64 FFT (headline), exact NTT, two-bit f64, two-bit exact
   W=3968; [ $A = 2 ] && W=4096        # the two-bit f64 kernel is launched in chunks of 1024 rows: 4 whole launches
   PB="python3 tools/time_mb2.py --profile --arith=$A $W"
@@ -28,7 +33,7 @@ for A in $ARITHS; do          # f64 FFT (headline), exact NTT, two-bit f64, two-
     done
   fi
 done
-if [ $PART = 2 ]; then
+if [ $PART != 1 ]; then
 # the narrow-level kernel on 64-row launches
 PB="python3 tools/time_mb2.py --profile --arith=1 64"
 run n64_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/n64_stats -- $PB
