@@ -645,6 +645,8 @@ def _main(safety, args):
 
         def on_sigterm():
             os.read(rfd, 1)
+            if safety.get("line_out"):           # the complete line is out already: leave, never print a second one
+                os._exit(EXIT_INCOMPLETE)
             bail("SIGTERM from the launcher (another rank failed or the run was cancelled)")
         th = threading.Thread(target=on_sigterm, daemon=True)
         th.start()
@@ -1169,11 +1171,13 @@ def _main(safety, args):
                     "4.4: 'extrapolated'); fused = the DAG the GPU runs, as_written = the reference's op order" % line["cpu_baseline"]["cores"])
         if safety.get("timer"):
             safety["timer"].cancel()
+        safety["line_out"] = True
         print(json.dumps(line))
         sys.stdout.flush()
     if safety.get("timer"):
         safety["timer"].cancel()
     safety["bail"] = None                    # the line is out: from here on failures are ordinary
+    safety["line_out"] = True
     if dist is not None:
         import threading
         def cut_short():                         # the line is out, but a rank that hangs while shutting down is a hang:
