@@ -84,6 +84,18 @@ def test_keyswitch_every_row_at_bench_width(exact_ctx, wide_inputs, oracle_ks_al
     assert bad.size == 0, ("rows differing from the oracle", bad[:10])
 
 
+def test_keyswitch_every_row_at_random_widths(exact_ctx, wide_inputs, oracle_ks_all):
+    """... and at 16 widths drawn between 129 and 4096 (whatever the tile count does to the round / slice split), plus
+    the widths around the kernel switch at 129 rows and around whole groups of 256."""
+    _, cts = wide_inputs
+    rnd = np.random.default_rng(20261004)
+    widths = sorted(set(int(x) for x in rnd.integers(129, 4097, 16)) | {127, 128, 255, 257, 2560, 2561, 2815, 2817})
+    for B in widths:
+        got = exact_ctx.keyswitch_modswitch_batch(cts[:B])
+        bad = np.nonzero((got != oracle_ks_all[:B]).any(axis=1))[0]
+        assert bad.size == 0, ("rows differing from the oracle at width", B, bad[:10])
+
+
 def _luts():
     from oracle import radix
     return np.stack([radix.lut_poly(n) for n in NAMES])
