@@ -94,9 +94,11 @@ def test_bench_json_line_contract():
     assert sw["64"]["pbs"] < sw["256"]["pbs"] < sw["1024"]["pbs"] < sw["4096"]["pbs"]
     assert sw["64"]["ms_per_op"] < sw["4096"]["ms_per_op"] and sw["4096"]["pbs_per_s"] > 3 * sw["64"]["pbs_per_s"]
     assert all(sw[k]["levels"] <= 12 and sw[k]["found"] == 1 for k in ("64", "256", "1024", "4096"))
-    assert 0.5 * d["value"] < d["value_median_protocol"] < 1.2 * d["value"]
+    assert 0.8 * d["value"] < d["value_median_protocol"] < 1.2 * d["value"]
     assert abs(d["value_median_protocol"] * d["median_ms_per_step"] * 1e-3 - d["pbs_per_op"] * 8) < 1.0
     assert r["counters_stale"] is False and set(r["counters"]) >= {"source_rev"}
+    ksr = r["keyswitch"]                                     # the matrix-core kernel of a launch group, timed live
+    assert ksr["bound"] == "mfma" and 0.05 < ksr["frac"] < 1.0 and ksr["share_of_step_time"] < 0.03
     f3 = d["configs"]["cfg3_find_encrypted_256"]            # requests streaming in: the narrow tail rides along
     assert f3["streamed"]["requests"] >= 8 and f3["streamed"]["ms_per_op"] < 0.9 * f3["ms_per_op"]
     m = aw["cfg5_le_4096"].get("measured")                  # recorded by bench.py --as-written-fullsize, or this run's
