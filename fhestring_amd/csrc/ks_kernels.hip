@@ -272,6 +272,9 @@ __global__ __launch_bounds__(256, 1) void keyswitch_mfma2_kernel(const int8_t *_
         }
     }
 
+    // the tail's dummy fetches are still writing into this workgroup's LDS: let them land before any wavefront can
+    // leave (the allocation goes to the next workgroup when the last one does)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int col = cg * 32 + (lane & 31);
     if (col >= SMALL_CT) return;
 #pragma unroll
