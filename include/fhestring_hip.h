@@ -366,7 +366,8 @@ int fhs_get_stats(fhs_ctx *ctx, fhs_stats *out);
  * (tfhe 0.5.2, Cargo.lock:416-433): query it here before the download ... */
 int fhs_char_sum_c2(fhs_ctx *ctx, fhs_char_t h, uint64_t *out);
 /* ... and declare it after fhs_upload / fhs_upload_string of such a ciphertext (uploads count as 1 otherwise, the
- * figure of a fresh client encryption -- fheasciichar.rs:27-29).  Handles of uploaded (or trivial) blocks only. */
+ * figure of a fresh client encryption -- fheasciichar.rs:27-29).  Handles of uploaded (or trivial) blocks only; the
+ * figure can be raised, never lowered below what the library tracks. */
 int fhs_char_set_noise(fhs_ctx *ctx, fhs_char_t h, uint64_t sum_c2);
 /* Constant folding made visible: *is_trivial = 1 and *value = the byte if all four blocks of the handle are trivial
  * (plaintext) ciphertexts -- what an operation on trivially encrypted inputs folds to, without a GPU (planner contexts

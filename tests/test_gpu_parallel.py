@@ -58,6 +58,17 @@ for a, b in [("apple pie", "apple pie"), ("apple pie", "apple pif"), ("bpple", "
 strings = ["the quick brown fox jumps over", "a lazy dog sleeps under the sun", "abcabcabcabdabcabcabcabdabcabc"]
 shards = [D.window_shard(ck, s, 4)[0] for s in strings]
 ok &= [ck.decrypt_char(o) for o in D.contains_batch(shards, "n fo")] == [int("n fo" in s) for s in strings]
+# the generic primitive on handles that are SUMS of bootstrap outputs (round 4): a comparison's verdict (sum c^2 up to 4)
+# and a find index (up to 57) -- the sender refreshes them (receivers book every imported block as one output), values
+# and the budget survive
+ea, eb = ck.encrypt("sharded", 1, None, sk), ck.encrypt("shardee" if rank else "sharded", 1, None, sk)
+verdict, index = sk.le(ea, eb), sk.find(ea, ck.encrypt_no_padding("rd" if rank else "ha", sk))
+flags = D.allgather_flags([verdict])
+ok &= [ck.decrypt_char(flags[r][0]) for r in range(world)] == [1, 1]
+chars = D.allgather_chars([index])
+ok &= [ck.decrypt_char(chars[r][0]) for r in range(world)] == [1, 3]
+ok &= all(chars[r][0].sum_c2() == 1 for r in range(world))
+ok &= ck.decrypt_char(chars[1][0].add(chars[0][0])) == 4
 assert sk.stats()["max_input_sum_c2"] <= 64
 dist.barrier()
 D.shutdown()

@@ -374,6 +374,9 @@ def test_noise_figure_stays_with_a_handle_and_can_be_declared(sk):
     assert back.sum_c2() == 1
     back.set_noise(idx.sum_c2())
     assert back.sum_c2() == idx.sum_c2()
+    from fhestring_amd.api import FhsError
+    with pytest.raises(FhsError):                # the figure can be raised, never lowered
+        back.set_noise(1)
     other = sk.dummy_string(1)[0]
     for c in (idx, back):
         sk.stats(reset=True)
