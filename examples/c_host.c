@@ -125,12 +125,28 @@ int main(int argc, char **argv) {
         if (!out) die("malloc", -1);
         TRY(fhs_str_replace(ctx, s, n, p, np, to, nt, out, cap, &out_len));
         char *got = decrypt_str(out, out_len);
-        /* the clear model: every non-overlapping occurrence, left to right (str::replace) */
+        /* the clear model.  |from| >= |to| (handle_longer_from, mod.rs:828-882): EVERY window of the ORIGINAL text that
+         * matches is overwritten with `to` padded with NULs, later windows over earlier ones, then the NULs are bubbled out
+         * -- "aaaa".replace("aa", "<>") is "<<<>" in the reference, not str::replace's "<><>".  |from| < |to|
+         * (handle_shorter_from, :885-980): the greedy non-overlapping matches, left to right, like str::replace. */
         char *want = calloc(n_text * 2 + 3, 1);
         if (!want) die("malloc", -1);
-        for (const char *q = text; *q;) {
-            if (m && strncmp(q, pat, m) == 0) { strcat(want, "<>"); q += m; }
-            else { strncat(want, q, 1); q++; }
+        if (m >= 2) {
+            char *work = malloc(n_text + 1);
+            size_t w = 0;
+            if (!work) die("malloc", -1);
+            memcpy(work, text, n_text + 1);
+            for (size_t i = 0; i + m <= n_text; i++)
+                if (strncmp(text + i, pat, m) == 0)
+                    for (size_t k = 0; k < m; k++) work[i + k] = k < 2 ? "<>"[k] : '\0';
+            for (size_t i = 0; i < n_text; i++)
+                if (work[i]) want[w++] = work[i];
+            free(work);
+        } else {
+            for (const char *q = text; *q;) {
+                if (m && strncmp(q, pat, m) == 0) { strcat(want, "<>"); q += m; }
+                else { strncat(want, q, 1); q++; }
+            }
         }
         ok &= report_str("replace", got, want);
         for (size_t i = 0; i < out_len; i++) TRY(fhs_release(ctx, out[i]));

@@ -24,5 +24,8 @@ def test_c_host_runs_the_reference_flow(text, pat):
     assert all("Test Passed: OK" in l for l in lines[:6]) and "FAILED" not in out.stdout
     want_find = text.find(pat) if pat in text else 255
     assert "Result: %d, Expected: %d" % (want_find, want_find) in lines[2]
-    assert 'Result: "%s"' % text.replace(pat, "<>") in lines[5]
+    # replace with |from| >= |to| follows the REFERENCE (mod.rs:828-882: every matching window of the original text is
+    # overwritten, later over earlier), which is str.replace only where occurrences do not overlap
+    want_replace = "<<<>" if (text, pat) == ("aaaa", "aa") else text.replace(pat, "<>")
+    assert 'Result: "%s"' % want_replace in lines[5]
     assert lines[6].startswith("PBS executed:")
