@@ -73,6 +73,9 @@ def parse():
                     help="level-skewed batching without round alignment of the launch groups (fhs_set_tick_balance off)")
     ap.add_argument("--skip-single-op", action="store_true", help="skip single-op latency / end-to-end / as-written")
     ap.add_argument("--skip-extras", action="store_true", help="skip the configs 3-5 section of the default run")
+    ap.add_argument("--as-written-replace-1024", action="store_true",
+                    help="with --as-written-fullsize: also config 4 itself as written (replace 5 -> 5 on 1024 characters, the "
+                         "O(n^2) bubble: ~27 M bootstraps, about five minutes)")
     ap.add_argument("--as-written-fullsize", action="store_true",
                     help="also RUN the reference-order (as written) DAGs of configs 3-5 at full size on the GPU -- find 256, "
                          "eq_ignore_case 4096, le 4096, replace 256: about two minutes -- and compare with the fused results; "
@@ -929,8 +932,11 @@ def _main(safety, args):
     if args.as_written_fullsize and world == 1 and rank == 0:
         aw_full = {}
         sk0 = sks[0]
-        for name, op, n in (("cfg3_find_encrypted_256", "find_enc", 256), ("cfg4_replace_256", "replace", 256),
-                            ("cfg5_eq_ignore_case_4096", "eq_ignore_case", 4096), ("cfg5_le_4096", "le", 4096)):
+        aw_cases = [("cfg3_find_encrypted_256", "find_enc", 256), ("cfg4_replace_256", "replace", 256),
+                    ("cfg5_eq_ignore_case_4096", "eq_ignore_case", 4096), ("cfg5_le_4096", "le", 4096)]
+        if args.as_written_replace_1024:
+            aw_cases.append(("cfg4_replace_1024", "replace", 1024))
+        for name, op, n in aw_cases:
             stage[0] = "as written at full size: " + name
             w = Workload(args, ck, [sk0], [None], 0, 1, op=op, chars=n, strings=1)
             dec = (lambda o: ck.decrypt(o[0])) if op == "replace" else (lambda o: ck.decrypt_char(o[0]))
@@ -996,6 +1002,8 @@ def _main(safety, args):
             except Exception:
                 measured = None
         for k, v in (measured or {}).items():
+            if k == "cfg4_replace_1024":                  # config 4 itself as written: beside its n^2 extrapolation
+                k = "cfg4_replace_1024_extrapolated"
             if k in as_written_shapes:
                 as_written_shapes[k]["measured"] = dict(v, source=src)
 
