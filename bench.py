@@ -848,11 +848,11 @@ def _main(safety, args):
                 dists[0].level_parallel(False)
             extras[op] = {"ms_local": d * 1e3, "pbs_local": float(s2["pbs_executed"]), "levels": s2["levels"],
                           "workload": w.describe(), "parallelism": w.parallelism()}
-            if op == "find_enc" and world == 1:
-                # requests streaming in (level-skewed batching): one fhs_submit + one fhs_pump per find, so
-                # the five narrow tail levels of find k ride in the launch groups of finds k+1 .. k+5 instead of paying
+            if world == 1 and op != "replace":            # (replace runs at 0.95 of the kernel rate alone: 43 mostly wide levels)
+                # requests streaming in (level-skewed batching): one fhs_submit + one fhs_pump per request, so
+                # the narrow tail levels of request k ride in the launch groups of requests k+1 ... instead of paying
                 # one bootstrap latency each on an idle chip -- what a server under load sees per request
-                n_req = 12
+                n_req = 12 if op == "find_enc" else 6
                 sync()
                 sks[0].stats(reset=True)
                 t0 = time.perf_counter()
@@ -869,8 +869,8 @@ def _main(safety, args):
                     w.check(o)
                 extras[op]["streamed"] = {"requests": n_req, "ms_per_op": ds / n_req * 1e3,
                                           "pbs_per_s": st_s["pbs_executed"] / ds,
-                                          "note": "12 finds submitted back to back, one launch group pumped per request "
-                                                  "(fhs_submit / fhs_pump); ms_per_op above is ONE find alone"}
+                                          "note": "%d requests submitted back to back, one launch group pumped per request "
+                                                  "(fhs_submit / fhs_pump); ms_per_op above is ONE request alone" % n_req}
                 del outs_s
             if multi_bit is not None:                     # the same op once more in the two-bit f64 arithmetic
                 set_arith("mb2")
