@@ -177,8 +177,20 @@ TUNE = {
     "noprio": {K: [(P1, ""), (P2, ""), (P0, "")]},
     "sched_default": {},
     "sched_memclause": {},
+    # round 4: the rest of LLVM's scheduler switches on the unchanged source (bit-identical by construction)
+    "sched_iterative_ilp": {},
+    "sched_iterative_minreg": {},
+    "sched_no_postra": {},
+    "sched_ilp_no_postra": {},
+    "sched_ilp_O2": {},
 }
-FLAGS = {"sched_default": [], "sched_memclause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]}
+MAXILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+FLAGS = {"sched_default": [], "sched_memclause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
+         "sched_iterative_ilp": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+         "sched_iterative_minreg": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"],
+         "sched_no_postra": ["-mllvm", "-enable-post-misched=0"],
+         "sched_ilp_no_postra": MAXILP + ["-mllvm", "-enable-post-misched=0"],
+         "sched_ilp_O2": MAXILP + ["-O2"]}
 
 VARIANTS = {
     "base": {},
