@@ -922,6 +922,24 @@ def _main(safety, args):
                                       "pbs_per_s": best[1]["pbs_executed"] / best[0], "pattern_len": w.m, "found": 1,
                                       "level_widths": [int(x) for x in best[2]][:16]}
             del keep, w
+        # ... and find with an encrypted pattern over ITS range (the u8 index ends it at 254 + m characters)
+        find_sweep = {}
+        for n in (64, 128, 256):
+            w = Workload(args, ck, sks[:1], [None], 0, 1, op="find_enc", chars=n, strings=1)
+            keep = w.step(0); sks[0].flush(); sync()
+            best = None
+            for _ in range(3):
+                sks[0].stats(reset=True)
+                t0 = time.perf_counter()
+                keep = w.step(0); sks[0].flush(); sync()
+                d = time.perf_counter() - t0
+                if best is None or d < best[0]:
+                    best = (d, sks[0].stats())
+            w.check(keep)
+            find_sweep[str(n)] = {"ms_per_op": best[0] * 1e3, "pbs": best[1]["pbs_executed"], "levels": best[1]["levels"],
+                                  "pbs_per_s": best[1]["pbs_executed"] / best[0], "pattern_len": w.m}
+            del keep, w
+        contains_sweep["find_encrypted_pattern"] = find_sweep
         contains_sweep["note"] = ("one contains_clear (m = 4, hit) alone on the GPU, best of 3; find / find_clear stop at "
                                   "254 + m characters: the reference panics beyond a u8 index (mod.rs:1025-1027), so "
                                   "find has no 1024 / 4096 rows")

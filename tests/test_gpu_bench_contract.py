@@ -90,7 +90,9 @@ def test_bench_json_line_contract():
     # round 4: contains over north_star's size range, the median-protocol figure, the roofline
     # tied to the sources it was counted on, as-written DAGs measured at full size beside their shapes
     sw = d["contains_sweep"]
-    assert [k for k in sw if k != "note"] == ["64", "256", "1024", "4096"] and "254 + m" in sw["note"]
+    assert [k for k in sw if k[0].isdigit()] == ["64", "256", "1024", "4096"] and "254 + m" in sw["note"]
+    fs = sw["find_encrypted_pattern"]
+    assert list(fs) == ["64", "128", "256"] and fs["64"]["pbs"] < fs["128"]["pbs"] < fs["256"]["pbs"]
     assert sw["64"]["pbs"] < sw["256"]["pbs"] < sw["1024"]["pbs"] < sw["4096"]["pbs"]
     assert sw["64"]["ms_per_op"] < sw["4096"]["ms_per_op"] and sw["4096"]["pbs_per_s"] > 3 * sw["64"]["pbs_per_s"]
     assert all(sw[k]["levels"] <= 12 and sw[k]["found"] == 1 for k in ("64", "256", "1024", "4096"))
