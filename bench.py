@@ -84,6 +84,9 @@ def parse():
     ap.add_argument("--watchdog", type=float, default=900.0,
                     help="multi-GPU runs: seconds the legs AFTER the timed measurement may take before rank 0 prints the "
                          "headline line it already has and every rank exits (0 = off)")
+    ap.add_argument("--extras-out", default=None,
+                    help="where the full record goes (default: bench_extras.json next to bench.py + a copy under gpurun_out/); "
+                         "stdout carries only the compact contract line")
     ap.add_argument("--inject-fault", choices=["raise", "hang"], default=None, help=argparse.SUPPRESS)   # tests only:
     # the last rank fails / hangs right after the timed measurement (tests/test_gpu_bench_contract.py)
     a = ap.parse_args()
@@ -277,6 +280,8 @@ def cpu_baseline(n_pbs, level_widths):
     per_thread_ms = 1e3 * cores / best
     out = {"value": best, "unit": "PBS/s", "cores": cores, "kind": "port",
            "ms_per_pbs_per_thread": per_thread_ms,
+           "sample_short": "C port of the reference's algorithm class (f64 FFT, AVX2+FMA; NOT tfhe-rs), %d PBS in %.1f s on %d "
+                           "threads" % (n_vec, vec_dt, cores),
            "variants_pbs_per_s": {"f64_fft_avx2_fma": vec_rate, "f64_fft_scalar_textbook": fft_rate,
                                   "f64_fft_scalar_mirror_of_gpu_kernel": mir_rate, "exact_ntt_parity_oracle": ex_rate},
            "sample": "oracle/tfhe_oracle.c mode 6 (a C port of the reference's algorithm class -- folded 1024-point "
@@ -370,6 +375,114 @@ def roofline_for(kernel, pbs_per_launch, launch_ms, n_launches, counters, traffi
     return r
 
 
+LINE_LIMIT = 8000            # hard cap of the contract line in bytes (target <= 4 KB); tests/test_gpu_bench_contract.py
+OUT_LOCK = __import__("threading").Lock()    # stdout carries exactly ONE line: whoever prints it holds this lock
+
+
+def _r(x, sig=6):
+    """floats to `sig` significant digits (the line is a record, not an archive)"""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _roofline_compact(r):
+    if not r:
+        return None
+    out = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms",
+                                 "launches", "avg_pbs_per_launch", "counters_stale")}
+    c = r.get("counters") or {}
+    out["fp64_flop_per_pbs"] = c.get("fp64_flop_per_pbs")
+    out["valu_busy_frac"] = c.get("valu_busy_frac_of_simd")
+    h = r.get("hbm")
+    if h:
+        out["hbm"] = {"compulsory_bytes_per_launch": h["compulsory_bytes_per_launch"],
+                      "compulsory_frac_of_peak": h["compulsory_frac_of_peak"],
+                      "measured_fabric_bytes_per_launch": h["measured_fabric_bytes_per_launch"],
+                      "survey_8d_bytes_per_pbs": h["survey_8d_algorithmic_bytes_per_pbs"],
+                      "survey_8d_frac": h["survey_8d_figure_gbs"] / HBM_PEAK_GBS, "peak_gbs": HBM_PEAK_GBS}
+    ks = r.get("keyswitch")
+    if ks:
+        out["keyswitch"] = {"bound": ks["bound"], "frac": ks["frac"], "avg_launch_ms": ks["avg_launch_ms"],
+                            "share_of_step_time": ks["share_of_step_time"]}
+    nl = r.get("narrow_levels")
+    if nl:
+        out["narrow_levels"] = {k: nl[k] for k in ("launches", "avg_launch_ms", "avg_pbs_per_launch")}
+    return out
+
+
+def compact_line(full, extras_path):
+    """The driver's contract line: numbers and short names only.  Everything else bench.py measures (side legs, sweeps,
+    notes) is in the sidecar file `extras` names and on stderr -- round 4's 21 KB line could not be parsed by the driver."""
+    c = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                  "scaling", "vs_baseline", "dtype", "data")}
+    cfg = full["config"]
+    c["config"] = {"workload": cfg["workload"], "parallelism": cfg.get("parallelism"), "transport": cfg.get("transport"),
+                   "pipelines": cfg.get("pipelines")}
+    ex = cfg.get("exchange")
+    if ex:
+        c["config"]["exchange"] = {k: ex[k] for k in ("transport", "allgather_calls_per_step", "bytes_sent_per_rank_per_step")}
+    for k in ("ms_per_op", "single_op_latency_ms", "end_to_end_ms", "pbs_per_op", "levels_per_op", "median_ms_per_step",
+              "value_median_protocol", "max_input_sum_c2", "two_queued_ms_per_op"):
+        if full.get(k) is not None:
+            c[k] = full[k]
+    c["roofline"] = _roofline_compact(full.get("roofline"))
+    cb = full.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                             "sample": cb["sample_short"], "ms_per_pbs_per_thread": cb["ms_per_pbs_per_thread"]}
+        if "config1_eq_hello_hello" in cb:
+            c["cpu_baseline"]["config1_eq_hello_hello_ms"] = cb["config1_eq_hello_hello"]["ms"]
+    if full.get("configs"):
+        c["configs"] = {name: {k: e[k] for k in ("ms_per_op", "pbs", "levels", "pbs_per_s", "end_to_end_ms",
+                                                "two_queued_ms_per_op", "streamed_ms_per_op") if e.get(k) is not None}
+                        for name, e in full["configs"].items()}
+    oa = full.get("other_arithmetic")
+    if oa:
+        c["other_arithmetic"] = {"arithmetic": "exact-NTT" if "exact" in oa["arithmetic"] else "f64-FFT", "value": oa["value"],
+                                 "frac": (oa.get("roofline") or {}).get("frac")}
+    c["extras"] = extras_path
+    c = _r(c)
+    text = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:               # never again a line the driver cannot parse: shed the optional objects
+        for k in ("other_arithmetic", "configs"):
+            c.pop(k, None)
+        text = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
+
+
+def emit(full, args, safety):
+    """Sidecar first (bench_extras.json next to bench.py, a copy under gpurun_out/ so that it travels back from a GPU
+    box), the full record on stderr, then the ONE contract line on stdout -- last, flushed, under the lock the SIGTERM
+    helper takes, and only then is the line marked as out."""
+    paths = []
+    blob = json.dumps(_r(full, 9), indent=1)
+    for path in ([args.extras_out] if args.extras_out else
+                 [os.path.join(ROOT, "bench_extras.json"), os.path.join(ROOT, "gpurun_out", "bench_extras.json")]):
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            tmp = path + ".tmp%d" % os.getpid()
+            with open(tmp, "w") as f:
+                f.write(blob)
+            os.replace(tmp, path)
+            paths.append(path)
+        except OSError as exc:
+            sys.stderr.write("bench.py: could not write %s: %s\n" % (path, exc))
+    sys.stderr.write("bench.py: full record (side legs, sweeps, notes) follows; also in %s\n" % (", ".join(paths) or "(nowhere)"))
+    sys.stderr.write(json.dumps(_r(full, 9)) + "\n")
+    sys.stderr.flush()
+    text = compact_line(full, os.path.relpath(paths[0], ROOT) if paths else None)
+    with OUT_LOCK:
+        sys.stdout.write(text + "\n")
+        sys.stdout.flush()
+        safety["line_out"] = True
+
+
 def main():
     """Runs the bench; in a multi-GPU run a failure (or a hang) AFTER the contract's timed measurement costs the extra
     legs, not the headline line (see `safety` in _main)."""
@@ -419,13 +532,36 @@ def launch_ranks_if_needed(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd)))
     sys.stderr.flush()
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    import signal
+    # own session: the launcher and its N GPU ranks form one process group that this parent (which has not touched the
+    # GPU) can end as a whole when it is told to stop -- a driver that kills bench.py by pid must not leave ranks behind
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    stopped = []
+
+    def forward(signum, _frame):
+        stopped.append(signum)
+        try:
+            os.killpg(child.pid, signal.SIGTERM)
+        except OSError:
+            pass
+    old_handlers = {sig: signal.signal(sig, forward) for sig in (signal.SIGTERM, signal.SIGINT)}
     n_json = 0
     for line in child.stdout:                    # relay as it comes; stderr goes straight through
         sys.stdout.write(line)
         sys.stdout.flush()
         n_json += line.lstrip().startswith("{")
-    rc = child.wait()
+    try:
+        rc = child.wait(timeout=30 if stopped else None)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        rc = child.wait()
+    for sig, h in old_handlers.items():
+        signal.signal(sig, h)
+    if stopped:
+        return 128 + int(stopped[0])
     if rc == 0 and n_json != 1:
         sys.stderr.write("bench.py: the %d-rank run exited 0 but printed %d JSON lines\n" % (args.gpus, n_json))
         rc = 1
@@ -629,9 +765,13 @@ def _main(safety, args):
              -- without collective clean-up (another rank may be stuck in one)."""
             try:
                 where = "rank %d during '%s'" % (rank, stage[0])
-                if rank == 0:
-                    print(json.dumps(dict(head, incomplete="%s [%s]" % (reason, where), incomplete_stage=stage[0])))
-                    sys.stdout.flush()
+                with OUT_LOCK:
+                    if rank == 0 and not safety.get("line_out"):
+                        short = dict(head, roofline=_roofline_compact(head.get("roofline")),
+                                     incomplete="%s [%s]" % (reason, where), incomplete_stage=stage[0])
+                        sys.stdout.write(json.dumps(_r(short), allow_nan=False, separators=(",", ":")) + "\n")
+                        sys.stdout.flush()
+                        safety["line_out"] = True
                 sys.stderr.write("bench.py %s: leaving after the timed measurement: %s\n" % (where, reason))
                 sys.stderr.flush()
             finally:
@@ -648,9 +788,11 @@ def _main(safety, args):
         signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
 
         def on_sigterm():
-            os.read(rfd, 1)
-            if safety.get("line_out"):           # the complete line is out already: leave, never print a second one
-                os._exit(EXIT_INCOMPLETE)
+            while True:
+                b = os.read(rfd, 1)              # the wake-up pipe carries the signal NUMBER: only SIGTERM is ours
+                if b and b[0] == int(signal.SIGTERM):   # (Ctrl-C stays Python's KeyboardInterrupt in the main thread)
+                    break
+            # the complete line is out already (checked under the lock inside bail): leave, never print a second one
             bail("SIGTERM from the launcher (another rank failed or the run was cancelled)")
         th = threading.Thread(target=on_sigterm, daemon=True)
         th.start()
@@ -705,6 +847,17 @@ def _main(safety, args):
         e2e_ms = (time.perf_counter() - t2) * 1e3
         single = {"latency_ms": lat, "level_widths": widths, "pbs": int(sum(widths)), "levels": len(widths),
                   "end_to_end_ms": e2e_ms}
+        # two independent requests recorded, ONE fhs_flush (levels of equal depth share their launch groups)
+        two = Workload(args, ck, [sk], [None], 0, 1, strings=2)
+        keep2 = two.step(0); sk.flush(); sync()
+        t3 = time.perf_counter()
+        for _ in range(3):
+            keep2 = two.step(0)
+            sk.flush()
+        sync()
+        single["two_queued_ms_per_op"] = (time.perf_counter() - t3) / 3 / 2 * 1e3
+        two.check(keep2)
+        del keep2, two
         if args.op in ("contains", "find_enc") and args.mode == "fused":
             sk.set_mode(0)
             sk.stats(reset=True)
@@ -848,6 +1001,34 @@ def _main(safety, args):
                 dists[0].level_parallel(False)
             extras[op] = {"ms_local": d * 1e3, "pbs_local": float(s2["pbs_executed"]), "levels": s2["levels"],
                           "workload": w.describe(), "parallelism": w.parallelism()}
+            if world == 1:
+                # what the reference's own timer brackets (src/utils.rs:135-145, src/main.rs:103-114): client encryption of
+                # the inputs + upload + the op + download + client decryption of the result (SURVEY 8d asks for this figure
+                # beside the server-only one)
+                sync()
+                t0 = time.perf_counter()
+                w_e = Workload(args, ck, sks[:1], dists[:1], rank, world, op=op, chars=FIXED[op], strings=1)
+                t1 = time.perf_counter()
+                w_e.check(w_e.step(0))
+                t2 = time.perf_counter()
+                extras[op]["end_to_end_ms"] = (t2 - t0) * 1e3
+                extras[op]["end_to_end_split_ms"] = {"client_encrypt_and_upload": (t1 - t0) * 1e3,
+                                                     "op_download_decrypt": (t2 - t1) * 1e3}
+                del w_e
+            if world == 1 and op != "replace":
+                # two independent requests recorded, ONE fhs_flush: levels of equal depth share their launch groups, so
+                # the narrow tail is paid once for both ("alone" is ms_per_op above)
+                w_2 = Workload(args, ck, sks[:1], dists[:1], rank, world, op=op, chars=FIXED[op], strings=2)
+                keep2 = w_2.step(0); sks[0].flush(); sync()
+                best2 = None
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    keep2 = w_2.step(0); sks[0].flush(); sync()
+                    d2q = time.perf_counter() - t0
+                    best2 = d2q if best2 is None else min(best2, d2q)
+                w_2.check(keep2)
+                extras[op]["two_queued_ms_per_op"] = best2 / 2 * 1e3
+                del keep2, w_2
             if world == 1 and op != "replace":            # (replace runs at 0.95 of the kernel rate alone: 43 mostly wide levels)
                 # requests streaming in (level-skewed batching): one fhs_submit + one fhs_pump per request, so
                 # the narrow tail levels of request k ride in the launch groups of requests k+1 ... instead of paying
@@ -1114,6 +1295,7 @@ def _main(safety, args):
             line["single_op_latency_ms"] = single["latency_ms"]
             line["single_op"] = single
             line["end_to_end_ms"] = single["end_to_end_ms"]
+            line["two_queued_ms_per_op"] = single["two_queued_ms_per_op"]
         else:
             line["single_op_latency_ms"] = dt / args.steps * 1e3
         ksw = kt[1]
@@ -1127,10 +1309,12 @@ def _main(safety, args):
                 "avg_rows_per_launch": rows, "achieved": ops / (ksw["ms"] * 1e-3) / 1e12,
                 "frac": ops / (ksw["ms"] * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
                 "share_of_step_time": ksw["ms"] * ksw["n"] / (dt * 1e3),
-                "counters": {k: counters.get("keyswitch_mfma2_kernel", {}).get(k) for k in
+                "counters_stale": bool(counters.get("keyswitch_mfma2_kernel", {}).get("_stale_files", True)),
+                "counters": {k: (None if counters.get("keyswitch_mfma2_kernel", {}).get("_stale_files", True) else
+                                 counters["keyswitch_mfma2_kernel"].get(k)) for k in
                              ("mfma_busy_frac_of_simd", "achieved_i8_pops", "clock_ghz", "profile")},
                 "note": "algorithmic i8 multiply-adds (743 columns, no tile padding) over the time of digits + product; "
-                        "rocprofv3 counts the matrix pipes 45 % busy inside the product kernel (profiles/r04_counters.json)"}
+                        "counters = rocprofv3 on the product kernel alone, withheld when ks_kernels.hip changed since"}
         if narrow["n"] and kernel != "blind_rotate_fft4_kernel":
             line["roofline"]["narrow_levels"] = {
                 "kernel": "blind_rotate_fft4_kernel", "launches": narrow["n"], "avg_launch_ms": narrow["ms"],
@@ -1199,6 +1383,10 @@ def _main(safety, args):
                     line["configs"][names[op]]["ms_per_op_multi_bit"] = e["ms_two_bit"]
                 if "streamed" in e:
                     line["configs"][names[op]]["streamed"] = e["streamed"]
+                    line["configs"][names[op]]["streamed_ms_per_op"] = e["streamed"]["ms_per_op"]
+                for k in ("end_to_end_ms", "end_to_end_split_ms", "two_queued_ms_per_op"):
+                    if k in e:
+                        line["configs"][names[op]][k] = e[k]
         if args.cpu_pbs != 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_pbs, single["level_widths"] if single else None)
             if extras:
@@ -1215,13 +1403,10 @@ def _main(safety, args):
                     "4.4: 'extrapolated'); fused = the DAG the GPU runs, as_written = the reference's op order" % line["cpu_baseline"]["cores"])
         if safety.get("timer"):
             safety["timer"].cancel()
-        safety["line_out"] = True
-        print(json.dumps(line))
-        sys.stdout.flush()
+        emit(line, args, safety)
     if safety.get("timer"):
         safety["timer"].cancel()
     safety["bail"] = None                    # the line is out: from here on failures are ordinary
-    safety["line_out"] = True
     if dist is not None:
         import threading
         def cut_short():                         # the line is out, but a rank that hangs while shutting down is a hang:

@@ -18,7 +18,10 @@ KERNEL_SOURCES = {
     "blind_rotate_kernel": ["pbs_kernels.hip"] + _NTT,
     "blind_rotate_ntt_mb2_kernel": ["nttmb_kernels.hip"] + _NTT,
     "keyswitch_mfma_kernel": ["ks_kernels.hip", FLAGS],
+    "keyswitch_mfma2_kernel": ["ks_kernels.hip", FLAGS],
+    "ks_digits_tile_kernel": ["ks_kernels.hip", FLAGS],
 }
+UNKNOWN = "(kernel not listed in fhestring_amd/kernel_sources.py)"
 
 
 def blob_hash(data):
@@ -39,7 +42,10 @@ def source_blobs(kernel, read=None):
 
 
 def stale_sources(kernel, recorded):
-    """Files of `kernel` whose hash in the tree differs from the recorded one (all of them if nothing was recorded)."""
+    """Files of `kernel` whose hash in the tree differs from the recorded one (all of them if nothing was recorded).
+    A kernel this module does not know is stale by definition: nothing ties its counters to a source."""
+    if kernel not in KERNEL_SOURCES:
+        return [UNKNOWN]
     now = source_blobs(kernel)
     if not recorded:
         return sorted(now)

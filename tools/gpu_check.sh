@@ -13,5 +13,5 @@ python - <<'PY'
 import json
 d=json.loads(open("gpurun_out/check/bench_default.json").read().strip().split("\n")[-1]); r=d["roofline"]
 print("value %.0f ms/step %.2f ms/op %.2f pbs/op %.0f launch %.2f x %.0f frac %.3f single %.2f e2e %.2f"%(d["value"],d["ms_per_step"],d["ms_per_op"],d["pbs_per_op"],r["avg_launch_ms"],r["avg_pbs_per_launch"],r["frac"],d["single_op_latency_ms"],d["end_to_end_ms"]))
-print({k:(round(v["ms_per_op"],1), v["pbs"]) for k,v in d["configs"].items()}, d.get("larger_batch"))
+print({k:(round(v["ms_per_op"],1), v["pbs"]) for k,v in d["configs"].items()})
 PY
