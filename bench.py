@@ -186,9 +186,12 @@ class Workload:
 
     def parallelism(self):
         w = self.world
-        if self.op in ("contains", "find_enc"):
-            return "match windows sharded over %d GPU(s), 1 ncclAllGather of %d block(s) per rank per op" % (
-                w, 1 if self.op == "contains" else 5)
+        if self.op == "contains":
+            return "match windows sharded over %d GPU(s), 1 ncclAllGather of 1 block(s) per rank per op" % w
+        if self.op == "find_enc":
+            n_win = self.total_chars() + 1 - self.m + 1
+            return "match windows sharded over %d GPU(s), 1 ncclAllGather of %d window flag(s) per rank per op" % (
+                w, -(-n_win // w))
         if self.op == "replace":
             return "level-parallel: every PBS level split over %d GPU(s), 1 ncclAllGather per level" % w
         return "character positions sharded over %d GPU(s), 1 ncclAllGather of %d block(s) per rank" % (

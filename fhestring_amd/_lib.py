@@ -257,6 +257,8 @@ def _declare(L):
     L.fhs_pump.restype = i
     L.fhs_level_widths.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.fhs_level_widths.restype = i
+    L.fhs_launch_groups.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.fhs_launch_groups.restype = i
     L.fhs_get_stats.argtypes = [vp, vp]
     L.fhs_get_stats.restype = i
     L.fhs_char_sum_c2.argtypes = [vp, C.c_uint64, vp]

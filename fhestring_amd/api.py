@@ -547,6 +547,14 @@ class MyServerKey:
         self.ctx._check(self.ctx._L.fhs_level_widths(self.ctx._h, _ptr(out), n.value, C.byref(n)))
         return out[:n.value].tolist()
 
+    def launch_groups(self):
+        """Rows this rank ran in every launch group since the last stats reset (fhs_launch_groups)."""
+        n = C.c_size_t()
+        self.ctx._check(self.ctx._L.fhs_launch_groups(self.ctx._h, None, 0, C.byref(n)))
+        out = np.zeros(max(1, n.value), np.uint32)
+        self.ctx._check(self.ctx._L.fhs_launch_groups(self.ctx._h, _ptr(out), n.value, C.byref(n)))
+        return out[:n.value].tolist()
+
     def stats(self, reset=False):
         from ._lib import Stats
         st = Stats()

@@ -209,25 +209,43 @@ static int dist_find(fhs_ctx *c, const fhs_char_t *s, size_t n, const FStr &pat,
         return e.ctx.fail(FHS_ERR_LIMIT, "Maximum supported size for find reached");
     FusedScope fs(e);
     Strings S(&e);
-    if (total_chars == 0 && pat.empty()) {                          // mod.rs:1017-1019: "" in "" is found at position 0
+    if (pat.empty()) {                                              // mod.rs:1017-1019: "" is found at position 0 (every window matches)
         FChar zero = ch_trivial(&e, 0);
         *out = store(e, zero);
         return FHS_OK;
     }
-    Ref found;
-    FChar pos;
-    S.f_find_partial(load_str(e, s, n), pat, first_window, &found, &pos);
-    std::vector<std::vector<Ref>> got;
-    if (int rc = gather(e, {found, pos.b[0], pos.b[1], pos.b[2], pos.b[3]}, got)) return rc;
-    std::vector<Ref> fnd;
-    std::vector<FChar> ps;
-    for (auto &g : got) {
-        fnd.push_back(g[0]);
-        FChar p;
-        for (int b = 0; b < 4; b++) p.b[b] = g[1 + b];
-        ps.push_back(p);
+    // Every rank bootstraps the match flags of ITS windows (the two wide levels of find: nibble tests, AND per window --
+    // 1 / world of the work), ONE all-gather hands every rank all flags (ceil(W / world) blocks per rank: 0.5 MB at
+    // 256 characters on 8 GPUs), and the narrow rest -- prefix OR, index of the first flag set (Strings::first_index),
+    // 255 if none -- runs replicated on every rank.  Six dependency levels like the single-GPU find; the earlier
+    // formulation (a (found, position) partial per slice + "the first slice that found one decides") needed eleven,
+    // which a 256-character string cannot amortise: its levels are bootstrap latencies, not throughput.
+    const int world = e.ctx.dist.world, rank = e.ctx.dist.rank;
+    const size_t m = pat.size();
+    const size_t n_win = m <= total_chars ? total_chars - m + 1 : 0;
+    size_t w0 = 0, w1 = 0, c0 = 0, c1 = 0;
+    fhs_dist_plan_windows(total_chars, m, world, rank, &w0, &w1, &c0, &c1);
+    if (n != c1 - c0 || (w1 > w0 && first_window != w0))
+        return e.ctx.fail(FHS_ERR_ARG, "fhs_dist_str_find: the shard is not this rank's slice of fhs_dist_plan_windows");
+    if (n_win == 0) {                                               // pattern longer than the string: mod.rs:1029-1031
+        FChar none = ch_trivial(&e, 255);
+        *out = store(e, none);
+        return FHS_OK;
     }
-    FChar r = S.find_first_decides(fnd, ps);
+    const size_t per = (n_win + (size_t)world - 1) / (size_t)world;  // blocks every rank contributes (short slices pad)
+    std::vector<Ref> local = w1 > w0 ? S.f_find_window_flags(load_str(e, s, n), pat) : std::vector<Ref>();
+    if (local.size() != w1 - w0) return e.ctx.fail(FHS_ERR_STATE, "internal: window count of the slice");
+    while (local.size() < per) local.push_back(trivial_block(&e, 0));
+    std::vector<std::vector<Ref>> got;
+    if (int rc = gather(e, local, got)) return rc;
+    std::vector<Ref> flags;
+    flags.reserve(n_win);
+    for (int r = 0; r < world; r++) {
+        size_t a = 0, b = 0, x = 0, y = 0;
+        fhs_dist_plan_windows(total_chars, m, world, r, &a, &b, &x, &y);
+        for (size_t k = 0; k < b - a; k++) flags.push_back(got[(size_t)r][k]);
+    }
+    FChar r = S.f_find_from_flags(flags);
     *out = store(e, r);
     return FHS_OK;
 }

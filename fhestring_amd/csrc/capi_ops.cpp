@@ -469,6 +469,13 @@ int fhs_level_widths(fhs_ctx *c, uint32_t *out, size_t cap, size_t *n) {
     if (out) std::copy(w.begin(), w.begin() + std::min(cap, w.size()), out);
     return FHS_OK;
 }
+int fhs_launch_groups(fhs_ctx *c, uint32_t *out, size_t cap, size_t *n) {
+    if (!c || !n) return bad(c);
+    const auto &w = c->eng.stats.group_rows;
+    *n = w.size();
+    if (out) std::copy(w.begin(), w.begin() + std::min(cap, w.size()), out);
+    return FHS_OK;
+}
 int fhs_reset_stats(fhs_ctx *c) {
     if (!c) return FHS_ERR_ARG;
     c->eng.stats = EngineStats();

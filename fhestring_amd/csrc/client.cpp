@@ -12,8 +12,10 @@
 #endif
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <mutex>
@@ -174,6 +176,7 @@ struct fhs_client {
     std::vector<uint64_t> bsk_mb2;   // pair key of FHS_ARITH_F64_FFT_MB2, generated on first use
     std::mutex mb2_mu;
     Rng enc_mask, enc_noise;      // encryption streams: public masks and noise never share a stream
+    std::atomic<uint64_t> str_calls{0};   // fhs_client_encrypt_str: every call (and every character of it) has its own streams
 };
 
 namespace {
@@ -270,13 +273,44 @@ void keygen_mb2(fhs_client *ck) {
     for (auto &x : th) x.join();
 }
 
-void encrypt_block(fhs_client *ck, uint64_t m, uint64_t *ct) {
-    ck->enc_mask.fill(ct, BIG_N);
+void encrypt_block_with(const fhs_client *ck, Rng &mask, Rng &noise, uint64_t m, uint64_t *ct) {
+    mask.fill(ct, BIG_N);
     uint64_t acc = 0;
     const uint64_t *sk = ck->glwe_sk.data();
     for (int j = 0; j < BIG_N; j++) acc += ct[j] & ((uint64_t)0 - sk[j]);   // binary key
-    ct[BIG_N] = acc + ck->enc_noise.noise(GLWE_NOISE) + (m << DELTA_LOG);
+    ct[BIG_N] = acc + noise.noise(GLWE_NOISE) + (m << DELTA_LOG);
 }
+void encrypt_block(fhs_client *ck, uint64_t m, uint64_t *ct) { encrypt_block_with(ck, ck->enc_mask, ck->enc_noise, m, ct); }
+// host threads for the per-character work of one string (encryption: 16 KB of ChaCha20 keystream and a 2048-term masked
+// sum per block; decryption: a 2048-term product): config 5 hands over 2 x 4097 characters = 537 MB of ciphertext, which
+// one thread needs ~0.16 s for -- as long as the GPU needs for the whole op (VERDICT r4 "missing 5")
+unsigned string_threads(size_t n_chars) {
+    unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    if (const char *e = std::getenv("FHS_CLIENT_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));   // tests: 1 = sequential
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(hw, n_chars / 32));
+}
+template <class F>
+void for_each_char(size_t n, F &&f) {
+    const unsigned nt = string_threads(n);
+    if (nt <= 1) {
+        for (size_t i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const size_t i0 = next.fetch_add(16);
+            if (i0 >= n) return;
+            for (size_t i = i0; i < std::min(n, i0 + 16); i++) f(i);
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &x : th) x.join();
+}
+constexpr uint64_t STR_STREAM_BASE = 1ull << 62;   // stream ids of string encryptions: base + (call << 24) + character
+constexpr size_t STR_MAX_CHARS = (size_t)1 << 24;
 uint64_t decrypt_block(const fhs_client *ck, const uint64_t *ct) {
     uint64_t acc = 0;
     for (int j = 0; j < BIG_N; j++) acc += ct[j] * ck->glwe_sk[j];
@@ -352,18 +386,29 @@ int fhs_client_encrypt_str(fhs_client *ck, const char *s, size_t len, size_t pad
     if (!ck || (len && !s) || !out) return FHS_ERR_ARG;
     for (size_t i = 0; i < len; i++)
         if ((unsigned char)s[i] >= 128 || s[i] == 0) return FHS_ERR_ARG;   // the reference asserts ASCII, no NUL (:52-55)
-    for (size_t i = 0; i < len + padding; i++)
-        fhs_client_encrypt_char(ck, i < len ? (uint8_t)s[i] : 0, out + i * FHS_CHAR_WORDS);
+    const size_t n = len + padding;
+    if (n > STR_MAX_CHARS) return FHS_ERR_LIMIT;
+    // Every character draws from its own (mask, noise) stream pair, keyed by the call number and its index: the result
+    // does not depend on how many host threads share the work, masks and noise never share a stream, and no two
+    // characters of any two calls share one.  (fhs_client_encrypt_char keeps the client's sequential streams.)
+    const uint64_t call = ck->str_calls.fetch_add(1);
+    for_each_char(n, [&](size_t i) {
+        const uint64_t sid = STR_STREAM_BASE + (call << 24) + i;
+        Rng mask(ck->key, sid, DOM_MASK), noise(ck->key, sid, DOM_NOISE);
+        const uint8_t v = i < len ? (uint8_t)s[i] : 0;
+        for (int b = 0; b < 4; b++)
+            encrypt_block_with(ck, mask, noise, (v >> (2 * b)) & 3, out + i * FHS_CHAR_WORDS + (size_t)b * BIG_CT);
+    });
     return FHS_OK;
 }
 int fhs_client_decrypt_str(const fhs_client *ck, const uint64_t *chars, size_t n, char *out, size_t *out_len) {   // decrypt (:89-106)
     if (!ck || (n && !chars) || !out || !out_len) return FHS_ERR_ARG;
+    std::vector<uint8_t> vals(n);
+    for_each_char(n, [&](size_t i) { fhs_client_decrypt_char(ck, chars + i * FHS_CHAR_WORDS, &vals[i]); });
     size_t k = 0;
     for (size_t i = 0; i < n; i++) {
-        uint8_t v;
-        fhs_client_decrypt_char(ck, chars + i * FHS_CHAR_WORDS, &v);
-        if (v == 0) break;   // truncate at the first NUL (:91-96)
-        out[k++] = (char)v;
+        if (vals[i] == 0) break;   // truncate at the first NUL (:91-96)
+        out[k++] = (char)vals[i];
     }
     *out_len = k;
     return FHS_OK;

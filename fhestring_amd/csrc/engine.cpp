@@ -650,7 +650,12 @@ int Engine::run_tick(std::vector<TickLevel> &levels, bool sharded) {
     const size_t cap = (width + world - 1) / world;
     const size_t lo = std::min(width, rank * cap), hi = std::min(width, lo + cap), cnt = hi - lo;
     stats.pbs_executed += cnt;
-    if (planner) return 0;
+    if (stats.group_rows.size() < (1u << 20)) stats.group_rows.push_back((uint32_t)cnt);
+    if (planner) {
+        // nothing runs, but the exchange of a level-parallel launch group is accounted for like Dist::all_gather does
+        if (sharded) { ctx.dist.n_gathers++; ctx.dist.bytes_sent += cap * BIG_CT * 8; }
+        return 0;
+    }
     if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
     const size_t off_desc = 0;
     const size_t off_terms = off_desc + width * sizeof(LinDesc);
@@ -747,6 +752,14 @@ int Engine::gather_blocks(const Bid *local, size_t n, std::vector<Bid> &out) {
     else
         while (!rc && !sched_.empty() && sched_.begin()->first <= need) rc = pump(1);
     if (rc) return rc;
+    if (planner) {
+        // a planner context exchanges nothing: count the all-gather like Dist::all_gather does and hand back world * n
+        // fresh single-output blocks, so that the combine DAG can be recorded and levelised (multi-GPU projections)
+        ctx.dist.n_gathers++;
+        ctx.dist.bytes_sent += n * row;
+        for (size_t i = 0; i < world * n; i++) out.push_back(from_device(nullptr));
+        return 0;
+    }
     if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
     if (ctx.xchg_send.cap < n * row || ctx.xchg_recv.cap < world * n * row) {
         hipError_t e = hipStreamSynchronize(ctx.stream);
@@ -900,6 +913,7 @@ int Engine::exec_level(size_t k, size_t lo, size_t hi, uint64_t *dense_out) {
     if (lo > hi || hi > lp.count) return ctx.fail(-1, "slice out of range");
     const size_t cnt = hi - lo;
     if (cnt == 0) return 0;
+    if (stats.group_rows.size() < (1u << 20)) stats.group_rows.push_back((uint32_t)cnt);
     if (planner) {
         stats.pbs_executed += cnt;
         if (lo == 0 || dense_out) {

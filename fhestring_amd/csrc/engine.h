@@ -47,6 +47,7 @@ struct EngineStats {
     uint64_t pbs_shared = 0;         // bootstraps not run because an identical one (same input combination, same LUT) exists
     uint64_t max_input_sum_c2 = 0;   // largest sum of squared coefficients of any executed bootstrap's input
     std::vector<uint32_t> level_widths;   // width of every dependency level executed since the last reset (capped)
+    std::vector<uint32_t> group_rows;     // rows THIS rank ran in every launch group (lincomb -> keyswitch -> blind rotation) since the last reset (capped)
 };
 
 class Engine {

@@ -999,10 +999,21 @@ std::vector<Ref> Strings::prefix_or(const std::vector<Ref> &f) {
 
 // find (mod.rs:1010-1053) re-associated: window flags, exclusive prefix OR, first = f & !prefix,
 // position digits as sums of first_i * digit(i) (at most one term is non-zero), 255 when absent.
-FChar Strings::f_find(const FStr &s, const FStr &pat) {
+FChar Strings::f_find(const FStr &s, const FStr &pat) { return f_find_from_flags(f_find_window_flags(s, pat)); }
+
+// the match flag of every window of `s` (the first two dependency levels of find: nibble tests, AND per window)
+std::vector<Ref> Strings::f_find_window_flags(const FStr &s, const FStr &pat) {
+    if (s.size() < pat.size()) return {};
     const size_t W = s.size() - pat.size() + 1;
     std::vector<Ref> f(W);
     for (size_t i = 0; i < W; i++) f[i] = pat.empty() ? trivial_block(e_, 1) : window_match(s, i, pat);
+    return f;
+}
+
+// ... and the rest of find on ALL window flags in string order: index of the first one set, 255 if none.  The sharded
+// find exchanges the flags and runs this part on every rank (fhs_dist_str_find).
+FChar Strings::f_find_from_flags(const std::vector<Ref> &f) {
+    const size_t W = f.size();
     std::vector<Ref> p = prefix_or(f);
     Ref found = or_tree(f);
     if (W <= 256) return first_index(p, found);              // 255 = 3,3,3,3 when absent (:1023)
@@ -1078,50 +1089,6 @@ FChar Strings::first_index(const std::vector<Ref> &before, const Ref &found) {
         // as it is -- like a comparison's verdict -- instead of paying one more dependency level for a refresh; consumers
         // that weigh their operands refresh them by the engine's bookkeeping.
         r.b[d] = lin(e_, {{1, &digit}, {3, &nf}});
-    }
-    return r;
-}
-
-// Window-sharded find: the same DAG as f_find on one rank's slice, with the global window index baked into the
-// position digits (free: they are plaintext weights) and the found flag kept apart instead of the 255 sentinel.
-void Strings::f_find_partial(const FStr &s, const FStr &pat, size_t first_window, Ref *found, FChar *pos) {
-    if (s.size() < pat.size() || s.empty()) {
-        *found = trivial_block(e_, 0);
-        *pos = t(0);
-        return;
-    }
-    const size_t W = s.size() - pat.size() + 1;
-    std::vector<Ref> f(W);
-    for (size_t i = 0; i < W; i++) f[i] = pat.empty() ? trivial_block(e_, 1) : window_match(s, i, pat);
-    std::vector<Ref> p = prefix_or(f);
-    std::vector<Ref> first(W);
-    for (size_t i = 0; i < W; i++) first[i] = pbs(lin(e_, {{2, &f[i]}, {1, &p[i]}}), LUT_IS2);
-    *found = or_tree(f);
-    *pos = position_of(first, first_window, nullptr, 0);
-}
-
-// The first slice (string order) that found a match decides (mod.rs:1010-1053: the FIRST match index, 255 if none).
-FChar Strings::find_first_decides(const std::vector<Ref> &found, const std::vector<FChar> &pos) {
-    const size_t n = std::min(found.size(), pos.size());
-    Ref three = trivial_block(e_, 3);
-    FChar r;
-    if (n == 0) return t(255);
-    std::vector<Ref> before = prefix_or(found);              // exclusive: an earlier slice found one
-    std::vector<Ref> sel(n);
-    for (size_t k = 0; k < n; k++) sel[k] = pbs(lin(e_, {{2, &found[k]}, {1, &before[k]}}), LUT_IS2);
-    Ref any = or_tree(found);
-    for (int blk = 0; blk < 4; blk++) {
-        std::vector<Ref> picked(n);
-        for (size_t k = 0; k < n; k++) picked[k] = pbs(lin(e_, {{4, &sel[k]}, {1, &pos[k].b[blk]}}), LUT_SEL_T);
-        Ref sum = n <= 15 ? sum_refs(e_, picked.data(), n) : Ref();
-        if (n > 15) {                                        // more than 15 slices: refreshed partial sums (one-hot)
-            std::vector<Ref> part;
-            for (size_t g = 0; g < n; g += 15)
-                part.push_back(pbs(sum_refs(e_, &picked[g], std::min<size_t>(15, n - g)), LUT_MSG));
-            sum = sum_refs(e_, part.data(), part.size());
-        }
-        // + 3 * (1 - any): every digit of 255 when no slice found the pattern
-        r.b[blk] = pbs(lin(e_, {{1, &sum}, {1, &three}, {-3, &any}}), LUT_MSG);
     }
     return r;
 }

@@ -35,11 +35,10 @@ class Strings {
     void f_cmp_partial(const FStr &a, const FStr &b, int cmp, FChar *any_diff_out, FChar *verdict_out);
     // combine such partials over consecutive ranges: the first range that differs decides, `tie` if none does
     FChar flags_first_decides(const FStr &any_diff, const FStr &verdict, int tie);
-    // window-sharded find (multi-GPU): local partial on a slice whose first window has global index `first_window`:
-    // *found = some local window matches, *pos = global index of the first local match (0 when none)
-    void f_find_partial(const FStr &s, const FStr &pat, size_t first_window, Ref *found, FChar *pos);
-    // combine such partials over consecutive slices (string order): position of the first slice that found one, 255 if none
-    FChar find_first_decides(const std::vector<Ref> &found, const std::vector<FChar> &pos);
+    // window-sharded find (multi-GPU): the match flags of a slice's windows, and the rest of find on ALL flags in string
+    // order (index of the first one set, 255 if none) -- fhs_dist_str_find exchanges the flags in between
+    std::vector<Ref> f_find_window_flags(const FStr &s, const FStr &pat);
+    FChar f_find_from_flags(const std::vector<Ref> &flags);
     FStr to_upper(const FStr &s);
     FStr to_lower(const FStr &s);
     FStr replace(const FStr &s, const FStr &from, const FStr &to);

@@ -290,9 +290,11 @@ void fhs_dist_plan_positions(size_t n_chars, int world, int rank, size_t *c0, si
 int fhs_dist_allgather_chars(fhs_ctx *ctx, const fhs_char_t *local, size_t n, fhs_char_t *out /*[world * n]*/);
 int fhs_dist_allgather_flags(fhs_ctx *ctx, const fhs_char_t *local, size_t n, fhs_char_t *out /*[world * n]*/);
 /* Sharded string methods: `shard` is THIS rank's slice (fhs_dist_plan_*), patterns are replicated; every rank returns
- * the full result.  contains: mod.rs:151-182 (1 block exchanged per rank).  find: mod.rs:1010-1053, partial =
- * (found, position) with the global index of the slice's first window baked in, first slice that finds decides
- * (5 blocks per rank); FHS_ERR_LIMIT when total_chars >= 255 + m like the reference's panic.  eq / eq_ignore_case:
+ * the full result.  contains: mod.rs:151-182 (1 block exchanged per rank).  find: mod.rs:1010-1053, every rank
+ * bootstraps the match flags of its windows (the two wide levels), ONE all-gather of ceil(W / world) blocks per rank hands
+ * every rank all W flags, the narrow rest (prefix OR, index of the first flag) runs replicated: six dependency levels
+ * like the single-GPU find; `shard` / `first_window` must be this rank's slice of fhs_dist_plan_windows(total_chars, m);
+ * FHS_ERR_LIMIT when total_chars >= 255 + m like the reference's panic.  eq / eq_ignore_case:
  * mod.rs:1122-1149, :1221-1231 on equally long padded buffers (1 block).  compare: mod.rs:1470-1541, cmp 0 lt, 1 le,
  * 2 gt, 3 ge (2 blocks). */
 int fhs_dist_str_contains(fhs_ctx *c, const fhs_char_t *shard, size_t n, const fhs_char_t *pat, size_t m, fhs_char_t *out);
@@ -377,6 +379,13 @@ int fhs_trivial_value(fhs_ctx *ctx, fhs_char_t h, int *is_trivial, uint8_t *valu
  * of the levelized batches: what a CPU baseline has to run to do the same work).  *n = number of levels; out may be
  * NULL to query it. */
 int fhs_level_widths(fhs_ctx *ctx, uint32_t *out, size_t cap, size_t *n);
+/* Rows THIS rank ran in every launch group (one lincomb -> keyswitch -> blind-rotation sequence) since the last
+ * fhs_reset_stats, in order: several dependency levels may share a group (level-skewed batching, round alignment) and a
+ * level-parallel rank runs its slice of each.  With a planner context that has a host transport attached
+ * (fhs_dist_init_host_transport with any callback: it is never called) the sharded entry points can be RECORDED for any
+ * (rank, world): groups, PBS, all-gathers and bytes of fhs_dist_stats are what a real run of that rank would issue --
+ * the basis of tools/project_multi_gpu.py. */
+int fhs_launch_groups(fhs_ctx *ctx, uint32_t *out, size_t cap, size_t *n);
 int fhs_reset_stats(fhs_ctx *ctx);
 
 /* ---- client side (MyClientKey, src/client_key.rs) -- host CPU, like the reference -- */

@@ -99,6 +99,40 @@ def test_client_roundtrip_and_cross_decrypt_with_oracle():
         ck.close()
 
 
+def test_string_encryption_is_threaded_and_independent_of_the_thread_count():
+    """fhs_client_encrypt_str / _decrypt_str share one string's characters among host threads (config 5 hands over 2 x
+    4097 characters = 537 MB): every character draws from its own (mask, noise) ChaCha20 streams keyed by call number and
+    index, so the ciphertexts do not depend on the number of threads; a second call never reuses a stream; the result
+    decrypts under the oracle's arithmetic too."""
+    import os
+    from fhestring_amd.api import MyClientKey
+    from oracle import core
+    text = "".join(chr(0x20 + (7 * i) % 95) for i in range(300))
+    old = os.environ.get("FHS_CLIENT_THREADS")
+    try:
+        os.environ["FHS_CLIENT_THREADS"] = "1"
+        a = MyClientKey(1234)
+        x1 = a.encrypt_str_raw(text, 1)
+        os.environ["FHS_CLIENT_THREADS"] = "6"
+        b = MyClientKey(1234)
+        x6 = b.encrypt_str_raw(text, 1)
+        assert x1.shape == (301, 4, 2049) and np.array_equal(x1, x6)
+        y6 = b.encrypt_str_raw(text, 1)
+        assert not np.array_equal(y6[:, :, :8], x6[:, :, :8])                     # fresh masks on every call
+        assert len({bytes(x6[i, k, :4]) for i in range(301) for k in range(4)}) == 1204   # no two blocks share a mask stream
+        assert b.decrypt_str_raw(y6) == text and a.decrypt_str_raw(x6) == text
+        _, glwe = a.secret_keys()
+        got = [sum(int(core.lib().orc_decrypt_block(glwe, np.ascontiguousarray(x1[i, k]))) << (2 * k) for k in range(4))
+               for i in (0, 17, 299, 300)]
+        assert got == [ord(text[0]), ord(text[17]), ord(text[299]), 0]
+        a.close(); b.close()
+    finally:
+        if old is None:
+            os.environ.pop("FHS_CLIENT_THREADS", None)
+        else:
+            os.environ["FHS_CLIENT_THREADS"] = old
+
+
 def test_product_keys_bootstrap_correctly_under_the_oracle():
     """Keys generated by the product's client are valid: the oracle PBS decrypts f(m) with them."""
     from fhestring_amd.api import MyClientKey

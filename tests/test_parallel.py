@@ -60,16 +60,21 @@ def contains(full, pat, pad=1):         # fhs_dist_str_contains
     local = int(len(shard) >= len(pat) and pat.encode() in shard) if len(pat) else 1
     return int(any(p[0] for p in gather([local])))
 
-def find(full, pat, pad=1):             # fhs_dist_str_find: partial (found, global position), first slice decides
+def find(full, pat, pad=1):             # fhs_dist_str_find: every rank's window flags, ONE gather, the rest replicated
     buf = full.encode() + b"\0" * pad
-    w0, w1, c0, c1 = plan_windows(len(buf), len(pat), world)[rank]
+    m = len(pat)
+    plan = plan_windows(len(buf), m, world)
+    n_win = len(buf) - m + 1 if m <= len(buf) else 0
+    if n_win == 0:
+        return 255
+    per = -(-n_win // world)                                  # blocks every rank contributes (short slices pad with 0)
+    w0, w1, c0, c1 = plan[rank]
     shard = buf[c0:c1]
-    k = shard.find(pat.encode()) if len(shard) >= len(pat) else -1
-    found, pos = int(k >= 0), (w0 + k if k >= 0 else 0)
-    for f, p in gather([found, pos]):
-        if f:
-            return p
-    return 255
+    local = [int(shard[i:i + m] == pat.encode()) for i in range(w1 - w0)]
+    parts = gather(local + [0] * (per - len(local)))
+    flags = [f for r, (a, b, _, _) in enumerate(plan) for f in parts[r][:b - a]]
+    assert len(flags) == n_win
+    return flags.index(1) if 1 in flags else 255
 
 def eq(a, b, n, fold=False):            # fhs_dist_str_eq on equally long padded buffers
     c0, c1 = plan_positions(n, world)[rank]
