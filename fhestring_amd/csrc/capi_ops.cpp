@@ -446,8 +446,9 @@ int fhs_char_sum_c2(fhs_ctx *c, fhs_char_t h, uint64_t *out) {
 int fhs_char_set_noise(fhs_ctx *c, fhs_char_t h, uint64_t sum_c2) {
     if (!ok(c, h)) return bad(c);
     const Bid *b = c->eng.char_blocks(h);
-    for (int i = 0; i < 4; i++)
-        if (int rc = c->eng.set_var(b[i], sum_c2)) return rc;
+    for (int i = 0; i < 4; i++)                               // all four blocks are checked before any is changed:
+        if (int rc = c->eng.set_var(b[i], sum_c2, true)) return rc;   // a refused declaration leaves the handle as it was
+    for (int i = 0; i < 4; i++) (void)c->eng.set_var(b[i], sum_c2);
     return FHS_OK;
 }
 int fhs_trivial_value(fhs_ctx *c, fhs_char_t h, int *is_trivial, uint8_t *value) {

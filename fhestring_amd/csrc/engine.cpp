@@ -266,14 +266,14 @@ int64_t Engine::sum_c2(Bid b) const {
     return c2;
 }
 
-int Engine::set_var(Bid b, uint64_t v) {
+int Engine::set_var(Bid b, uint64_t v, bool check_only) {
     BlockNode &n = nodes_[b];
     if (n.kind == BlockNode::TRIV) return 0;                  // a plaintext block carries no noise whatever is declared
     if (n.kind != BlockNode::MAT) return ctx.fail(-1, "noise can only be declared for uploaded ciphertexts");
     // a declaration can only ADD to what the bookkeeping knows: an upload starts at 1, a block the library itself
     // materialised from a sum keeps at least its own figure (no laundering through this entry point)
     if (v < n.var) return ctx.fail(-1, "fhs_char_set_noise: the declared figure is below the one the library tracks for this block");
-    n.var = (uint16_t)std::min<uint64_t>(std::max<uint64_t>(v, 1), 65535);
+    if (!check_only) n.var = (uint16_t)std::min<uint64_t>(std::max<uint64_t>(v, 1), 65535);
     return 0;
 }
 

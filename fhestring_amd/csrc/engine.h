@@ -80,7 +80,7 @@ class Engine {
     // units of one bootstrap output's): 0 trivial, 1 materialised or pending bootstrap, sum c^2 for a linear combination
     int64_t sum_c2(Bid b) const;
     int64_t term_var(Bid b) const { return nodes_[b].kind == BlockNode::MAT ? nodes_[b].var : 1; }   // of a flattened term
-    int set_var(Bid b, uint64_t v);                         // MAT blocks only (fhs_char_set_noise)
+    int set_var(Bid b, uint64_t v, bool check_only = false);                         // MAT blocks only (fhs_char_set_noise)
 
     int flush();
     // ---- level-skewed batching of independent jobs (fhs_submit / fhs_pump) ----------------------------------------

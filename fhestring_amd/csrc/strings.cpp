@@ -1,6 +1,7 @@
 #include "strings.h"
 
 #include <algorithm>
+#include <set>
 
 #include "../../include/fhestring_hip.h"
 
@@ -795,28 +796,30 @@ static Ref sum_refs(Engine *e, const Ref *r, size_t n) {
 // "The same" is structural: a flag may be a linear form over a block (1 - bad of char_significant, 1 - same ...), a new
 // node every time it is built, so two nodes are the same flag when they are the same block or the same constant + terms
 // (a string that holds one ciphertext several times -- `repeat`, a caller's own FheString -- produces those).
-static bool same_flag(const Engine *e, Bid a, Bid b) {
-    if (a == b) return true;
-    const BlockNode &x = e->node(a), &y = e->node(b);
-    if (x.kind != BlockNode::LIN || y.kind != BlockNode::LIN) return false;
-    if (x.konst != y.konst || x.terms.size() != y.terms.size()) return false;
-    auto key = [](const Term &t) { return std::make_pair(t.blk, t.coef); };
-    std::vector<std::pair<Bid, int64_t>> ta, tb;
-    for (const Term &t : x.terms) ta.push_back(key(t));
-    for (const Term &t : y.terms) tb.push_back(key(t));
-    std::sort(ta.begin(), ta.end());
-    std::sort(tb.begin(), tb.end());
-    return ta == tb;
+// One canonical key per flag -- the block id, or for a linear form its constant and its sorted (block, coefficient)
+// terms -- and an order-preserving de-duplication through a sorted set: O(n log n) in the number of flags (an and_tree
+// over 4096 characters compares thousands; pairwise comparison with two sorted temporaries each was O(n^2) allocations
+// on the host planning path).
+using FlagKey = std::vector<int64_t>;
+static FlagKey flag_key(const Engine *e, Bid a) {
+    const BlockNode &x = e->node(a);
+    if (x.kind != BlockNode::LIN) return {0, (int64_t)a};
+    std::vector<std::pair<Bid, int64_t>> tt;
+    tt.reserve(x.terms.size());
+    for (const Term &t : x.terms) tt.emplace_back(t.blk, t.coef);
+    std::sort(tt.begin(), tt.end());
+    if (tt.size() == 1 && tt[0].second == 1 && x.konst == 0) return {0, (int64_t)tt[0].first};   // 1 * block: that block
+    FlagKey k{1, (int64_t)x.konst};
+    for (auto &t : tt) { k.push_back((int64_t)t.first); k.push_back(t.second); }
+    return k;
 }
 static void distinct_flags(const Engine *e, std::vector<Ref> &f) {
+    if (f.size() < 2) return;
+    std::set<FlagKey> seen;
     std::vector<Ref> out;
     out.reserve(f.size());
-    for (Ref &x : f) {
-        bool dup = false;
-        for (const Ref &y : out)
-            if (same_flag(e, x.id(), y.id())) { dup = true; break; }
-        if (!dup) out.push_back(x);
-    }
+    for (Ref &x : f)
+        if (seen.insert(flag_key(e, x.id())).second) out.push_back(x);
     f.swap(out);
 }
 

@@ -166,6 +166,32 @@ D.level_parallel(True)
 s = ck.encrypt("hello abc abc", 1, None, sks[0])
 ok &= ck.decrypt(sks[0].replace(s, ck.encrypt_no_padding("abc", sks[0]), ck.encrypt_no_padding("xy", sks[0]))) == "hello xy xy"
 D.level_parallel(False)
+# ... and the level-parallel replace of BASELINE config 4 at FULL size (1024 characters, 5 -> 5, 8 occurrences: 131 k
+# bootstraps in 38 launch groups, every one followed by an ncclAllGather of the level and a scatter into the nodes'
+# blocks, all enqueued back to back on the stream): the engine invariants the host-staged rehearsal transport hides
+# behind its two stream synchronisations -- exchange buffers reused by the next level while the previous scatter may
+# still read them, blocks recycled in stream order, no host wait between levels (DESIGN section 8) -- only ever run here
+import random
+rnd = random.Random(4)
+text = list("".join(chr(rnd.randint(0x20, 0x7D)) for _ in range(1024)))
+for k in range(8):
+    text[20 + 120 * k:25 + 120 * k] = "~from"
+text = "".join(text)
+big = ck.encrypt(text, 1, None, sks[0])
+frm, to = ck.encrypt_no_padding("~from", sks[0]), ck.encrypt_no_padding("[to!]", sks[0])
+sks[0].flush()
+st0 = D.stats()
+D.level_parallel(True)
+sks[0].stats(reset=True)
+res = sks[0].replace(big, frm, to)
+sks[0].flush(wait=False)
+torch.cuda.synchronize()
+st = sks[0].stats()
+D.level_parallel(False)
+st1 = D.stats()
+ok &= ck.decrypt(res) == text.replace("~from", "[to!]")
+ok &= st["pbs_executed"] == 131405 and st1["allgather_calls"] - st0["allgather_calls"] == len(sks[0].launch_groups()) >= 38
+ok &= st1["transport"] == "rccl" and st1["bytes_sent"] - st0["bytes_sent"] == 131405 * 2049 * 8
 for D in jobs:
     D.shutdown()
 for sk in sks:
