@@ -70,6 +70,8 @@ def lib():
         L.orc_keyswitch.restype = None
         L.orc_pbs.argtypes = [C.c_void_p, _u64p, _u64p, _u64p, C.c_int]
         L.orc_pbs.restype = None
+        L.orc_pbs_shifted.argtypes = [C.c_void_p, _u64p, _u64p, _u32p, C.c_uint64, _u64p, C.c_int]
+        L.orc_pbs_shifted.restype = None
         L.orc_blind_rotate.argtypes = [C.c_void_p, _u32p, _u64p, _u64p, C.c_int]
         L.orc_blind_rotate.restype = None
         L.orc_pbs_batch.argtypes = [C.c_void_p, _u64p, _u32p, _u64p, _u64p, C.c_uint64, C.c_int, C.c_int]
@@ -170,6 +172,15 @@ class ServerKey:
         out = np.zeros(BIG_CT, np.uint64)
         lib().orc_pbs(self._h, np.ascontiguousarray(ct, np.uint64),
                       np.ascontiguousarray(lut, np.uint64), out, mode)
+        return out
+
+    def pbs_shifted(self, ct, lut, shifts, mode=0):
+        """orc_pbs_shifted: ONE blind rotation, one sample extraction per shift: [len(shifts), 2049], row s = what a
+        bootstrap of (ct + shifts[s] * Delta) would give (message units, 0..31)."""
+        shifts = np.ascontiguousarray(shifts, np.uint32)
+        out = np.zeros((len(shifts), BIG_CT), np.uint64)
+        lib().orc_pbs_shifted(self._h, np.ascontiguousarray(ct, np.uint64), np.ascontiguousarray(lut, np.uint64),
+                              shifts, len(shifts), out, mode)
         return out
 
     def pbs_batch(self, cts, lut_idx, luts, nthreads=None, mode=0):

@@ -1189,6 +1189,31 @@ void orc_pbs(const orc_server_key *k, const u64 *in, const u64 *lut, u64 *out, i
     out[BIG_N] = acc[POLY_N];
     free(acc);
 }
+/* ONE blind rotation, several sample extractions (the product's shift sharing, fhestring_amd/csrc/engine.cpp
+ * "rotation sharing"): out[s] is what a bootstrap of (in + shift[s] * Delta) with the same look-up table yields, shift in
+ * message units 0..31 -- adding c * Delta = c * 2^59 to the body moves the modulus-switched body by exactly 128 c
+ * (2^59 * 4096 / 2^64), i.e. rotates the accumulator by X^(128 c), so that bootstrap's constant coefficient is
+ * coefficient K = 128 c (negacyclic index in [0, 4096)) of THIS accumulator: extract coefficient K mod 2048, negate the
+ * whole LWE when K >= 2048.  shift 0 is orc_pbs itself. */
+void orc_pbs_shifted(const orc_server_key *k, const u64 *in, const u64 *lut, const u32 *shifts, u64 n, u64 *out, int mode) {
+    ensure_mode(k, mode);
+    u32 ms[SMALL_CT];
+    orc_keyswitch_modswitch(k, in, ms);
+    u64 *acc = (u64 *)malloc(2 * POLY_N * sizeof(u64));
+    blind_rotate(k, ms, lut, acc, mode);
+    for (u64 s = 0; s < n; s++) {
+        const u32 K = (128u * (shifts[s] & 31u)) & (2 * POLY_N - 1);
+        const u32 h = K & (POLY_N - 1);
+        const u64 neg = K >= POLY_N ? ~(u64)0 : 0;          /* two's complement negate: (x ^ neg) - neg */
+        u64 *o = out + s * BIG_CT;
+        for (u32 i = 0; i < POLY_N; i++) {
+            const u64 v = i <= h ? acc[h - i] : (u64)0 - acc[POLY_N + h - i];
+            o[i] = (v ^ neg) - neg;
+        }
+        o[BIG_N] = (acc[POLY_N + h] ^ neg) - neg;
+    }
+    free(acc);
+}
 /* blind rotation only, from given mod-switched values (kernel-level tests) */
 void orc_blind_rotate(const orc_server_key *k, const u32 *ms, const u64 *lut, u64 *acc, int mode) {
     ensure_mode(k, mode);
