@@ -50,8 +50,9 @@ def parse():
     ap.add_argument("--chars", type=int, default=None, help="plaintext characters (per rank if weak, in total if strong)")
     ap.add_argument("--pattern-len", type=int, default=None)
     ap.add_argument("--strings", type=int, default=None,
-                    help="independent FheStrings per step (default 8 for contains: one 64-char contains() has ~560 PBS "
-                         "in 4 dependent levels and cannot fill 256 CUs; 1 for the other ops)")
+                    help="independent FheStrings per step (default 16 for contains: one 64-char contains() is 198 blind "
+                         "rotations in 4 dependent levels and cannot fill 256 CUs -- 16 of them are three rounds of the "
+                         "persistent kernel; 1 for the other ops)")
     ap.add_argument("--mode", choices=["fused", "as_written"], default="fused")
     ap.add_argument("--cpu-pbs", type=int, default=-1, help="PBS in the CPU-baseline throughput sample (0 = skip)")
     ap.add_argument("--arith", choices=["fft", "exact", "mb2", "exact_mb2"], default="fft",
@@ -84,6 +85,10 @@ def parse():
     ap.add_argument("--watchdog", type=float, default=900.0,
                     help="multi-GPU runs: seconds the legs AFTER the timed measurement may take before rank 0 prints the "
                          "headline line it already has and every rank exits (0 = off)")
+    ap.add_argument("--launch-chunk", type=int, default=0,
+                    help="cut every blind-rotation launch into chunks of this many rows (fhs_set_launch_chunk; 0 = one launch "
+                         "per group): 1024 restarts the key walk of the persistent workgroups every round -- less fabric "
+                         "traffic, one launch per round (A/B of tools/gpu_profile_r5.sh PART=3)")
     ap.add_argument("--extras-out", default=None,
                     help="where the full record goes (default: bench_extras.json next to bench.py + a copy under gpurun_out/); "
                          "stdout carries only the compact contract line")
@@ -99,7 +104,7 @@ def parse():
     if a.pattern_len is None:
         a.pattern_len = 5 if a.op == "replace" else 4
     if a.strings is None:
-        a.strings = 8 if a.op == "contains" else 1
+        a.strings = 16 if a.op == "contains" else 1
     if a.pipelines is None:
         a.pipelines = 0 if a.op == "contains" else 1
     return a
@@ -429,7 +434,7 @@ def compact_line(full, extras_path):
     ex = cfg.get("exchange")
     if ex:
         c["config"]["exchange"] = {k: ex[k] for k in ("transport", "allgather_calls_per_step", "bytes_sent_per_rank_per_step")}
-    for k in ("ms_per_op", "single_op_latency_ms", "end_to_end_ms", "pbs_per_op", "levels_per_op", "median_ms_per_step",
+    for k in ("ms_per_op", "single_op_latency_ms", "end_to_end_ms", "pbs_per_op", "extractions_per_op", "levels_per_op", "median_ms_per_step",
               "value_median_protocol", "max_input_sum_c2", "two_queued_ms_per_op"):
         if full.get(k) is not None:
             c[k] = full[k]
@@ -639,6 +644,9 @@ def _main(safety, args):
     if not args.no_balance:
         for x in sks:
             x.set_tick_balance()                         # launch groups in whole rounds of the persistent kernel
+    if args.launch_chunk:
+        for x in sks:
+            x.ctx.set_launch_chunk(ARITH[args.arith], args.launch_chunk)
     wl = Workload(args, ck, sks, dists, rank, world)
     if wl.op == "replace" and world > 1:
         for D in dists:
@@ -1266,7 +1274,7 @@ def _main(safety, args):
             "dtype": "u64" if args.arith in ("exact", "exact_mb2") else "f64",
             "data": "synthetic",
             "config": {"workload": "%s, %s DAG, %s arithmetic" % (wl.describe(), args.mode, ARITH_NAME[args.arith]),
-                       "pipelines": args.pipelines,
+                       "pipelines": args.pipelines, "launch_chunk": args.launch_chunk,
                        "scheduling": (("level-skewed batching: one context, fhs_submit + fhs_pump per step, the narrow "
                                        "levels of step k ride in the wide launch of step k+1" +
                                        ("" if args.no_balance else "; launch groups aligned to whole rounds of the "
@@ -1284,6 +1292,9 @@ def _main(safety, args):
             "repeat_ms_per_step": rep_ms,
             "repeat_steps": n_rep_steps,
             "pbs_per_op": pbs_total / args.steps / wl.n_strings,
+            # rotation sharing: results that are a further sample extraction of another row's blind rotation (same table,
+            # same ciphertext up to a trivial constant: the nibble tests of a clear pattern); NOT counted in `value`
+            "extractions_per_op": st.get("pbs_extracted", 0) / args.steps / wl.n_strings,
             "levels_per_op": st["levels"] / args.steps,
             "max_level_width": st["max_level_width"],
             "max_input_sum_c2": st.get("max_input_sum_c2"),

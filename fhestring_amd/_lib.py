@@ -257,6 +257,10 @@ def _declare(L):
     L.fhs_pump.restype = i
     L.fhs_level_widths.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.fhs_level_widths.restype = i
+    L.fhs_pbs_batch_shifted.argtypes = [vp, vp, vp, vp, sz, vp, sz, vp, sz]
+    L.fhs_pbs_batch_shifted.restype = i
+    L.fhs_set_rotation_sharing.argtypes = [vp, i]
+    L.fhs_set_rotation_sharing.restype = i
     L.fhs_launch_groups.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.fhs_launch_groups.restype = i
     L.fhs_get_stats.argtypes = [vp, vp]
@@ -316,7 +320,8 @@ class CaptureRec(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("pbs_executed", C.c_uint64), ("pbs_folded", C.c_uint64), ("levels", C.c_uint64),
-                ("max_level_width", C.c_uint64), ("blocks_live", C.c_uint64), ("max_input_sum_c2", C.c_uint64), ("pbs_shared", C.c_uint64)]
+                ("max_level_width", C.c_uint64), ("blocks_live", C.c_uint64), ("max_input_sum_c2", C.c_uint64), ("pbs_shared", C.c_uint64),
+                ("pbs_extracted", C.c_uint64)]
 
 
 def fft_tables():

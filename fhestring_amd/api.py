@@ -105,6 +105,22 @@ class Context:
                                           _ptr(out), B))
         return out
 
+    def pbs_batch_shifted(self, cts, lut_idx, luts, shifts):
+        """fhs_pbs_batch_shifted: ONE blind rotation per input, one sample extraction per shift -> [B, S, 2049]; row
+        (b, s) = what a bootstrap of (cts[b] + shifts[b][s] * Delta) yields (message units 0..31)."""
+        cts = np.ascontiguousarray(cts, np.uint64).reshape(-1, BIG_CT)
+        luts = np.ascontiguousarray(luts, np.uint64).reshape(-1, POLY_N)
+        lut_idx = np.ascontiguousarray(lut_idx, np.uint32)
+        B = cts.shape[0]
+        shifts = np.ascontiguousarray(shifts, np.uint32).reshape(B, -1)
+        out = np.zeros((B, shifts.shape[1], BIG_CT), np.uint64)
+        self._check(self._L.fhs_pbs_batch_shifted(self._h, _ptr(cts), _ptr(lut_idx), _ptr(luts), luts.shape[0],
+                                                  _ptr(shifts), shifts.shape[1], _ptr(out), B))
+        return out
+
+    def set_rotation_sharing(self, on=True):
+        self._check(self._L.fhs_set_rotation_sharing(self._h, int(bool(on))))
+
     def keyswitch_modswitch_batch(self, cts):
         cts = np.ascontiguousarray(cts, np.uint64).reshape(-1, BIG_CT)
         B = cts.shape[0]

@@ -112,6 +112,13 @@ int fhs_pbs_batch(fhs_ctx *ctx, const uint64_t *in, const uint32_t *lut_idx, con
     return ctx->eng.ctx.pbs_batch_host(in, lut_idx, luts, n_luts, out, B);
 }
 
+int fhs_pbs_batch_shifted(fhs_ctx *ctx, const uint64_t *in, const uint32_t *lut_idx, const uint64_t *luts, size_t n_luts,
+                          const uint32_t *shifts, size_t n_shifts, uint64_t *out, size_t B) {
+    if (!ctx) return FHS_ERR_ARG;
+    if (ctx->eng.planner) return ctx->eng.ctx.fail(FHS_ERR_STATE, "planner context: nothing is computed");
+    return ctx->eng.ctx.pbs_batch_shifted_host(in, lut_idx, luts, n_luts, shifts, n_shifts, out, B);
+}
+
 int fhs_debug_blind_rotate_batch(fhs_ctx *ctx, const uint64_t *ks, const uint32_t *lut_idx, const uint64_t *luts,
                                  size_t n_luts, uint64_t *out, size_t B) {
     if (!ctx) return FHS_ERR_ARG;

@@ -433,6 +433,7 @@ int fhs_get_stats(fhs_ctx *c, fhs_stats *out) {
     out->blocks_live = c->eng.blocks_live();
     out->max_input_sum_c2 = c->eng.stats.max_input_sum_c2;
     out->pbs_shared = c->eng.stats.pbs_shared;
+    out->pbs_extracted = c->eng.stats.pbs_extracted;
     return FHS_OK;
 }
 int fhs_char_sum_c2(fhs_ctx *c, fhs_char_t h, uint64_t *out) {
@@ -468,6 +469,11 @@ int fhs_level_widths(fhs_ctx *c, uint32_t *out, size_t cap, size_t *n) {
     const auto &w = c->eng.stats.level_widths;
     *n = w.size();
     if (out) std::copy(w.begin(), w.begin() + std::min(cap, w.size()), out);
+    return FHS_OK;
+}
+int fhs_set_rotation_sharing(fhs_ctx *c, int on) {
+    if (!c) return FHS_ERR_ARG;
+    c->eng.share_rotations = on != 0;
     return FHS_OK;
 }
 int fhs_launch_groups(fhs_ctx *c, uint32_t *out, size_t cap, size_t *n) {

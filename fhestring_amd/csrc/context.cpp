@@ -136,6 +136,7 @@ void Context::shutdown() {
     in_buf.release();
     out_buf.release();
     lutidx_buf.release();
+    tab_buf.release();
     luts_buf.release();
     if (d_ksk_planes) (void)hipFree(d_ksk_planes);
     d_ksk_planes = nullptr;
@@ -306,7 +307,7 @@ int Context::load_multibit_key(const uint64_t *bsk_mb2) {
 }
 
 int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const uint64_t *d_luts, uint64_t *d_out,
-                          uint64_t *const *d_out_ptrs, size_t B, hipStream_t s) {
+                          uint64_t *const *d_out_ptrs, size_t B, hipStream_t s, uint64_t *const *d_body_ptrs) {
     hipError_t e = hipSuccess;
     const bool four = arith == 1 && B <= (size_t)fft4_max_batch;
     if (arith == 2 && !d_bsk_mb) return fail(-3, "pair key not loaded (fhs_load_multibit_key)");
@@ -325,11 +326,12 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
         const uint32_t *li = d_lut_idx + off;
         uint64_t *out = d_out ? d_out + off * BIG_CT : nullptr;
         uint64_t *const *outp = d_out_ptrs ? d_out_ptrs + off : nullptr;
+        uint64_t *const *bodyp = d_body_ptrs ? d_body_ptrs + off : nullptr;   // rotation sharing (engine.cpp)
         if (arith == 3) {
             BlindRotateNttMb2Params p{};
             p.ks = ks; p.lut_idx = li; p.luts = d_luts;
             p.bsk_ntt_mb = d_bsk_ntt_mb; p.tw = tw; p.crt_c = crt_c; p.mono = d_ntt_mono;
-            p.out = out; p.out_ptrs = outp; p.B = (int)n;
+            p.out = out; p.out_ptrs = outp; p.body_ptrs = bodyp; p.B = (int)n;
             e = launch_blind_rotate_ntt_mb2(p, s);
         } else if (arith == 2) {
             BlindRotateMb2Params p{};
@@ -340,7 +342,7 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
             p.r16 = p.mono + 2 * 4096;
             p.work_counter = d_work_counter;
             p.slots = wg_slots;
-            p.out = out; p.out_ptrs = outp; p.B = (int)n;
+            p.out = out; p.out_ptrs = outp; p.body_ptrs = bodyp; p.B = (int)n;
             e = launch_blind_rotate_mb2(p, s);
         } else if (arith == 1) {
             BlindRotateFftParams p{};
@@ -350,13 +352,13 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
             p.weff = d_fft_tables + 12 * 64;
             p.work_counter = d_work_counter;
             p.slots = wg_slots;
-            p.out = out; p.out_ptrs = outp; p.B = (int)n;
+            p.out = out; p.out_ptrs = outp; p.body_ptrs = bodyp; p.B = (int)n;
             e = four ? launch_blind_rotate_fft4(p, s) : launch_blind_rotate_fft(p, s);
         } else {
             BlindRotateParams p{};
             p.ks = ks; p.lut_idx = li; p.luts = d_luts;
             p.bsk_ntt = d_bsk_ntt; p.tw = tw; p.crt_c = crt_c;
-            p.out = out; p.out_ptrs = outp; p.B = (int)n;
+            p.out = out; p.out_ptrs = outp; p.body_ptrs = bodyp; p.B = (int)n;
             e = launch_blind_rotate(p, s);
         }
     }
@@ -394,6 +396,55 @@ int Context::pbs_batch_host(const uint64_t *in, const uint32_t *lut_idx, const u
                               out_buf.as<uint64_t>(), B, stream);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, out_buf.ptr, B * BIG_CT * 8, hipMemcpyDeviceToHost, stream), "D2H");
+    HIP_TRY(hipStreamSynchronize(stream), "sync");
+    return 0;
+}
+
+// Rotation sharing at the raw boundary: ONE keyswitch + blind rotation per input, S sample extractions each --
+// out[b][s] = what a bootstrap of (in[b] + shifts[b][s] * Delta) with LUT lut_idx[b] yields (shifts in message units,
+// 0..31).  The engine does the same for rows of a level that differ only in a trivial constant (engine.cpp plan_job).
+int Context::pbs_batch_shifted_host(const uint64_t *in, const uint32_t *lut_idx, const uint64_t *luts, size_t n_luts,
+                                    const uint32_t *shifts, size_t S, uint64_t *out, size_t B) {
+    if (!key_loaded) return fail(-3, "server key not loaded");
+    if (!in || !lut_idx || !luts || !shifts || !out) return fail(-1, "null pointer");
+    if (B == 0 || S == 0) return 0;
+    if (B * S > (size_t)1 << 22) return fail(-1, "batch too large");
+    for (size_t b = 0; b < B; b++)
+        if (lut_idx[b] >= n_luts) return fail(-1, "lut_idx out of range");
+    HIP_TRY(hipSetDevice(device), "hipSetDevice");
+    // device layout: [B rotation outputs | B body polynomials (2049-word rows) | B * S extractions]
+    HIP_TRY(in_buf.reserve(B * BIG_CT * 8), "hipMalloc");
+    HIP_TRY(out_buf.reserve((2 * B + B * S) * BIG_CT * 8), "hipMalloc");
+    HIP_TRY(lutidx_buf.reserve(B * 4), "hipMalloc");
+    HIP_TRY(luts_buf.reserve(n_luts * POLY_N * 8), "hipMalloc");
+    HIP_TRY(ks_buf.reserve(B * SMALL_CT * sizeof(uint64_t)), "hipMalloc ks");
+    uint64_t *d_rot = out_buf.as<uint64_t>(), *d_body = d_rot + B * BIG_CT, *d_ext = d_body + B * BIG_CT;
+    std::vector<uint64_t *> ptrs(2 * B);
+    std::vector<ExtractDesc> descs(B * S);
+    for (size_t b = 0; b < B; b++) {
+        ptrs[b] = d_rot + b * BIG_CT;
+        ptrs[B + b] = d_body + b * BIG_CT;
+        for (size_t k = 0; k < S; k++)
+            descs[b * S + k] = ExtractDesc{ptrs[b], ptrs[B + b], d_ext + (b * S + k) * BIG_CT, 128u * (shifts[b * S + k] & 31u), 0};
+    }
+    DevBuf &tab = tab_buf;
+    const size_t tab_bytes = ptrs.size() * sizeof(uint64_t *) + descs.size() * sizeof(ExtractDesc);
+    HIP_TRY(tab.reserve(tab_bytes), "hipMalloc");
+    HIP_TRY(hipMemcpyAsync(tab.ptr, ptrs.data(), ptrs.size() * sizeof(uint64_t *), hipMemcpyHostToDevice, stream), "H2D");
+    HIP_TRY(hipMemcpyAsync(tab.as<uint8_t>() + ptrs.size() * sizeof(uint64_t *), descs.data(), descs.size() * sizeof(ExtractDesc),
+                           hipMemcpyHostToDevice, stream), "H2D");
+    HIP_TRY(hipMemcpyAsync(in_buf.ptr, in, B * BIG_CT * 8, hipMemcpyHostToDevice, stream), "H2D");
+    HIP_TRY(hipMemcpyAsync(lutidx_buf.ptr, lut_idx, B * 4, hipMemcpyHostToDevice, stream), "H2D");
+    HIP_TRY(hipMemcpyAsync(luts_buf.ptr, luts, n_luts * POLY_N * 8, hipMemcpyHostToDevice, stream), "H2D");
+    HIP_TRY(hipStreamSynchronize(stream), "sync");                       // the host vectors above are pageable
+    if (int rc = keyswitch(in_buf.as<uint64_t>(), B, stream)) return rc;
+    uint64_t *const *d_ptrs = tab.as<uint64_t *>();
+    if (int rc = blind_rotate(ks_buf.as<uint64_t>(), lutidx_buf.as<uint32_t>(), luts_buf.as<uint64_t>(), nullptr, d_ptrs, B, stream,
+                              d_ptrs + B))
+        return rc;
+    HIP_TRY(launch_extract_shift(reinterpret_cast<const ExtractDesc *>(tab.as<uint8_t>() + ptrs.size() * sizeof(uint64_t *)),
+                                 (int)(B * S), stream), "extract launch");
+    HIP_TRY(hipMemcpyAsync(out, d_ext, B * S * BIG_CT * 8, hipMemcpyDeviceToHost, stream), "D2H");
     HIP_TRY(hipStreamSynchronize(stream), "sync");
     return 0;
 }

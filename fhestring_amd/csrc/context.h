@@ -74,7 +74,7 @@ class Context {
     int keyswitch(const uint64_t *d_in, size_t B, hipStream_t s);
     // blind rotation in the selected arithmetic (timed as kernel kind 0)
     int blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const uint64_t *d_luts, uint64_t *d_out,
-                     uint64_t *const *d_out_ptrs, size_t B, hipStream_t s);
+                     uint64_t *const *d_out_ptrs, size_t B, hipStream_t s, uint64_t *const *d_body_ptrs = nullptr);
 
     // multi-GPU exchange (fhs_dist_init): RCCL communicator of this context, or a host transport
     Dist dist;
@@ -82,7 +82,7 @@ class Context {
 
     // scratch
     DevBuf dig_buf;                  // keyswitch digits of the current batch
-    DevBuf ks_buf, ms_buf, in_buf, out_buf, lutidx_buf, luts_buf;
+    DevBuf ks_buf, ms_buf, in_buf, out_buf, lutidx_buf, luts_buf, tab_buf;
     KernelTimer timer;
 
     int init(int device_id);
@@ -94,6 +94,8 @@ class Context {
     // all device pointers; enqueues KS+MS then blind rotation on `s`
     int pbs_batch_device(const uint64_t *d_in, const uint32_t *d_lut_idx, const uint64_t *d_luts,
                          uint64_t *d_out, size_t B, hipStream_t s);
+    int pbs_batch_shifted_host(const uint64_t *in, const uint32_t *lut_idx, const uint64_t *luts, size_t n_luts,
+                               const uint32_t *shifts, size_t S, uint64_t *out, size_t B);
     int pbs_batch_host(const uint64_t *in, const uint32_t *lut_idx, const uint64_t *luts, size_t n_luts,
                        uint64_t *out, size_t B);
     int ks_ms_batch_host(const uint64_t *in, uint32_t *ms_out, size_t B);

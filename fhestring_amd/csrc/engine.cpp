@@ -439,9 +439,69 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
         std::vector<Bid> &lv = lvit->second;
         TickLevel tl;
         tl.job = job;
-        row_need.assign(lv.size(), 0);
+        // ---- rotation sharing ------------------------------------------------------------------------------------
+        // Rows of this level with the same look-up table on the same linear combination up to its trivial CONSTANT
+        // (e.g. the nibble of a character tested against the different nibbles of a clear pattern: is0(x - c)) share ONE
+        // keyswitch + blind rotation: adding c * Delta to a ciphertext rotates the accumulator by X^(128 c) exactly, so the
+        // other rows are further sample extractions of the leader's accumulator (extract_shift_kernel) -- the same
+        // ciphertext a bootstrap of their own would give, up to decomposition ties (oracle: orc_pbs_shifted).  The level
+        // is reordered: rotation rows first (R of them), followers behind.
+        std::vector<ShareRow> followers;
+        size_t R = lv.size();
+        if (share_rotations && mode == 1 && lv.size() > 1 && !(level_parallel && ctx.dist.active())) {
+            std::unordered_map<uint64_t, std::vector<uint32_t>> seen;     // hash of (lut, terms) -> leader positions
+            std::vector<Bid> rot, fol;
+            std::vector<ShareRow> fmeta;
+            auto key_terms = [&](const BlockNode &src, Bid self, std::vector<std::pair<Bid, int64_t>> &tt, int &konst) {
+                tt.clear();
+                if (src.kind == BlockNode::LIN) {
+                    for (const Term &t : src.terms) tt.emplace_back(t.blk, t.coef);
+                    std::sort(tt.begin(), tt.end());
+                    konst = src.konst;
+                } else {
+                    tt.emplace_back(self, 1);
+                    konst = 0;
+                }
+            };
+            std::vector<std::pair<Bid, int64_t>> ta, tb;
+            for (Bid b : lv) {
+                const BlockNode &n = nodes_[b];
+                int ka = 0;
+                key_terms(nodes_[n.src], n.src, ta, ka);
+                uint64_t h = 0x9E3779B97F4A7C15ull * (uint64_t)(n.lut + 1);
+                for (auto &t : ta) {
+                    h ^= ((uint64_t)t.first << 20) + (uint64_t)t.second * 0xBF58476D1CE4E5B9ull;
+                    h = (h ^ (h >> 29)) * 0x94D049BB133111EBull;
+                }
+                std::vector<uint32_t> &cand = seen[h];
+                bool shared = false;
+                for (uint32_t pos : cand) {
+                    const BlockNode &ln = nodes_[rot[pos]];
+                    int kb = 0;
+                    key_terms(nodes_[ln.src], ln.src, tb, kb);
+                    if (ln.lut != n.lut || ta != tb) continue;
+                    fol.push_back(b);
+                    fmeta.push_back({pos, (uint32_t)(128 * (((ka - kb) % 32 + 32) % 32)), nullptr});
+                    shared = true;
+                    break;
+                }
+                if (!shared) {
+                    cand.push_back((uint32_t)rot.size());
+                    rot.push_back(b);
+                }
+            }
+            if (!fol.empty()) {
+                R = rot.size();
+                lv.swap(rot);
+                lv.insert(lv.end(), fol.begin(), fol.end());
+                followers.swap(fmeta);
+                tl.body.assign(R, nullptr);
+            }
+        }
+        row_need.assign(R, 0);
         size_t row_i = 0;
-        for (Bid b : lv) {
+        for (size_t li = 0; li < R; li++) {
+            const Bid b = lv[li];
             BlockNode &n = nodes_[b];
             const BlockNode &s = nodes_[n.src];
             LinDesc d{};
@@ -482,6 +542,15 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
             if (!o) return ctx.fail(-2, "device block pool exhausted (hipMalloc failed)");
             tl.out.push_back(o);
         }
+        for (ShareRow &f : followers) {                      // a follower's own block; its leader also stores the body polynomial
+            f.out = alloc_block();
+            if (!f.out) return ctx.fail(-2, "device block pool exhausted (hipMalloc failed)");
+            if (!tl.body[f.lead_row]) {
+                tl.body[f.lead_row] = alloc_block();
+                if (!tl.body[f.lead_row]) return ctx.fail(-2, "device block pool exhausted (hipMalloc failed)");
+            }
+        }
+        tl.ext = followers;
         if (run_now) {
             // nothing is scheduled (flush drained it): enqueue this level right away, then plan the next one meanwhile
             std::vector<TickLevel> one;
@@ -491,7 +560,7 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                 BlockNode &n = nodes_[lv[k]];
                 const Bid src = n.src;
                 n.kind = BlockNode::MAT;
-                n.dev = one[0].out[k];
+                n.dev = k < R ? one[0].out[k] : followers[k - R].out;
                 n.src = 0;
                 n.level = 0;
                 release(src);                                // immediate recycling is safe: stream order
@@ -504,7 +573,7 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
         // which was itself sent one tick later (round alignment below, or a dependent job) follow it, the others stay.
         const uint64_t t0 = tick + 1;
         uint64_t base = ~0ull, last = 0;
-        for (size_t k = 0; k < lv.size(); k++) {
+        for (size_t k = 0; k < R; k++) {
             row_need[k] = std::max(t0, row_need[k] + 1);      // now: the row's own tick
             base = std::min(base, row_need[k]);
             last = std::max(last, row_need[k]);
@@ -514,7 +583,7 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
         // rows as fill whole rounds of the persistent kernel; the excess (less than one round) runs one tick later with
         // whatever is scheduled there -- only ITS consumers follow it, the rest of the next level does not wait
         size_t n_base = 0;
-        for (size_t k = 0; k < lv.size(); k++) n_base += row_need[k] == base;
+        for (size_t k = 0; k < R; k++) n_base += row_need[k] == base;
         if (balance_slots) {
             size_t cur = 0;
             auto it = sched_.find(base);
@@ -537,23 +606,23 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
             if (stream_pump && !defer && total * 8 < balance_slots && nx != by_level.end() &&
                 nx->second.size() >= 2 * balance_slots)
                 defer = n_base;
-            for (size_t k = lv.size(); k-- > 0 && defer;)
+            for (size_t k = R; k-- > 0 && defer;)
                 if (row_need[k] == base) { row_need[k] = base + 1; defer--; }
-            for (size_t k = 0; k < lv.size(); k++) last = std::max(last, row_need[k]);
+            for (size_t k = 0; k < R; k++) last = std::max(last, row_need[k]);
         }
         last_sched_tick_ = std::max(last_sched_tick_, last);  // before the releases below
         for (size_t k = 0; k < lv.size(); k++) {
             BlockNode &n = nodes_[lv[k]];
             const Bid src = n.src;
             n.kind = BlockNode::MAT;
-            n.dev = tl.out[k];
+            n.dev = k < R ? tl.out[k] : tl.ext[k - R].out;
             n.src = 0;
             n.level = 0;
-            n.ready_tick = row_need[k];
+            n.ready_tick = k < R ? row_need[k] : row_need[tl.ext[k - R].lead_row];   // a follower is ready with its leader
             release(src);
         }
         // hand the rows to their ticks (ascending): one TickLevel per job and tick, rows of several levels merged
-        std::vector<uint64_t> ticks(row_need.begin(), row_need.begin() + lv.size());
+        std::vector<uint64_t> ticks(row_need.begin(), row_need.begin() + R);
         std::sort(ticks.begin(), ticks.end());
         ticks.erase(std::unique(ticks.begin(), ticks.end()), ticks.end());
         for (uint64_t tk : ticks) {
@@ -571,16 +640,24 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                 *dst = std::move(tl);
                 break;
             }
-            for (size_t k = 0; k < lv.size(); k++) {
+            std::vector<uint32_t> moved(tl.ext.empty() ? 0 : R, 0);   // leader row -> its position in dst
+            for (size_t k = 0; k < R; k++) {
                 if (row_need[k] != tk) continue;
                 LinDesc d = tl.descs[k];
                 const uint32_t f = d.first_term;
                 d.first_term = (uint32_t)dst->terms.size();
                 dst->terms.insert(dst->terms.end(), tl.terms.begin() + f, tl.terms.begin() + f + d.n_terms);
+                if (!tl.ext.empty()) {
+                    moved[k] = (uint32_t)dst->descs.size();
+                    dst->body.resize(dst->descs.size(), nullptr);
+                    dst->body.push_back(tl.body[k]);
+                }
                 dst->descs.push_back(d);
                 dst->lut.push_back(tl.lut[k]);
                 dst->out.push_back(tl.out[k]);
             }
+            for (const ShareRow &f : tl.ext)                       // followers travel with their leader's tick
+                if (row_need[f.lead_row] == tk) dst->ext.push_back({moved[f.lead_row], f.K, f.out});
         }
         // streaming flush: every tick up to `base` is complete now (later levels cannot reach back) -- enqueue them while
         // the host plans the next level
@@ -650,10 +727,17 @@ int Engine::run_tick(std::vector<TickLevel> &levels, bool sharded) {
     const size_t cap = (width + world - 1) / world;
     const size_t lo = std::min(width, rank * cap), hi = std::min(width, lo + cap), cnt = hi - lo;
     stats.pbs_executed += cnt;
+    size_t n_ext = 0;
+    for (auto &l : levels) n_ext += l.ext.size();
+    if (n_ext && sharded) return ctx.fail(-3, "internal: rotation sharing in a level-parallel launch group");
+    stats.pbs_extracted += n_ext;
     if (stats.group_rows.size() < (1u << 20)) stats.group_rows.push_back((uint32_t)cnt);
     if (planner) {
         // nothing runs, but the exchange of a level-parallel launch group is accounted for like Dist::all_gather does
         if (sharded) { ctx.dist.n_gathers++; ctx.dist.bytes_sent += cap * BIG_CT * 8; }
+        for (auto &l : levels)
+            for (uint64_t *b : l.body)
+                if (b) free_block(b);
         return 0;
     }
     if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
@@ -661,13 +745,18 @@ int Engine::run_tick(std::vector<TickLevel> &levels, bool sharded) {
     const size_t off_terms = off_desc + width * sizeof(LinDesc);
     const size_t off_lut = off_terms + n_terms * sizeof(LinTerm);
     const size_t off_out = (off_lut + width * 4 + 15) & ~(size_t)15;
-    const size_t total = off_out + width * sizeof(uint64_t *);
+    // rotation sharing: [body pointer per row | one ExtractDesc per follower] behind the output pointers
+    const size_t off_body = off_out + width * sizeof(uint64_t *);
+    const size_t off_ext = off_body + (n_ext ? width * sizeof(uint64_t *) : 0);
+    const size_t total = off_ext + n_ext * sizeof(ExtractDesc);
     std::vector<uint8_t> host(total);
     LinDesc *hd = reinterpret_cast<LinDesc *>(host.data() + off_desc);
     LinTerm *ht = reinterpret_cast<LinTerm *>(host.data() + off_terms);
     uint32_t *hl = reinterpret_cast<uint32_t *>(host.data() + off_lut);
     uint64_t **ho = reinterpret_cast<uint64_t **>(host.data() + off_out);
-    size_t di = 0, ti = 0;
+    uint64_t **hb = reinterpret_cast<uint64_t **>(host.data() + off_body);
+    ExtractDesc *hx = reinterpret_cast<ExtractDesc *>(host.data() + off_ext);
+    size_t di = 0, ti = 0, xi = 0;
     for (auto &l : levels) {
         for (size_t k = 0; k < l.descs.size(); k++) {
             LinDesc d = l.descs[k];
@@ -675,7 +764,9 @@ int Engine::run_tick(std::vector<TickLevel> &levels, bool sharded) {
             hd[di + k] = d;
             hl[di + k] = l.lut[k];
             ho[di + k] = l.out[k];
+            if (n_ext) hb[di + k] = k < l.body.size() ? l.body[k] : nullptr;
         }
+        for (const ShareRow &f : l.ext) hx[xi++] = ExtractDesc{l.out[f.lead_row], l.body[f.lead_row], f.out, f.K, 0};
         std::memcpy(ht + ti, l.terms.data(), l.terms.size() * sizeof(LinTerm));
         di += l.descs.size();
         ti += l.terms.size();
@@ -702,7 +793,17 @@ int Engine::run_tick(std::vector<TickLevel> &levels, bool sharded) {
         e = launch_lincomb(d_desc, d_terms, batch_in_.as<uint64_t>(), (int)width, ctx.stream);
         if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
         if (int rc = ctx.keyswitch(batch_in_.as<uint64_t>(), width, ctx.stream)) return rc;
-        if (int rc = ctx.blind_rotate(ctx.ks_buf.as<uint64_t>(), d_lut, d_luts_, nullptr, d_out, width, ctx.stream)) return rc;
+        uint64_t *const *d_body = n_ext ? reinterpret_cast<uint64_t *const *>(dp + off_body) : nullptr;
+        if (int rc = ctx.blind_rotate(ctx.ks_buf.as<uint64_t>(), d_lut, d_luts_, nullptr, d_out, width, ctx.stream, d_body)) return rc;
+        if (n_ext) {
+            // the followers: further sample extractions of their leaders' accumulators, then the body polynomials' blocks
+            // go back to the pool (stream order: whoever gets them next runs behind this kernel)
+            e = launch_extract_shift(reinterpret_cast<const ExtractDesc *>(dp + off_ext), (int)n_ext, ctx.stream);
+            if (e != hipSuccess) return ctx.hip_fail(e, "extract launch");
+            for (auto &l : levels)
+                for (uint64_t *b : l.body)
+                    if (b) free_block(b);
+        }
         if (!last_group_done_) (void)hipEventCreateWithFlags(&last_group_done_, hipEventDisableTiming);
         if (last_group_done_) (void)hipEventRecord(last_group_done_, ctx.stream);
         return 0;

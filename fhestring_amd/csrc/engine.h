@@ -47,6 +47,7 @@ struct EngineStats {
     uint64_t pbs_shared = 0;         // bootstraps not run because an identical one (same input combination, same LUT) exists
     uint64_t max_input_sum_c2 = 0;   // largest sum of squared coefficients of any executed bootstrap's input
     std::vector<uint32_t> level_widths;   // width of every dependency level executed since the last reset (capped)
+    uint64_t pbs_extracted = 0;      // results obtained as a further sample extraction of a shared blind rotation (not in pbs_executed)
     std::vector<uint32_t> group_rows;     // rows THIS rank ran in every launch group (lincomb -> keyswitch -> blind rotation) since the last reset (capped)
 };
 
@@ -106,6 +107,9 @@ class Engine {
     // records the same DAG; flush() then runs slice [rank*cap, (rank+1)*cap) of every level, all-gathers the slices on
     // the context's stream (ctx.dist: RCCL, no host wait between levels) and installs the gathered level.
     bool level_parallel = false;
+    // Rotation sharing (fused mode): rows of one level that differ only in the trivial constant of their input share one
+    // keyswitch + blind rotation (plan_job).  fhs_set_rotation_sharing(ctx, 0) switches it off (A/B measurements, tests).
+    bool share_rotations = true;
     // Gathers `n` blocks per rank: local[k] of every rank -> out[r * n + k] (fresh MAT blocks owned by the caller).
     // Flushes the local DAG first; everything is enqueued on the context's stream.
     int gather_blocks(const Bid *local, size_t n, std::vector<Bid> &out);
@@ -168,11 +172,19 @@ class Engine {
         size_t off_desc = 0, off_terms = 0, off_lut = 0, off_out = 0, max_width = 0;
     } plan_;
 
+    // rotation sharing (plan_job): a follower row is a further sample extraction of its leader's blind rotation
+    struct ShareRow {
+        uint32_t lead_row;                // position of the leader among the rotation rows of the same TickLevel
+        uint32_t K;                       // negacyclic coefficient to extract: 128 x (constant difference mod 32)
+        uint64_t *out;                    // the follower's own block
+    };
     struct TickLevel {
         std::vector<LinDesc> descs;       // first_term relative to `terms`
         std::vector<LinTerm> terms;
         std::vector<uint32_t> lut;
         std::vector<uint64_t *> out;
+        std::vector<uint64_t *> body;     // empty, or per rotation row: where the accumulator's body polynomial goes (leaders)
+        std::vector<ShareRow> ext;        // followers of this level's leaders
         uint64_t job = 0;                 // rows of one job that land on the same tick share one TickLevel
     };
     std::map<uint64_t, std::vector<TickLevel>> sched_;            // tick -> job levels to run in that launch group

@@ -345,8 +345,13 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
             if (n == 0) out[0] = acc[r] + 1;
             else out[POLY_N - n] = (uint64_t)0 - (acc[r] + 1);
         }
-    } else if (k0 == 0) {
-        out[BIG_N] = acc[0] + 1;
+    } else {
+        if (k0 == 0) out[BIG_N] = acc[0] + 1;
+        uint64_t *body = P.body_ptrs ? P.body_ptrs[ct] : nullptr;      // rotation sharing: the whole body polynomial
+        if (body) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) body[k0 + 64 * (r & 7) + 1024 * (r >> 3)] = acc[r] + 1;
+        }
     }
 }
 

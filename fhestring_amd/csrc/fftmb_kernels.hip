@@ -230,8 +230,13 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_mb2_kernel(BlindRotateMb2
             if (n == 0) out[0] = acc[r];
             else out[POLY_N - n] = (uint64_t)0 - acc[r];
         }
-    } else if (lane == 0) {
-        out[BIG_N] = acc[0];
+    } else {
+        if (lane == 0) out[BIG_N] = acc[0];
+        uint64_t *body = P.body_ptrs ? P.body_ptrs[ct] : nullptr;      // rotation sharing: the whole body polynomial
+        if (body) {
+#pragma unroll
+            for (int r = 0; r < 32; r++) body[lane + 64 * r] = acc[r];
+        }
     }
     }   // persistent loop
 }

@@ -201,8 +201,13 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_ntt_mb2_kernel(BlindRotat
             if (n == 0) out[0] = acc[o];
             else out[POLY_N - n] = (uint64_t)0 - acc[o];
         }
-    } else if (q == 0 && lane == 0) {
-        out[BIG_N] = acc[0];
+    } else {
+        if (q == 0 && lane == 0) out[BIG_N] = acc[0];
+        uint64_t *body = P.body_ptrs ? P.body_ptrs[ct] : nullptr;      // rotation sharing: the whole body polynomial
+        if (body) {
+#pragma unroll
+            for (int o = 0; o < 16; o++) body[lane + 64 * (2 * o + q)] = acc[o];
+        }
     }
 }
 

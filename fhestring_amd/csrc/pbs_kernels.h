@@ -42,6 +42,9 @@ struct BlindRotateParams {
     double crt_c;             // p0^-1 mod p1, centred
     uint64_t *out;            // [B][2049] dense output, or
     uint64_t *const *out_ptrs; // [B] per-ciphertext output blocks (used when non-null)
+    uint64_t *const *body_ptrs; // [B] or null; body_ptrs[ct] != null: also store the accumulator's BODY polynomial (2048
+                               // words) there -- rotation sharing: further sample extractions of the same rotation
+                               // (extract_shift_kernel) need B[h], the mask polynomial is in the output LWE already
     int B;
 };
 
@@ -57,6 +60,7 @@ struct BlindRotateFftParams {
     int slots;                // 2-wavefront kernel: resident workgroup slots of the device (4 per CU)
     uint64_t *out;
     uint64_t *const *out_ptrs;
+    uint64_t *const *body_ptrs;   // see BlindRotateParams
     int B;
 };
 
@@ -73,6 +77,7 @@ struct BlindRotateMb2Params {
     int slots;
     uint64_t *out;
     uint64_t *const *out_ptrs;
+    uint64_t *const *body_ptrs;   // see BlindRotateParams
     int B;
 };
 
@@ -87,6 +92,7 @@ struct BlindRotateNttMb2Params {
     const double *mono;       // [2 primes][4096] psi_q^k centred
     uint64_t *out;
     uint64_t *const *out_ptrs;
+    uint64_t *const *body_ptrs;   // see BlindRotateParams
     int B;
 };
 
@@ -128,5 +134,16 @@ hipError_t launch_modswitch(const uint64_t *d_ks, uint32_t *d_ms /*[B][743]*/, i
 hipError_t launch_lincomb(const LinDesc *d_desc, const LinTerm *d_terms, uint64_t *d_out /*[n][2049]*/,
                           int n, hipStream_t s);
 hipError_t launch_scatter_blocks(const uint64_t *d_in, uint64_t *const *d_dst, int n, hipStream_t s);
+// Rotation sharing: one more sample extraction of a finished blind rotation.  `lead` = the output LWE of that rotation
+// (its mask IS the accumulator's mask polynomial in extract-at-0 order), `body` = the accumulator's body polynomial
+// (body_ptrs of the blind-rotation kernels), K in [0, 4096) = negacyclic coefficient index to extract: out = what a
+// bootstrap of (input + (K / 128) * Delta) with the same look-up table yields.
+struct ExtractDesc {
+    const uint64_t *lead;
+    const uint64_t *body;
+    uint64_t *out;
+    uint32_t K, pad;
+};
+hipError_t launch_extract_shift(const ExtractDesc *d_desc, int n, hipStream_t s);
 
 }  // namespace fhs

@@ -160,8 +160,13 @@ __global__ __launch_bounds__(256, 2) void blind_rotate_kernel(BlindRotateParams 
             if (n == 0) out[0] = acc[o];
             else out[POLY_N - n] = (uint64_t)0 - acc[o];
         }
-    } else if (q == 0 && lane == 0) {
-        out[BIG_N] = acc[0];
+    } else {
+        if (q == 0 && lane == 0) out[BIG_N] = acc[0];
+        uint64_t *body = P.body_ptrs ? P.body_ptrs[ct] : nullptr;      // rotation sharing: the whole body polynomial
+        if (body) {
+#pragma unroll
+            for (int o = 0; o < 16; o++) body[lane + 64 * (2 * o + q)] = acc[o];
+        }
     }
 }
 
@@ -234,6 +239,28 @@ __global__ __launch_bounds__(256) void scatter_blocks_kernel(const uint64_t *__r
 hipError_t launch_scatter_blocks(const uint64_t *d_in, uint64_t *const *d_dst, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(scatter_blocks_kernel, dim3(n), dim3(256), 0, s, d_in, d_dst);
+    return hipGetLastError();
+}
+
+// Rotation sharing: sample extraction of negacyclic coefficient K (index in [0, 2N)) of a finished blind rotation whose
+// coefficient-0 extraction E = desc.lead is in memory (E[0] = A[0], E[j] = -A[N-j]: the mask polynomial A, rearranged) and
+// whose body polynomial B = desc.body was stored by the blind-rotation kernel (body_ptrs).  With h = K mod N:
+//     a_i = A[h-i] (i <= h), -A[N+h-i] (i > h)   =   E[i-h] (i >= h), -E[N-h+i] (i < h);      b = B[h];
+// K >= N negates the whole LWE (X^N = -1).  Exact integer moves: the result equals oracle/tfhe_oracle.c orc_pbs_shifted
+// bit for bit.  One workgroup per extraction, 16 KB in, 16 KB out.
+__global__ __launch_bounds__(256) void extract_shift_kernel(const ExtractDesc *__restrict__ desc) {
+    const ExtractDesc d = desc[blockIdx.x];
+    const uint32_t h = d.K & (POLY_N - 1);
+    const uint64_t neg = d.K >= (uint32_t)POLY_N ? ~(uint64_t)0 : 0;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)POLY_N; i += 256) {
+        const uint64_t v = i >= h ? d.lead[i - h] : (uint64_t)0 - d.lead[POLY_N - h + i];
+        d.out[i] = (v ^ neg) - neg;
+    }
+    if (threadIdx.x == 0) d.out[BIG_N] = (d.body[h] ^ neg) - neg;
+}
+hipError_t launch_extract_shift(const ExtractDesc *d_desc, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(extract_shift_kernel, dim3(n), dim3(256), 0, s, d_desc);
     return hipGetLastError();
 }
 

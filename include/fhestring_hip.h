@@ -109,6 +109,17 @@ int fhs_pbs_batch(fhs_ctx *ctx, const uint64_t *in, const uint32_t *lut_idx, con
                   size_t n_luts, uint64_t *out, size_t B);
 /* keyswitch + modulus switch only: ms_out[B][743] values in [0,4096) */
 int fhs_keyswitch_modswitch_batch(fhs_ctx *ctx, const uint64_t *in, uint32_t *ms_out, size_t B);
+/* Rotation sharing at the raw boundary: ONE keyswitch + blind rotation per input and n_shifts sample extractions of its
+ * accumulator: out[b][s] ([B][n_shifts][2049]) is what a bootstrap of (in[b] + shifts[b][s] * 2^59) with the same table
+ * yields (shifts in message units, 0..31; 0 = fhs_pbs_batch's output): adding c * 2^59 to a body moves the modulus-switched
+ * body by exactly 128 c, i.e. rotates the accumulator by X^(128 c), so coefficient 128 c of ONE accumulator is the other
+ * bootstrap's coefficient 0.  The string layer gets this automatically: rows of one dependency level that apply the same
+ * table to the same linear combination up to its trivial constant -- the nibble of a character tested against the nibbles
+ * of a clear pattern, is0(x - c) -- share a rotation (fhs_set_rotation_sharing, on by default in fused mode;
+ * fhs_stats.pbs_extracted counts them).  shortint::ServerKey::apply_lookup_table per shifted input, batched. */
+int fhs_pbs_batch_shifted(fhs_ctx *ctx, const uint64_t *in, const uint32_t *lut_idx, const uint64_t *luts, size_t n_luts,
+                          const uint32_t *shifts /*[B][n_shifts]*/, size_t n_shifts, uint64_t *out, size_t B);
+int fhs_set_rotation_sharing(fhs_ctx *ctx, int on);
 /* Kernel-level tests: blind rotation + sample extraction only, in the selected arithmetic, from GIVEN keyswitched LWEs
  * ks[B][743] (u64 torus; the kernels apply the modulus switch to 2N = 4096 themselves) -> out[B][2049]. */
 int fhs_debug_blind_rotate_batch(fhs_ctx *ctx, const uint64_t *ks, const uint32_t *lut_idx, const uint64_t *luts,
@@ -353,6 +364,8 @@ typedef struct {
     uint64_t pbs_shared;       /* fused mode: PBS not run because an identical one (same LUT on the same linear combination
                                 * of the same blocks) already exists -- e.g. the high-nibble tests of one character
                                 * against pattern characters that share their high nibble */
+    uint64_t pbs_extracted;    /* results obtained as a further sample extraction of ANOTHER row's blind rotation (rotation
+                                * sharing: same table, same combination up to its trivial constant); not in pbs_executed */
 } fhs_stats;
 /* Design rule of the fused DAGs: with a measured bootstrap-output sigma of 2^48.9 a sum with
  * sum c^2 <= 64 adds sigma <= 2^51.9 to the 2^55.2 of keyswitch + modulus switch (+0.8 %): the reference parameter

@@ -20,7 +20,11 @@ def _reject_constant(name):
 def _parse_line(stdout, gloo_noise=False):
     """exactly one stdout line, strict JSON (no NaN / Infinity), far below the driver's 8 KB.  (The gloo rehearsals with
     several ranks on one GPU: libgloo itself prints "[Gloo] Rank ..." lines to stdout; the nccl run has none.)"""
-    lines = [l for l in stdout.splitlines() if l.strip() and not (gloo_noise and l.startswith("[Gloo]"))]
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    if gloo_noise:                       # (the ranks' "[Gloo]" lines interleave: keep what looks like the JSON line)
+        noise = [l for l in lines if not l.lstrip().startswith("{")]
+        assert all("Gloo" in l or "peer ranks" in l for l in noise), noise
+        lines = [l for l in lines if l.lstrip().startswith("{")]
     assert len(lines) == 1, lines
     assert len(lines[0].encode()) < LINE_CAP, len(lines[0])
     return json.loads(lines[0], parse_constant=_reject_constant)
@@ -144,7 +148,7 @@ def test_bench_json_line_contract(tmp_path):
     assert sw["64"]["ms_per_op"] < sw["4096"]["ms_per_op"] and sw["4096"]["pbs_per_s"] > 3 * sw["64"]["pbs_per_s"]
     assert all(sw[k]["levels"] <= 12 and sw[k]["found"] == 1 for k in ("64", "256", "1024", "4096"))
     assert 0.8 * d["value"] < d["value_median_protocol"] < 1.2 * d["value"]
-    assert abs(d["value_median_protocol"] * d["median_ms_per_step"] * 1e-3 - d["pbs_per_op"] * 8) < 1.0
+    assert abs(d["value_median_protocol"] * d["median_ms_per_step"] * 1e-3 - d["pbs_per_op"] * 16) < 1.0        # 16 strings per step
     assert r["counters_stale"] is False and set(r["counters"]) >= {"source_rev"}
     ksr = r["keyswitch"]                                     # the matrix-core kernel of a launch group, timed live
     assert ksr["bound"] == "mfma" and 0.05 < ksr["frac"] < 1.0 and ksr["share_of_step_time"] < 0.03

@@ -77,3 +77,26 @@ def test_keyswitch_reproduces_the_known_answers(ctx, kat, material):
     assert [hashlib.sha256(np.ascontiguousarray(g, "<u4").tobytes()).hexdigest() for g in got] == kat["keyswitch_modswitch"]
     wide = ctx.keyswitch_modswitch_batch(np.concatenate([cts] * 9))  # 288 rows: the LDS-ring MFMA kernel
     assert [hashlib.sha256(np.ascontiguousarray(g, "<u4").tobytes()).hexdigest() for g in wide] == kat["keyswitch_modswitch"] * 9
+
+
+@pytest.mark.parametrize("name,arith,fft4_max", [("shifted_exact", "ARITH_EXACT_NTT", None),
+                                                 ("shifted_f64_fft_mirror", "ARITH_F64_FFT", 1 << 30),
+                                                 ("shifted_f64_fft_mirror", "ARITH_F64_FFT", 0)],
+                         ids=["exact_ntt", "f64_fft_4wavefront", "f64_fft_2wavefront"])
+def test_shifted_extractions_reproduce_the_known_answers(ctx, kat, material, name, arith, fft4_max):
+    """Rotation sharing (fhs_pbs_batch_shifted: body polynomial stored by the blind-rotation kernel + extract_shift_kernel)
+    against the frozen digests of orc_pbs_shifted -- schoolbook ground truth for the exact kernel."""
+    _, cts, luts, _, _ = material
+    rec = kat[name]
+    rows = np.stack([cts[m] for m in rec["inputs"]])
+    shifts = np.tile(np.array(rec["shifts"], np.uint32), (len(rows), 1))
+    ctx.set_arithmetic(getattr(ctx, arith))
+    if fft4_max is not None:
+        ctx.set_fft4_max_batch(fft4_max)
+    try:
+        got = ctx.pbs_batch_shifted(rows, np.zeros(len(rows), np.uint32), luts, shifts)
+    finally:
+        ctx.set_fft4_max_batch(512)
+        ctx.set_arithmetic(ctx.ARITH_EXACT_NTT)
+    for b, want in enumerate(rec["outputs"]):
+        assert [gen_kat.sha(o) for o in got[b]] == [w["sha256"] for w in want], rec["inputs"][b]

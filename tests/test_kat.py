@@ -78,3 +78,16 @@ def test_oracle_mirrors_equal_their_frozen_digests(kat, material, mode, name):
     out = S.pbs_batch(rows, idx, luts, mode=mode)
     assert _match(out, kat[name]["outputs"]) == []
     assert [K.decrypt_block(o) for o in out] == kat["exact"]["decrypts_to"]
+
+
+@pytest.mark.parametrize("mode,name", [(0, "shifted_exact"), (3, "shifted_f64_fft_mirror")])
+def test_oracle_shifted_extractions_equal_their_known_answers(kat, material, mode, name):
+    """Rotation sharing: ONE blind rotation, several sample extractions (orc_pbs_shifted) -- the exact NTT against the
+    SCHOOLBOOK digests, the f64 mirror against its frozen ones."""
+    from oracle import core
+    K, cts, luts, _, _ = material
+    S = core.ServerKey(K)
+    rec = kat[name]
+    assert rec["inputs"] == gen_kat.SHIFT_INPUTS and rec["shifts"] == gen_kat.SHIFT_LIST
+    for m, want in zip(rec["inputs"], rec["outputs"]):
+        assert _match(S.pbs_shifted(cts[m], luts[0], rec["shifts"], mode=mode), want) == [], m

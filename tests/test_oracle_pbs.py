@@ -227,3 +227,37 @@ def test_config1_eq_hello_hello_on_the_cpu_oracle(oracle_keys, oracle_sk):
     a, b = enc_s("hello", 1), enc_s("hello", 1)
     assert dec_c(ops.eq(a, b)) == 1
     assert eng.pbs_count > 100 and eng.levels >= 10
+
+
+def test_shifted_extraction_is_the_bootstrap_of_the_shifted_input(oracle_keys, oracle_sk):
+    """orc_pbs_shifted (the oracle of the product's rotation sharing): ONE blind rotation, one sample extraction per shift
+    t = what a bootstrap of (ct + t * Delta) yields -- adding t * 2^59 to the body moves the modulus-switched body by exactly
+    128 t, i.e. rotates the accumulator by X^(128 t).  Checked three ways: every one of the 32 shifts decrypts to
+    f(m + t) under the negacyclic rule; shift 0 IS orc_pbs, word for word; and in exact arithmetic the extraction equals
+    the separate bootstrap of the shifted ciphertext bit for bit except where a decomposition rounding tie falls the
+    other way (monomial multiplication commutes with everything else), so most rows agree on every word."""
+    lut = radix.lut_poly("eq_c0")                       # [v == 0]: the nibble-equality test of a clear pattern
+    same = total = 0
+    for m in (0, 3, 9, 15, 22):
+        ct = oracle_keys.encrypt_block(m)
+        out = oracle_sk.pbs_shifted(ct, lut, list(range(32)))
+        assert [oracle_keys.decrypt_block(o) for o in out] == [radix.lut_eval("eq_c0", (m + t) & 31) for t in range(32)]
+        assert np.array_equal(out[0], oracle_sk.pbs(ct, lut))
+        if m == 9:
+            assert np.array_equal(out, oracle_sk.pbs_shifted(ct, lut, list(range(32)), mode=1))  # NTT == schoolbook
+        for t in (1, 7, 16, 27):
+            shifted = ct.copy()
+            shifted[-1] = np.uint64((int(shifted[-1]) + (t << core.DELTA_LOG)) & (2**64 - 1))
+            ref = oracle_sk.pbs(shifted, lut)
+            assert oracle_keys.decrypt_block(ref) == oracle_keys.decrypt_block(out[t])
+            e = (oracle_keys.phase(ref) - oracle_keys.phase(out[t])) & (2**64 - 1)
+            assert min(e, 2**64 - e) < 2**52             # the same ciphertext up to rounding ties
+            same += int(np.array_equal(ref, out[t]))
+            total += 1
+    assert same >= total // 2, (same, total)
+    # the approximate arithmetics extract from their own accumulators the same way
+    ct = oracle_keys.encrypt_block(6)
+    for mode in (3, 6):
+        out = oracle_sk.pbs_shifted(ct, lut, [0, 26, 5], mode=mode)
+        assert [oracle_keys.decrypt_block(o) for o in out] == [0, 1, 0]
+        assert np.array_equal(out[0], oracle_sk.pbs(ct, lut, mode=mode))

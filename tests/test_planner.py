@@ -60,10 +60,21 @@ def test_config_dag_shapes(sk):
         assert st["max_input_sum_c2"] <= BUDGET, st
         return st, sk.level_widths()
     s65, s257, p4 = sk.dummy_string(65), sk.dummy_string(257), sk.dummy_string(4)
+    sk.ctx.set_rotation_sharing(False)
     st, w = run(lambda: sk.contains_clear(s65, "a2S$"))               # no two pattern characters share a nibble
-    assert (st["pbs_executed"], st["levels"]) == (564, 4) and w == [496, 62, 5, 1]
+    assert (st["pbs_executed"], st["levels"]) == (564, 4) and w == [496, 62, 5, 1] and st["pbs_extracted"] == 0
     st, w = run(lambda: sk.contains_clear(s65, "abcd"))               # one shared high nibble: tested once per position
     assert st["pbs_executed"] + st["pbs_shared"] == 564 and w == [313, 62, 5, 1]
+    # rotation sharing (round 5): the tests of ONE nibble against the pattern's nibbles -- is0(x - c), the same table on
+    # the same ciphertext up to a trivial constant -- are sample extractions of one blind rotation: 130 rotations (65
+    # characters x 2 nibbles) whatever the pattern, every other flag of the first level is extracted
+    sk.ctx.set_rotation_sharing(True)
+    st, w = run(lambda: sk.contains_clear(s65, "a2S$"))
+    assert (st["pbs_executed"], st["pbs_extracted"], st["levels"]) == (198, 366, 4) and w == [130, 62, 5, 1]
+    st, w = run(lambda: sk.contains_clear(s65, "abcd"))
+    assert (st["pbs_executed"], st["pbs_extracted"]) == (198, 183) and st["pbs_shared"] == 183 and w == [130, 62, 5, 1]
+    st, w = run(lambda: sk.find_clear(s257, "a2S$"))                   # 2 574 without sharing: 257 x 2 rotations for 2 032 flags
+    assert (st["pbs_executed"], st["pbs_extracted"], st["levels"]) == (1056, 1518, 6) and w[0] == 514
     sk.set_auto_flush(0)                                             # whole DAGs: no levels peeled while recording
     # the fused DAGs of configs 3-5 as they are now (round 2: thermometer index for find, one bootstrap per block and
     # stage in the compaction, tail tests instead of popcounts in eq / comparisons, eq_ignore_case on the pair): a
@@ -117,8 +128,10 @@ def test_split_beyond_u8_buffer_index_plans(sk):
 
 def test_level_skewed_batching_schedule(sk):
     """fhs_submit / fhs_pump: one submit + one pump per request puts level l of request k into the launch group of
-    request k + l - 1 (4 requests of a 64-char contains: widths 496 / 62 / 5 / 1 each)."""
+    request k + l - 1 (4 requests of a 64-char contains: widths 496 / 62 / 5 / 1 each; rotation sharing off: this
+    test is about the schedule, the shared variant follows at the end)."""
     sk.set_mode(1)
+    sk.ctx.set_rotation_sharing(False)
     strings = [sk.dummy_string(65) for _ in range(4)]
     sk.stats(reset=True)
     keep = []
@@ -139,6 +152,20 @@ def test_level_skewed_batching_schedule(sk):
     sk.submit()
     sk.flush()
     assert sk.level_widths() == [496, 62, 5, 1, 1]
+    # with rotation sharing every request's first level is 130 rotations (one per nibble) + 366 sample extractions that
+    # travel with their leaders' tick; the schedule is the same
+    del keep, a, b
+    sk.ctx.set_rotation_sharing(True)
+    sk.stats(reset=True)
+    keep = []
+    for s in strings:
+        keep.append(sk.contains_clear(s, "a2S$"))
+        sk.submit()
+        sk.pump(1)
+    sk.flush()
+    st = sk.stats()
+    assert sk.level_widths()[:10] == [130, 62, 130, 5, 62, 130, 1, 5, 62, 130]
+    assert (st["pbs_executed"], st["pbs_extracted"], st["levels"]) == (4 * 198, 4 * 366, 16)
 
 
 def test_automatic_partial_flush_plans_the_same_bootstraps(sk):
@@ -170,6 +197,7 @@ def test_round_aligned_launch_groups(sk):
     the excess of a step's first level runs one tick later together with everything that consumes it.  A group that
     fills 95 % of its rounds anyway is left alone (8 strings: 4 512 = 8.8 rounds).  Nothing is lost or duplicated."""
     sk.set_mode(1)
+    sk.ctx.set_rotation_sharing(False)       # 564 rotations per contains: the round arithmetic below is about those
     slots = sk.set_tick_balance()
     assert slots == 512
 

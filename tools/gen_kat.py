@@ -27,6 +27,8 @@ sys.path.insert(0, ROOT)
 SEED = 0xF5E57121
 LUT_NAMES = ("msg", "eq_biv", "sign")
 OUT = os.path.join(ROOT, "tests", "golden", "pbs_kat.json")
+SHIFT_INPUTS = [0, 5, 9, 15, 22, 31]          # block values whose ciphertexts (kat_inputs) are bootstrapped once each ...
+SHIFT_LIST = [0, 1, 7, 16, 27, 31]            # ... and extracted at these shifts (message units)
 
 
 def sha(a):
@@ -77,6 +79,17 @@ def main():
         out = S.pbs_batch(rows, idx, luts, nt, mode=mode)
         assert [K.decrypt_block(o) for o in out] == want, name
         rec[name] = {"source": what, "outputs": digests(out)}
+    # rotation sharing: ONE blind rotation, several sample extractions (orc_pbs_shifted; the product's
+    # fhs_pbs_batch_shifted and the engine's shared rows) -- schoolbook ground truth, and the f64 mirror's digests
+    sh_rows, sh_shifts = SHIFT_INPUTS, SHIFT_LIST
+    for mode, name in ((1, "shifted_exact"), (3, "shifted_f64_fft_mirror")):
+        outs = [S.pbs_shifted(cts[m], luts[0], sh_shifts, mode=mode) for m in sh_rows]
+        for m, o in zip(sh_rows, outs):
+            assert [K.decrypt_block(x) for x in o] == [radix.lut_eval("msg", (m + t) & 31) for t in sh_shifts], (name, m)
+        if mode == 1:
+            assert all(np.array_equal(o, S.pbs_shifted(cts[m], luts[0], sh_shifts, mode=0)) for m, o in zip(sh_rows, outs))
+        rec[name] = {"lut": "msg", "inputs": sh_rows, "shifts": sh_shifts,
+                     "outputs": [digests(o) for o in outs]}
     with open(OUT, "w") as f:
         json.dump(rec, f, indent=0, separators=(",", ":"))
         f.write("\n")
