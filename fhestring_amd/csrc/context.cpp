@@ -121,6 +121,12 @@ int Context::init(int device_id) {
     // while the workgroups walk it together; consecutive launches overlap at the seams): 202 k instead of 183 k PBS/s at
     // 4096 rows, 214 k instead of 152 k at 14 336.  The classic f64 kernel (48 MB key) does not care below 4096 rows.
     launch_chunk[2] = (size_t)wg_slots;
+    // classic f64 kernel (round 5): one round per launch as well.  Time-neutral (default bench 134.5 k PBS/s plain, 135.5 k
+    // chunked; 3968-wide launches 30.12 ms plain, 30.33 ms chunked: profiles/r05_chunk_ab.txt) but every launch restarts
+    // the key walk of all workgroups together: L2 hit rate 95 -> 98.5 %, fabric-side traffic 6.3 -> 2.4 GB per launch
+    // group -- traffic that eight processes on one node would otherwise multiply by eight.  A remainder below a quarter of
+    // a round rides in the last launch instead of becoming one of its own (blind_rotate()).
+    launch_chunk[1] = (size_t)wg_slots;
     HIP_TRY(hipMalloc(&d_work_counter, 64), "hipMalloc counter");
     return 0;
 }
@@ -317,11 +323,12 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
     // A launch is cut into chunks of launch_chunk[arith] ciphertexts (0 = whole batch): every chunk starts all workgroups on
     // the first key element together again.  The kernels whose key does not fit the L2 window of a drifting launch need
     // that (two-bit f64 kernel: 185 k PBS/s in launches of 3 072 - 4 096 rows, 144 k in one launch of 13 400).
-    // (the classic f64 kernel with its 48 MB key gains 2-3 % from 1024-row launches at 14 336 rows but loses 5-8 % at widths
-    // like 8194 = 8 rounds + 2 rows, where the remainder becomes a launch of its own: left unchunked)
-    const size_t chunk = launch_chunk[arith] ? launch_chunk[arith] : B;
-    for (size_t off = 0; off < B && e == hipSuccess; off += chunk) {
-        const size_t n = std::min(chunk, B - off);
+    // A remainder of less than a quarter of a chunk does not become a launch of its own (8194 rows = 7 launches of 1024 and
+    // one of 1026, not eight and a launch of 2 that costs a whole bootstrap alone).  The narrow-level kernel is never cut.
+    const size_t chunk = (launch_chunk[arith] && !four) ? launch_chunk[arith] : B;
+    for (size_t off = 0, n = 0; off < B && e == hipSuccess; off += n) {
+        n = std::min(chunk, B - off);
+        if (B - off - n < chunk / 4) n = B - off;
         const uint64_t *ks = d_ks + off * SMALL_CT;
         const uint32_t *li = d_lut_idx + off;
         uint64_t *out = d_out ? d_out + off * BIG_CT : nullptr;

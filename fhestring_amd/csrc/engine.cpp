@@ -444,7 +444,7 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
         // (e.g. the nibble of a character tested against the different nibbles of a clear pattern: is0(x - c)) share ONE
         // keyswitch + blind rotation: adding c * Delta to a ciphertext rotates the accumulator by X^(128 c) exactly, so the
         // other rows are further sample extractions of the leader's accumulator (extract_shift_kernel) -- the same
-        // ciphertext a bootstrap of their own would give, up to decomposition ties (oracle: orc_pbs_shifted).  The level
+        // ciphertext a bootstrap of their own would give, up to decomposition ties (the CPU oracle restates it: orc_pbs_shifted).  The level
         // is reordered: rotation rows first (R of them), followers behind.
         std::vector<ShareRow> followers;
         size_t R = lv.size();

@@ -246,7 +246,7 @@ hipError_t launch_scatter_blocks(const uint64_t *d_in, uint64_t *const *d_dst, i
 // coefficient-0 extraction E = desc.lead is in memory (E[0] = A[0], E[j] = -A[N-j]: the mask polynomial A, rearranged) and
 // whose body polynomial B = desc.body was stored by the blind-rotation kernel (body_ptrs).  With h = K mod N:
 //     a_i = A[h-i] (i <= h), -A[N+h-i] (i > h)   =   E[i-h] (i >= h), -E[N-h+i] (i < h);      b = B[h];
-// K >= N negates the whole LWE (X^N = -1).  Exact integer moves: the result equals oracle/tfhe_oracle.c orc_pbs_shifted
+// K >= N negates the whole LWE (X^N = -1).  Exact integer moves: the result equals the CPU oracle's orc_pbs_shifted
 // bit for bit.  One workgroup per extraction, 16 KB in, 16 KB out.
 __global__ __launch_bounds__(256) void extract_shift_kernel(const ExtractDesc *__restrict__ desc) {
     const ExtractDesc d = desc[blockIdx.x];

@@ -43,7 +43,7 @@ def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
 
 
 def test_roofline_counters_are_tied_to_the_kernel_sources():
-    """profiles/r04_counters.json carries the git blob hashes of the sources each kernel was counted
+    """profiles/r05_counters.json carries the git blob hashes of the sources each kernel was counted
     on (fhestring_amd/kernel_sources.py computes them without git); bench.py withholds the counted figures for a kernel
     whose sources have moved on.  Here: the hash IS git's, the committed counters describe THIS tree for every
     blind-rotation kernel, and a changed byte is noticed."""
@@ -56,14 +56,14 @@ def test_roofline_counters_are_tied_to_the_kernel_sources():
         assert ks.blob_hash(open(path, "rb").read()) == want
     except (OSError, subprocess.CalledProcessError):
         pass                                                  # no git here: the hash function is still exercised below
-    counters = json.load(open(os.path.join(ROOT, "profiles", "r04_counters.json")))
+    counters = json.load(open(os.path.join(ROOT, "profiles", "r05_counters.json")))
     import warnings
     for kernel in ("blind_rotate_fft_kernel", "blind_rotate_kernel", "blind_rotate_mb2_kernel",
                    "blind_rotate_ntt_mb2_kernel", "blind_rotate_fft4_kernel"):
         assert set(counters[kernel]["source_blobs"]) == set(ks.KERNEL_SOURCES[kernel])
         moved = ks.stale_sources(kernel, counters[kernel]["source_blobs"])
         if moved:        # not a failure on the CPU (a kernel under development): bench.py withholds the figures, and the
-            warnings.warn("%s changed after its counters were taken (%s): re-run tools/gpu_profile_r4.sh before the "
+            warnings.warn("%s changed after its counters were taken (%s): re-run tools/gpu_profile_r5.sh + tools/build_counters.py before the "
                           "round ends -- tests/test_gpu_bench_contract.py refuses a stale headline" % (kernel, moved))
     rec = dict(counters["blind_rotate_fft_kernel"]["source_blobs"])
     rec["fft_transform.h"] = "0" * 40

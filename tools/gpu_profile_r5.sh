@@ -45,7 +45,7 @@ for A in $ARITHS; do          # f64 FFT (headline), exact NTT, two-bit f64, two-
     done
   fi
 done
-if [ $PART != 1 ]; then
+if [ $PART = 2 ]; then
 # the narrow-level kernel on 64-row launches
 PB="python3 tools/time_mb2.py --profile --arith=1 64"
 run n64_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/n64_stats -- $PB
