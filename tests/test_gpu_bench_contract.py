@@ -60,7 +60,7 @@ def _check_roofline(r, may_be_stale=True):
         return
     # the bounding resource is the FP64 vector unit (SQ counters, profiles/r02_*): a fraction of a peak, never above 1
     assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
-    assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6      # (the sidecar keeps 9 digits)
     assert r["counters"]["fp64_flop_per_pbs"] > 1e8          # measured flop count, not a static estimate
     h = r["hbm"]
     assert h["compulsory_frac_of_peak"] < 0.05 and "NOT the bound" in h["note"]

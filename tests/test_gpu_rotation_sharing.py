@@ -107,3 +107,34 @@ def test_string_ops_share_rotations_and_decrypt_alike(oracle_keys):
     assert res[True][2] + res[True][3] == res[False][2]                          # the same results, obtained two ways
     assert res[True][4] <= 64 and res[False][4] <= 64
     sk.close()
+
+
+def test_extracted_outputs_are_as_noisy_as_bootstrap_outputs_and_uncorrelated(ctx, oracle_keys):
+    """What the noise bookkeeping assumes about shared rotations, measured: the phase error of an
+    extraction at any shift has the sigma of an ordinary bootstrap output (2^48.9 in f64-FFT arithmetic), and the errors
+    of two extractions of the SAME accumulator are uncorrelated (different coefficients of the accumulator are different
+    inner products of the same independent key-noise terms), so sum c^2 over extractions counts like independent outputs."""
+    from noise_util import big_phase, centred
+    from oracle import radix
+    B, shifts = 768, [0, 5, 16, 27]
+    rng = np.random.default_rng(77)
+    msgs = rng.integers(0, 16, B)
+    cts = np.stack([oracle_keys.encrypt_block(int(m)) for m in msgs])
+    luts = radix.lut_poly("msg")[None]
+    ctx.set_arithmetic(ctx.ARITH_F64_FFT)
+    try:
+        got = ctx.pbs_batch_shifted(cts, np.zeros(B, np.uint32), luts, np.tile(np.array(shifts, np.uint32), (B, 1)))
+    finally:
+        ctx.set_arithmetic(ctx.ARITH_EXACT_NTT)
+    err = np.zeros((len(shifts), B))
+    for k, t in enumerate(shifts):
+        want = np.array([radix.lut_eval("msg", (int(m) + t) & 31) for m in msgs], np.uint64)
+        ph = big_phase(got[:, k, :], np.asarray(oracle_keys.glwe_sk, np.uint64))
+        e = centred(ph - (want << np.uint64(59)), 64)
+        assert np.abs(e).max() < 2**53, (t, np.abs(e).max())                 # every row decrypts, with margin
+        err[k] = e.astype(np.float64)
+    sig = np.log2(err.std(axis=1))
+    assert np.all(np.abs(sig - 48.9) < 0.35), sig                             # one bootstrap output's sigma, every shift
+    rho = np.corrcoef(err)
+    off = np.abs(rho - np.eye(len(shifts))).max()
+    assert off < 0.15, rho                                                     # 768 samples: |rho| of independent data < 0.12 (3.3 sigma)
