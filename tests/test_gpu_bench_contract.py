@@ -205,7 +205,8 @@ def test_bench_four_ranks_on_one_gpu(extra):
     ex = d["config"]["exchange"]
     assert ex["transport"] == "host" and ex["allgather_calls_per_step"] > 0
     if extra:
-        assert ex["allgather_calls_per_step"] == 1 and ex["bytes_sent_per_rank_per_step"] == 64 * 2049 * 8
+        assert ex["allgather_calls_per_step"] == 1                     # (the compact line keeps 6 significant digits)
+        assert abs(ex["bytes_sent_per_rank_per_step"] - 64 * 2049 * 8) < 16
         assert "64 window flag(s)" in d["config"]["parallelism"]
 
 
