@@ -5,7 +5,7 @@ O=gpurun_out/suite
 mkdir -p $O
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q --durations=40 > $O/gputests.log 2>&1; echo "gputests rc=$?" | tee -a $O/status.txt
+timeout -k 10 1000 python3 -m pytest tests -m gpu -q --durations=40 > $O/gputests.log 2>&1; echo "gputests rc=$?" | tee -a $O/status.txt
 timeout -k 10 600 python3 bench.py --extras-out $O/bench_extras.json > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" | tee -a $O/status.txt
 tail -5 $O/gputests.log; python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/status.txt; python3 - <<'PY'
 import json
