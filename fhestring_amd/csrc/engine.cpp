@@ -1,4 +1,5 @@
 #include "engine.h"
+#include "../../include/fhestring_hip.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -281,8 +282,35 @@ int64_t Engine::sum_c2(Bid b) const {
     if (n.kind == BlockNode::TRIV) return 0;
     if (n.kind == BlockNode::MAT) return n.var;
     if (n.kind != BlockNode::LIN) return 1;
+    return lin_c2(n.terms);
+}
+
+int64_t Engine::lin_c2(const std::vector<Term> &terms) const {
+    // var(sum c_i e_i) = sum c_i^2 var_i + 2 rho sum_{i<j} c_i c_j sqrt(var_i var_j) over extractions of ONE rotation, with
+    // 0 <= rho <= ROT_CORR = 1/4 (measured 0.17 on the MI355X, tests/test_gpu_rotation_sharing.py): same-sign sums are
+    // charged the cross terms, mixed-sign sums (whose true variance is LOWER) are charged as if independent.
     int64_t c2 = 0;
-    for (const Term &t : n.terms) c2 += t.coef * t.coef * term_var(t.blk);
+    struct Grp { uint32_t rot; int64_t sum_c, sum_c2, var; };
+    Grp grp[8];
+    int ng = 0;
+    for (const Term &t : terms) {
+        const BlockNode &tb = nodes_[t.blk];
+        const int64_t var = tb.kind == BlockNode::MAT ? tb.var : 1;
+        if (tb.kind != BlockNode::MAT || tb.rot == 0) { c2 += t.coef * t.coef * var; continue; }
+        int g = 0;
+        while (g < ng && grp[g].rot != tb.rot) g++;
+        if (g == ng) {
+            if (ng == 8) { c2 += t.coef * t.coef * var; continue; }       // (more than 8 shared rotations in one sum: unseen)
+            grp[ng++] = Grp{tb.rot, 0, 0, 0};
+        }
+        grp[g].sum_c += t.coef;
+        grp[g].sum_c2 += t.coef * t.coef;
+        grp[g].var = std::max(grp[g].var, var);
+    }
+    for (int g = 0; g < ng; g++) {
+        const int64_t cross = grp[g].sum_c * grp[g].sum_c - grp[g].sum_c2;      // 2 sum_{i<j} c_i c_j
+        c2 += (grp[g].sum_c2 + (cross > 0 ? (cross + 3) / 4 : 0)) * grp[g].var;
+    }
     return c2;
 }
 
@@ -500,6 +528,9 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                     int kb = 0;
                     key_terms(nodes_[ln.src], ln.src, tb, kb);
                     if (ln.lut != n.lut || ta != tb) continue;
+                    // a constant difference of 16 is the SAME coefficient of the accumulator, negated (X^2048 = -1): its
+                    // error is exactly minus the leader's, which no positive-correlation bound covers -- own rotation
+                    if ((((ka - kb) % 32 + 32) % 32) == 16) continue;
                     fol.push_back(b);
                     fmeta.push_back({pos, (uint32_t)(128 * (((ka - kb) % 32 + 32) % 32)), nullptr});
                     shared = true;
@@ -508,6 +539,66 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                 if (!shared) {
                     cand.push_back((uint32_t)rot.size());
                     rot.push_back(b);
+                }
+            }
+            if (!fol.empty()) {
+                // Sharing must not push a CONSUMER over the noise budget: extractions of one rotation are positively
+                // correlated (lin_c2), so a later bootstrap whose input sums several members of one group with the same
+                // sign is charged cross terms the string layer did not see when it built that sum.  Every pending consumer
+                // is known here (deeper levels of this plan; in a partial peel the nodes still pending) -- consumers recorded
+                // later see the groups through sum_c2().  A follower whose group would take a consumer from within the
+                // budget to beyond it gets a rotation of its own.
+                std::unordered_map<Bid, uint32_t> member;              // node -> leader position (leaders with followers too)
+                for (size_t i = 0; i < fol.size(); i++) {
+                    member[fol[i]] = fmeta[i].lead_row;
+                    member[rot[fmeta[i].lead_row]] = fmeta[i].lead_row;
+                }
+                std::vector<char> unshare(fol.size(), 0);
+                bool any_unshare = false;
+                auto check = [&](Bid consumer) {
+                    const BlockNode &cn = nodes_[consumer];
+                    if (cn.kind != BlockNode::PBS) return;
+                    const BlockNode &src = nodes_[cn.src];
+                    if (src.kind != BlockNode::LIN || src.terms.size() < 2) return;
+                    struct G { uint32_t lead; int64_t sum_c, sum_c2; };
+                    G g[8];
+                    int ng = 0;
+                    bool multi = false;
+                    for (const Term &t : src.terms) {
+                        auto it = member.find(t.blk);
+                        if (it == member.end()) continue;
+                        int k = 0;
+                        while (k < ng && g[k].lead != it->second) k++;
+                        if (k == ng) { if (ng == 8) continue; g[ng++] = G{it->second, 0, 0}; }
+                        else multi = true;
+                        g[k].sum_c += t.coef;
+                        g[k].sum_c2 += t.coef * t.coef;
+                    }
+                    if (!multi) return;
+                    int64_t plain = lin_c2(src.terms), extra = 0;      // (members are still pending: counted as independent)
+                    for (int k = 0; k < ng; k++) {
+                        const int64_t cross = g[k].sum_c * g[k].sum_c - g[k].sum_c2;
+                        if (cross > 0) extra += (cross + 3) / 4;
+                    }
+                    if (plain + extra <= FHS_NOISE_BUDGET_SUM_C2 || extra == 0) return;
+                    for (const Term &t : src.terms)                    // the followers among this sum's terms leave their groups
+                        for (size_t i = 0; i < fol.size(); i++)
+                            if (fol[i] == t.blk && !unshare[i]) { unshare[i] = 1; any_unshare = true; }
+                };
+                for (auto nx = std::next(lvit); nx != by_level.end(); ++nx)
+                    for (Bid c : nx->second) check(c);
+                if (first_level_only)
+                    for (const Pend &pd : pending_)
+                        if (nodes_[pd.id].gen == pd.gen) check(pd.id);
+                if (any_unshare) {
+                    std::vector<Bid> fol2;
+                    std::vector<ShareRow> fmeta2;
+                    for (size_t i = 0; i < fol.size(); i++) {
+                        if (unshare[i]) rot.push_back(fol[i]);         // a rotation row of its own (appended: positions stay valid)
+                        else { fol2.push_back(fol[i]); fmeta2.push_back(fmeta[i]); }
+                    }
+                    fol.swap(fol2);
+                    fmeta.swap(fmeta2);
                 }
             }
             if (!fol.empty()) {
@@ -540,8 +631,8 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                         return ctx.fail(-3, "internal: lincomb term not materialised at its level");
                     tl.terms.push_back({tb.dev, t.coef});
                     need = std::max(need, tb.ready_tick);
-                    c2 += t.coef * t.coef * tb.var;
                 }
+                c2 = lin_c2(s.terms);                        // extractions of one shared rotation count as fully correlated
                 d.n_terms = (uint32_t)s.terms.size();
                 d.konst_body = (uint64_t)(s.konst & 31) << DELTA_LOG;
             } else {
@@ -576,11 +667,15 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
             std::vector<TickLevel> one;
             one.push_back(std::move(tl));
             if (int rc = run_tick(one, level_parallel && ctx.dist.active())) return rc;
+            std::vector<uint32_t> rot_of(followers.empty() ? 0 : R, 0);
+            for (const ShareRow &f : followers)
+                if (!rot_of[f.lead_row]) rot_of[f.lead_row] = ++rot_counter_ ? rot_counter_ : ++rot_counter_;
             for (size_t k = 0; k < lv.size(); k++) {
                 BlockNode &n = nodes_[lv[k]];
                 const Bid src = n.src;
                 n.kind = BlockNode::MAT;
                 n.dev = k < R ? one[0].out[k] : followers[k - R].out;
+                if (!followers.empty()) n.rot = rot_of[k < R ? k : followers[k - R].lead_row];
                 n.src = 0;
                 n.level = 0;
                 release(src);                                // immediate recycling is safe: stream order
@@ -631,11 +726,15 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
             for (size_t k = 0; k < R; k++) last = std::max(last, row_need[k]);
         }
         last_sched_tick_ = std::max(last_sched_tick_, last);  // before the releases below
+        std::vector<uint32_t> rot_of(tl.ext.empty() ? 0 : R, 0);
+        for (const ShareRow &f : tl.ext)
+            if (!rot_of[f.lead_row]) rot_of[f.lead_row] = ++rot_counter_ ? rot_counter_ : ++rot_counter_;
         for (size_t k = 0; k < lv.size(); k++) {
             BlockNode &n = nodes_[lv[k]];
             const Bid src = n.src;
             n.kind = BlockNode::MAT;
             n.dev = k < R ? tl.out[k] : tl.ext[k - R].out;
+            if (!tl.ext.empty()) n.rot = rot_of[k < R ? k : tl.ext[k - R].lead_row];
             n.src = 0;
             n.level = 0;
             n.ready_tick = k < R ? row_need[k] : row_need[tl.ext[k - R].lead_row];   // a follower is ready with its leader
@@ -957,7 +1056,7 @@ int Engine::plan_flush() {
             {   // noise bookkeeping: sum of squared coefficients of the (flattened) linear combination entering this
                 // bootstrap, i.e. its noise variance in units of one bootstrap output's (uploads counted like outputs)
                 int64_t c2 = 0;
-                if (s.kind == BlockNode::LIN) for (const Term &t : s.terms) c2 += t.coef * t.coef * term_var(t.blk);
+                if (s.kind == BlockNode::LIN) c2 = lin_c2(s.terms);
                 else c2 = s.var;
                 stats.max_input_sum_c2 = std::max<uint64_t>(stats.max_input_sum_c2, (uint64_t)c2);
                 if (c2 > 64 && std::getenv("FHS_DEBUG_C2")) {

@@ -36,6 +36,8 @@ struct BlockNode {
     uint32_t level = 0;      // PBS depth since the last flush
     uint32_t refs = 0;
     uint32_t gen = 0;        // bumped every time the slot is handed out again (common-subexpression table keys)
+    uint32_t rot = 0;        // MAT: rotation group (non-zero for the leader and the followers of ONE shared blind rotation):
+                             // their noises are correlated, the bookkeeping adds their coefficients before squaring
     uint64_t ready_tick = 0; // MAT produced by a scheduled (not yet enqueued) job level: the tick that writes it
     Bid src = 0;             // PBS: input block
     uint64_t *dev = nullptr; // MAT: device ciphertext (2049 u64)
@@ -80,6 +82,12 @@ class Engine {
     // sum of squared coefficients of a block as a combination of bootstrap outputs / uploads (its noise variance in
     // units of one bootstrap output's): 0 trivial, 1 materialised or pending bootstrap, sum c^2 for a linear combination
     int64_t sum_c2(Bid b) const;
+    // ... of a flattened combination.  The leader and the followers of one shared blind rotation are extractions of one
+    // accumulator: their errors are POSITIVELY correlated (measured rho = 0.17 between different coefficients: the
+    // decomposition-rounding term goes through the binary GLWE key, whose autocorrelation at a non-zero lag is half its
+    // zero-lag value), so a group contributes sum c^2 + ROT_CORR x max(0, (sum c)^2 - sum c^2) with ROT_CORR = 1/4
+    // (same-sign sums pay the cross terms; mixed-sign sums, whose true variance is lower, count as independent)
+    int64_t lin_c2(const std::vector<Term> &terms) const;
     int64_t term_var(Bid b) const { return nodes_[b].kind == BlockNode::MAT ? nodes_[b].var : 1; }   // of a flattened term
     int set_var(Bid b, uint64_t v, bool check_only = false);                         // MAT blocks only (fhs_char_set_noise)
 
@@ -203,6 +211,7 @@ class Engine {
     // stream_pump (scheduled path only): enqueue every tick as soon as no later level can add rows to it
     int plan_job(bool run_now, bool first_level_only = false, bool stream_pump = false);
     uint64_t job_counter_ = 0;
+    uint32_t rot_counter_ = 0;           // rotation groups handed out (BlockNode::rot)
     size_t n_depth1_ = 0;                // pending bootstraps whose inputs are all available
     size_t peel_limit_ = 0;              // automatic partial flush of an idle GPU: take this many ready rows (0 = all)
     hipEvent_t last_group_done_ = nullptr;   // recorded behind every launch group: tells whether the GPU has run dry
