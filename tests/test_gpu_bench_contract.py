@@ -236,7 +236,7 @@ def test_bench_keeps_the_headline_when_a_later_leg_fails_on_one_rank(fault):
     env = dict(os.environ, FHS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29573", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--cpu-pbs", "0", "--skip-secondary", "--skip-extras", "--repeats", "1", "--watchdog", "25",
+           "--cpu-pbs", "0", "--skip-secondary", "--skip-extras", "--repeats", "1", "--watchdog", "12",
            "--inject-fault", fault]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode != 0, out.stdout[-2000:]
