@@ -286,11 +286,14 @@ int64_t Engine::sum_c2(Bid b) const {
 }
 
 int64_t Engine::lin_c2(const std::vector<Term> &terms) const {
-    // var(sum c_i e_i) = sum c_i^2 var_i + 2 rho sum_{i<j} c_i c_j sqrt(var_i var_j) over extractions of ONE rotation, with
-    // 0 <= rho <= ROT_CORR = 1/4 (measured 0.17 on the MI355X, tests/test_gpu_rotation_sharing.py): same-sign sums are
-    // charged the cross terms, mixed-sign sums (whose true variance is LOWER) are charged as if independent.
+    // var(sum c_i e_i) = sum c_i^2 var_i + 2 sum_{i<j} rho_ij c_i c_j sqrt(var_i var_j) over extractions of ONE rotation.
+    // Measured on the MI355X (profiles/r05_rotation_sharing_rho.txt, tools/rho_profile.py): rho falls linearly with the
+    // constant difference dt from +0.45 (dt -> 0) through 0 (dt = 8) to -0.45 (dt = 15) -- the decomposition-rounding error
+    // reaches every coefficient through the negacyclic product with the binary GLWE key -- and is exactly -1 at dt = 16
+    // (the same coefficient negated: such rows never share).  |rho| <= ROT_CORR = 1/2 whatever the signs:
+    //     group cost = sum c^2 + 1/2 ((sum |c|)^2 - sum c^2).
     int64_t c2 = 0;
-    struct Grp { uint32_t rot; int64_t sum_c, sum_c2, var; };
+    struct Grp { uint32_t rot; int64_t sum_abs, sum_c2, var; };
     Grp grp[8];
     int ng = 0;
     for (const Term &t : terms) {
@@ -303,14 +306,12 @@ int64_t Engine::lin_c2(const std::vector<Term> &terms) const {
             if (ng == 8) { c2 += t.coef * t.coef * var; continue; }       // (more than 8 shared rotations in one sum: unseen)
             grp[ng++] = Grp{tb.rot, 0, 0, 0};
         }
-        grp[g].sum_c += t.coef;
+        grp[g].sum_abs += t.coef < 0 ? -t.coef : t.coef;
         grp[g].sum_c2 += t.coef * t.coef;
         grp[g].var = std::max(grp[g].var, var);
     }
-    for (int g = 0; g < ng; g++) {
-        const int64_t cross = grp[g].sum_c * grp[g].sum_c - grp[g].sum_c2;      // 2 sum_{i<j} c_i c_j
-        c2 += (grp[g].sum_c2 + (cross > 0 ? (cross + 3) / 4 : 0)) * grp[g].var;
-    }
+    for (int g = 0; g < ng; g++)
+        c2 += (grp[g].sum_c2 + (grp[g].sum_abs * grp[g].sum_abs - grp[g].sum_c2 + 1) / 2) * grp[g].var;
     return c2;
 }
 
@@ -560,7 +561,7 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                     if (cn.kind != BlockNode::PBS) return;
                     const BlockNode &src = nodes_[cn.src];
                     if (src.kind != BlockNode::LIN || src.terms.size() < 2) return;
-                    struct G { uint32_t lead; int64_t sum_c, sum_c2; };
+                    struct G { uint32_t lead; int64_t sum_abs, sum_c2; };
                     G g[8];
                     int ng = 0;
                     bool multi = false;
@@ -571,15 +572,12 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                         while (k < ng && g[k].lead != it->second) k++;
                         if (k == ng) { if (ng == 8) continue; g[ng++] = G{it->second, 0, 0}; }
                         else multi = true;
-                        g[k].sum_c += t.coef;
+                        g[k].sum_abs += t.coef < 0 ? -t.coef : t.coef;
                         g[k].sum_c2 += t.coef * t.coef;
                     }
                     if (!multi) return;
                     int64_t plain = lin_c2(src.terms), extra = 0;      // (members are still pending: counted as independent)
-                    for (int k = 0; k < ng; k++) {
-                        const int64_t cross = g[k].sum_c * g[k].sum_c - g[k].sum_c2;
-                        if (cross > 0) extra += (cross + 3) / 4;
-                    }
+                    for (int k = 0; k < ng; k++) extra += (g[k].sum_abs * g[k].sum_abs - g[k].sum_c2 + 1) / 2;   // as lin_c2 will
                     if (plain + extra <= FHS_NOISE_BUDGET_SUM_C2 || extra == 0) return;
                     for (const Term &t : src.terms)                    // the followers among this sum's terms leave their groups
                         for (size_t i = 0; i < fol.size(); i++)

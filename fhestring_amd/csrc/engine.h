@@ -83,10 +83,8 @@ class Engine {
     // units of one bootstrap output's): 0 trivial, 1 materialised or pending bootstrap, sum c^2 for a linear combination
     int64_t sum_c2(Bid b) const;
     // ... of a flattened combination.  The leader and the followers of one shared blind rotation are extractions of one
-    // accumulator: their errors are POSITIVELY correlated (measured rho = 0.17 between different coefficients: the
-    // decomposition-rounding term goes through the binary GLWE key, whose autocorrelation at a non-zero lag is half its
-    // zero-lag value), so a group contributes sum c^2 + ROT_CORR x max(0, (sum c)^2 - sum c^2) with ROT_CORR = 1/4
-    // (same-sign sums pay the cross terms; mixed-sign sums, whose true variance is lower, count as independent)
+    // accumulator: their errors are correlated (measured: rho falls linearly with the constant difference from +0.45 to
+    // -0.45, profiles/r05_rotation_sharing_rho.txt), so a group contributes sum c^2 + 1/2 ((sum |c|)^2 - sum c^2)
     int64_t lin_c2(const std::vector<Term> &terms) const;
     int64_t term_var(Bid b) const { return nodes_[b].kind == BlockNode::MAT ? nodes_[b].var : 1; }   // of a flattened term
     int set_var(Bid b, uint64_t v, bool check_only = false);                         // MAT blocks only (fhs_char_set_noise)
