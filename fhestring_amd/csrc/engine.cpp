@@ -335,7 +335,7 @@ Bid Engine::pbs(Bid x, int lut) {
     const uint32_t lvl = s.level + 1;
     // fused mode: an identical bootstrap (same LUT on the same linear combination of the same blocks) is computed once,
     // e.g. the high-nibble test of a character against pattern characters that share their high nibble
-    uint64_t h1 = 0, h2 = 0;
+    uint64_t h1 = 0, h2 = 0, nk_hash = 0;
     const bool share = mode == 1;
     if (share) {
         auto mix = [](uint64_t v, uint64_t k) {
@@ -350,9 +350,13 @@ Bid Engine::pbs(Bid x, int lut) {
         };
         if (s.kind == BlockNode::LIN) {
             for (const Term &t : s.terms) term(t.blk, nodes_[t.blk].gen, t.coef);
+            nk_hash = mix(h1 ^ h2 ^ ((uint64_t)lut << 48), 0x9E3779B97F4A7C15ull) | 1;      // before the constant goes in
             h1 += mix((uint64_t)(uint32_t)s.konst + 77, 0x94D049BB133111EBull);
             h2 += mix((uint64_t)(uint32_t)s.konst + 131, 0xD6E8FEB86659FD93ull);
-        } else term(x, s.gen, 1);
+        } else {
+            term(x, s.gen, 1);
+            nk_hash = mix(h1 ^ h2 ^ ((uint64_t)lut << 48), 0x9E3779B97F4A7C15ull) | 1;
+        }
         h1 = mix(h1 + (uint64_t)lut * 0x9E3779B97F4A7C15ull, 0xD6E8FEB86659FD93ull);
         h2 = mix(h2 ^ ((uint64_t)lut << 40), 0x94D049BB133111EBull);
         auto it = cse_.find(h1);
@@ -373,22 +377,25 @@ Bid Engine::pbs(Bid x, int lut) {
     n.src = x;
     n.lut = (uint16_t)lut;
     n.level = lvl;
+    n.nk = (share && share_rotations && !(level_parallel && ctx.dist.active())) ? nk_hash : 0;
     pending_.push_back({id, n.gen});
-    if (lvl == 1) n_depth1_++;
+    if (lvl == 1) { n_depth1_++; depth1_add(n); }
     if (auto_flush_pending && !manual_jobs_ && !capture_max_rows && !in_auto_flush_ &&
         sched_.empty() && !(dist_world > 1 && !level_parallel) && (planner || ctx.key_loaded)) {
         // peel the ready level when a whole batch has accumulated -- or, on a real device, as soon as a grid's worth is
         // ready and the previous launch group has finished (polled every 256 recorded bootstraps): the GPU never idles
         // while the host is still recording, and nothing narrower than one full round of workgroups is launched early
         // (level-parallel ranks must all take the same decisions: there only the deterministic count rule applies)
-        bool go = n_depth1_ >= auto_flush_pending;
+        // counted in blind ROTATIONS: rows that will share one (rotation sharing) are one unit of GPU work
+        const size_t ready = depth1_rotations();
+        bool go = ready >= auto_flush_pending;
         peel_limit_ = 0;
         const size_t round = balance_slots ? balance_slots : 1024;
-        if (!go && n_depth1_ >= round && !planner && !level_parallel && last_group_done_ && (++idle_poll_ & 255) == 0) {
+        if (!go && ready >= round && !planner && !level_parallel && last_group_done_ && (++idle_poll_ & 255) == 0) {
             go = hipEventQuery(last_group_done_) == hipSuccess;
             // an idle GPU gets whole rounds of the persistent kernel only: 1 191 ready rows launched as they are cost two
             // rounds; the remainder stays pending (it is ready, and joins the next launch)
-            peel_limit_ = n_depth1_ / round * round;
+            peel_limit_ = ready / round * round;
         }
         if (go) {
             in_auto_flush_ = true;
@@ -454,14 +461,26 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
         // peel depth 1 only: the other pending nodes stay pending, one level shallower than before
         std::vector<Pend> rest;
         n_depth1_ = 0;
-        const size_t limit = peel_limit_ ? peel_limit_ : ~(size_t)0;
-        size_t left_ready = 0;
+        n_depth1_solo_ = 0;
+        depth1_keys_.clear();
+        const size_t limit = peel_limit_ ? peel_limit_ : ~(size_t)0;     // in ROTATIONS: rows sharing a taken row's key ride along
+        size_t left_ready = 0, taken_rot = 0;
+        std::unordered_map<uint64_t, char> taken_keys;
         for (const Pend &p : pending_) {
             BlockNode &n = nodes_[p.id];
             if (n.kind != BlockNode::PBS || n.gen != p.gen) continue;
-            if (n.level <= 1 && by_level[1].size() < limit) by_level[1].push_back(p.id);
+            bool take = false;
+            if (n.level <= 1) {
+                if (n.nk && taken_keys.count(n.nk)) take = true;
+                else if (taken_rot < limit) {
+                    take = true;
+                    taken_rot++;
+                    if (n.nk) taken_keys[n.nk] = 1;
+                }
+            }
+            if (take) by_level[1].push_back(p.id);
             else {
-                if (n.level <= 1) left_ready++;
+                if (n.level <= 1) { left_ready++; depth1_add(n); }
                 rest.push_back(p);
             }
         }
@@ -469,7 +488,7 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
         // a stale level is only ever too HIGH, which keeps the order valid
         if (left_ready == 0) {
             for (const Pend &p : rest)
-                if (--nodes_[p.id].level == 1) n_depth1_++;
+                if (--nodes_[p.id].level == 1) { n_depth1_++; depth1_add(nodes_[p.id]); }
         } else {
             n_depth1_ = left_ready;
         }
@@ -480,6 +499,8 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
             if (nodes_[p.id].kind == BlockNode::PBS && nodes_[p.id].gen == p.gen) by_level[nodes_[p.id].level].push_back(p.id);
         pending_.clear();
         n_depth1_ = 0;
+        n_depth1_solo_ = 0;
+        depth1_keys_.clear();
     }
     uint64_t tick = next_tick_ - 1;                           // the job's first level goes to next_tick_ at the earliest
     const uint64_t job = ++job_counter_;
@@ -1016,6 +1037,8 @@ int Engine::plan_flush() {
         if (nodes_[p.id].kind == BlockNode::PBS && nodes_[p.id].gen == p.gen) by_level[nodes_[p.id].level].push_back(p.id);
     pending_.clear();
     n_depth1_ = 0;
+    n_depth1_solo_ = 0;
+    depth1_keys_.clear();
     if (by_level.empty()) return 0;
 
     std::vector<LevelPlan> &levels = plan_.levels;

@@ -36,6 +36,8 @@ struct BlockNode {
     uint32_t level = 0;      // PBS depth since the last flush
     uint32_t refs = 0;
     uint32_t gen = 0;        // bumped every time the slot is handed out again (common-subexpression table keys)
+    uint64_t nk = 0;         // PBS (fused mode): hash of (table, terms) WITHOUT the trivial constant -- rows with equal nk will
+                             // share a blind rotation (plan_job); 0 = counts as a rotation of its own
     uint32_t rot = 0;        // MAT: rotation group (non-zero for the leader and the followers of ONE shared blind rotation):
                              // their noises are correlated, the bookkeeping adds their coefficients before squaring
     uint64_t ready_tick = 0; // MAT produced by a scheduled (not yet enqueued) job level: the tick that writes it
@@ -211,6 +213,12 @@ class Engine {
     uint64_t job_counter_ = 0;
     uint32_t rot_counter_ = 0;           // rotation groups handed out (BlockNode::rot)
     size_t n_depth1_ = 0;                // pending bootstraps whose inputs are all available
+    // ... and how many blind ROTATIONS they are once rows that differ only in a trivial constant share one: what the
+    // automatic partial flush counts in (a round of the persistent kernel is 1024 rotations, not 1024 results)
+    std::unordered_map<uint64_t, uint32_t> depth1_keys_;
+    size_t n_depth1_solo_ = 0;           // depth-1 nodes without a share key
+    size_t depth1_rotations() const { return n_depth1_solo_ + depth1_keys_.size(); }
+    void depth1_add(const BlockNode &n) { if (n.nk) depth1_keys_[n.nk]++; else n_depth1_solo_++; }
     size_t peel_limit_ = 0;              // automatic partial flush of an idle GPU: take this many ready rows (0 = all)
     hipEvent_t last_group_done_ = nullptr;   // recorded behind every launch group: tells whether the GPU has run dry
     uint32_t idle_poll_ = 0;
