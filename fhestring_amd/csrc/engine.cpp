@@ -514,14 +514,15 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
         // (e.g. the nibble of a character tested against the different nibbles of a clear pattern: is0(x - c)) share ONE
         // keyswitch + blind rotation: adding c * Delta to a ciphertext rotates the accumulator by X^(128 c) exactly, so the
         // other rows are further sample extractions of the leader's accumulator (extract_shift_kernel) -- the same
-        // ciphertext a bootstrap of their own would give, up to decomposition ties (the CPU oracle restates it: orc_pbs_shifted).  The level
-        // is reordered: rotation rows first (R of them), followers behind.
+        // ciphertext a bootstrap of their own would give, up to decomposition ties (the CPU oracle restates it:
+        // orc_pbs_shifted).  The level is reordered: rotation rows first (R of them), followers behind.
         std::vector<ShareRow> followers;
         size_t R = lv.size();
         if (share_rotations && mode == 1 && lv.size() > 1 && !(level_parallel && ctx.dist.active())) {
             std::unordered_map<uint64_t, std::vector<uint32_t>> seen;     // hash of (lut, terms) -> leader positions
             std::vector<Bid> rot, fol;
             std::vector<ShareRow> fmeta;
+            std::vector<uint32_t> used;                                    // per rotation row: bit t = an extraction at shift t exists
             auto key_terms = [&](const BlockNode &src, Bid self, std::vector<std::pair<Bid, int64_t>> &tt, int &konst) {
                 tt.clear();
                 if (src.kind == BlockNode::LIN) {
@@ -551,16 +552,20 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                     key_terms(nodes_[ln.src], ln.src, tb, kb);
                     if (ln.lut != n.lut || ta != tb) continue;
                     // a constant difference of 16 is the SAME coefficient of the accumulator, negated (X^2048 = -1): its
-                    // error is exactly minus the leader's, which no positive-correlation bound covers -- own rotation
-                    if ((((ka - kb) % 32 + 32) % 32) == 16) continue;
+                    // error is exactly minus the other's, which no |rho| <= 1/2 bound covers -- no two members of a group
+                    // may be 16 apart (such a row joins another group of the same key, or starts one)
+                    const uint32_t t = (uint32_t)(((ka - kb) % 32 + 32) % 32);
+                    if (used[pos] & (1u << ((t + 16) & 31))) continue;
+                    used[pos] |= 1u << t;
                     fol.push_back(b);
-                    fmeta.push_back({pos, (uint32_t)(128 * (((ka - kb) % 32 + 32) % 32)), nullptr});
+                    fmeta.push_back({pos, 128 * t, nullptr});
                     shared = true;
                     break;
                 }
                 if (!shared) {
                     cand.push_back((uint32_t)rot.size());
                     rot.push_back(b);
+                    used.push_back(1u);                                    // the leader itself: shift 0
                 }
             }
             if (!fol.empty()) {
@@ -613,7 +618,7 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                     std::vector<Bid> fol2;
                     std::vector<ShareRow> fmeta2;
                     for (size_t i = 0; i < fol.size(); i++) {
-                        if (unshare[i]) rot.push_back(fol[i]);         // a rotation row of its own (appended: positions stay valid)
+                        if (unshare[i]) { rot.push_back(fol[i]); used.push_back(1u); }   // a rotation row of its own (appended: positions stay valid)
                         else { fol2.push_back(fol[i]); fmeta2.push_back(fmeta[i]); }
                     }
                     fol.swap(fol2);

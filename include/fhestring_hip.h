@@ -351,7 +351,10 @@ int fhs_debug_capture_pbs_inputs(fhs_ctx *ctx, size_t max_rows_per_level);
  * rows == NULL only reports the count (nothing is cleared). */
 int fhs_debug_capture_read(fhs_ctx *ctx, uint64_t *rows, fhs_capture_rec *recs, size_t cap, size_t *n);
 
-/* ---- statistics ---------------------------------------------------------------- */
+/* ---- statistics ----------------------------------------------------------------
+ * fhs_stats grows at its END when a counter is added (round 5: pbs_extracted): a host must be compiled against the
+ * header of the library it loads -- fhs_get_stats writes sizeof(fhs_stats) bytes of THAT build.  (build() recompiles
+ * examples/c_host for this reason; the generated Rust binding carries the same layout.) */
 typedef struct {
     uint64_t pbs_executed;     /* PBS actually run on the GPU (constant-folded ones excluded) */
     uint64_t pbs_folded;       /* PBS on all-trivial inputs folded at DAG construction */
