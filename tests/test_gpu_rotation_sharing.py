@@ -143,3 +143,57 @@ def test_extracted_outputs_are_as_noisy_as_bootstrap_outputs_and_how_they_correl
     assert 0.25 < rho[0, 1] < 0.55 and 0.05 < rho[0, 2] < 0.30 and abs(rho[0, 3]) < 0.12 and -0.55 < rho[0, 4] < -0.25, rho
     off = max(abs(rho[i, j]) for i in range(5) for j in range(5) if i != j)
     assert off < 0.55, rho                            # the engine's bound is 1/2 (1536 samples: +- 0.08 at three sigma)
+
+
+def test_random_ops_with_clear_and_mixed_operands_against_the_clear_model():
+    """Differential fuzz on the GPU (f64-FFT arithmetic, fused mode): encrypted strings against CLEAR (trivially encrypted)
+    patterns / replacements / other strings -- where rows share rotations -- and against mixtures of trivial and encrypted
+    characters -- where the correlated-noise guard un-shares -- for every non-split method, each result equal to the
+    loop-for-loop restatement of the reference on plain bytes (oracle/strings.py), with every bootstrap input inside the
+    noise budget under the correlated bookkeeping."""
+    import random
+    from fhestring_amd.api import MyClientKey, FheString
+    from oracle import strings as ostr
+    from golden_util import run_vector
+    from test_folded_strings import _cases, clear_env
+    ck = MyClientKey(0xF5E57121)
+    sk = ck.get_server_key(0, arith=1)
+    sk.set_mode(1)
+    sk.trivial_char = sk.trivial
+    rnd = random.Random(99)
+    try:
+        def enc_mixed(t, pad, p_enc):
+            raw = ostr.pad_plain(t, pad)
+            if not raw:
+                return FheString([])
+            enc = ck.encrypt_str_raw(bytes(b if b else 1 for b in raw).decode("latin1"), 0) if any(raw) else None
+            chars = []
+            for i, b in enumerate(raw):
+                if b and rnd.random() < p_enc:
+                    chars.append(sk.upload_char(enc[i]))
+                elif b == 0 and rnd.random() < p_enc:
+                    chars.append(sk.upload_char(ck.encrypt_char_raw(0)))
+                else:
+                    chars.append(sk.trivial(b))
+            return FheString(chars)
+        cenv = clear_env()
+        n_shared = 0
+        for k, v in enumerate(_cases(4242, 10)):
+            p_pat = (0.0, 0.0, 0.5)[k % 3]            # clear patterns mostly; every third case mixes trivial and encrypted
+            env = (sk, lambda t, pad: enc_mixed(t, pad, 1.0 if p_pat == 0.0 else 0.7),
+                   lambda t: enc_mixed(t, 0, p_pat), lambda x: sk.trivial(x) if p_pat == 0.0 else ck.encrypt_char(x, sk),
+                   ck.decrypt, ck.decrypt_char)
+            try:
+                want = run_vector(v, *cenv)
+            except OverflowError:
+                continue
+            sk.stats(reset=True)
+            got = run_vector(v, *env)
+            st = sk.stats()
+            assert got == want, (v, got, want)
+            assert st["max_input_sum_c2"] <= 64, (v, st)
+            n_shared += st["pbs_extracted"]
+        assert n_shared > 200                          # rotations were shared along the way
+    finally:
+        sk.close()
+        ck.close()
