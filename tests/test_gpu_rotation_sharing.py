@@ -178,7 +178,7 @@ def test_random_ops_with_clear_and_mixed_operands_against_the_clear_model():
             return FheString(chars)
         cenv = clear_env()
         n_shared = 0
-        for k, v in enumerate(_cases(4242, 10)):
+        for k, v in enumerate(_cases(4242, 6)):
             p_pat = (0.0, 0.0, 0.5)[k % 3]            # clear patterns mostly; every third case mixes trivial and encrypted
             env = (sk, lambda t, pad: enc_mixed(t, pad, 1.0 if p_pat == 0.0 else 0.7),
                    lambda t: enc_mixed(t, 0, p_pat), lambda x: sk.trivial(x) if p_pat == 0.0 else ck.encrypt_char(x, sk),
@@ -193,7 +193,7 @@ def test_random_ops_with_clear_and_mixed_operands_against_the_clear_model():
             assert got == want, (v, got, want)
             assert st["max_input_sum_c2"] <= 64, (v, st)
             n_shared += st["pbs_extracted"]
-        assert n_shared > 200                          # rotations were shared along the way
+        assert n_shared > 100                          # rotations were shared along the way
     finally:
         sk.close()
         ck.close()
