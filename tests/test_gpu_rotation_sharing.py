@@ -193,7 +193,7 @@ def test_random_ops_with_clear_and_mixed_operands_against_the_clear_model():
             assert got == want, (v, got, want)
             assert st["max_input_sum_c2"] <= 64, (v, st)
             n_shared += st["pbs_extracted"]
-        assert n_shared > 100                          # rotations were shared along the way
+        assert n_shared > 30                           # rotations were shared along the way
     finally:
         sk.close()
         ck.close()
