@@ -41,12 +41,13 @@ hipEvent_t KernelTimer::get() {
 void KernelTimer::begin(int kind, uint64_t u, hipStream_t s) {
     if (!enabled) return;
     if (pending.size() > 4096) resolve();
-    Pending p{get(), get(), kind, u};
+    Pending p{get(), get(), kind, u, 1};
     (void)hipEventRecord(p.e0, s);
     pending.push_back(p);
 }
-void KernelTimer::end(hipStream_t s) {
+void KernelTimer::end(hipStream_t s, uint32_t kernel_launches) {
     if (!enabled || pending.empty()) return;
+    pending.back().launches = kernel_launches ? kernel_launches : 1;
     (void)hipEventRecord(pending.back().e1, s);
 }
 void KernelTimer::resolve() {
@@ -55,7 +56,7 @@ void KernelTimer::resolve() {
         float t = 0;
         if (hipEventElapsedTime(&t, p.e0, p.e1) == hipSuccess) {
             ms[p.kind] += t;
-            n[p.kind] += 1;
+            n[p.kind] += p.launches;
             units[p.kind] += p.units;
         }
         pool.push_back(p.e0);
@@ -326,9 +327,11 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
     // A remainder of less than a quarter of a chunk does not become a launch of its own (8194 rows = 7 launches of 1024 and
     // one of 1026, not eight and a launch of 2 that costs a whole bootstrap alone).  The narrow-level kernel is never cut.
     const size_t chunk = (launch_chunk[arith] && !four) ? launch_chunk[arith] : B;
+    uint32_t n_launches = 0;
     for (size_t off = 0, n = 0; off < B && e == hipSuccess; off += n) {
         n = std::min(chunk, B - off);
         if (B - off - n < chunk / 4) n = B - off;
+        n_launches++;
         const uint64_t *ks = d_ks + off * SMALL_CT;
         const uint32_t *li = d_lut_idx + off;
         uint64_t *out = d_out ? d_out + off * BIG_CT : nullptr;
@@ -369,7 +372,7 @@ int Context::blind_rotate(const uint64_t *d_ks, const uint32_t *d_lut_idx, const
             e = launch_blind_rotate(p, s);
         }
     }
-    timer.end(s);
+    timer.end(s, n_launches);
     if (e != hipSuccess) return hip_fail(e, "blind_rotate launch");
     return 0;
 }

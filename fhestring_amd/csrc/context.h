@@ -24,18 +24,19 @@ struct DevBuf {
 
 // HIP-event timing of the two PBS kernels on the stream they are launched on
 struct KernelTimer {
-    struct Pending { hipEvent_t e0, e1; int kind; uint64_t units; };
+    struct Pending { hipEvent_t e0, e1; int kind; uint64_t units; uint32_t launches; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
     // 0 = blind rotation (exact NTT kernel, or the 2-wavefront FFT kernel), 1 = keyswitch,
     // 2 = blind rotation on the 4-wavefront FFT kernel (batches <= fft4_max_batch)
     double ms[3] = {0, 0, 0};
-    uint64_t n[3] = {0, 0, 0};
+    uint64_t n[3] = {0, 0, 0};       // KERNEL launches covered (a blind rotation cut into one-round launches counts each of them:
+                                     // the per-launch average then is what `rocprofv3 --kernel-trace --stats` reports per kernel)
     uint64_t units[3] = {0, 0, 0};   // PBS covered by the timed launches
     bool enabled = true;
     hipEvent_t get();
     void begin(int kind, uint64_t units, hipStream_t s);
-    void end(hipStream_t s);
+    void end(hipStream_t s, uint32_t kernel_launches = 1);
     void resolve();   // synchronises pending events and accumulates
     void reset();
     void destroy();

@@ -129,8 +129,10 @@ int fhs_debug_blind_rotate_batch(fhs_ctx *ctx, const uint64_t *ks, const uint32_
  * must be ordered (one stream at a time); use several contexts for concurrent streams. */
 int fhs_pbs_batch_device(fhs_ctx *ctx, const uint64_t *d_in, const uint32_t *d_lut_idx,
                          const uint64_t *d_luts, uint64_t *d_out, size_t B, void *hip_stream);
-/* Average duration (ms) of the blind-rotation / keyswitch kernel launches since the last
- * reset, measured with HIP events on the launch stream; and number of launches timed. */
+/* Average duration (ms) of the blind-rotation / keyswitch KERNEL launches since the last reset, measured with HIP events
+ * on the launch stream, and the number of kernel launches timed (a batch cut into one-round launches --
+ * fhs_set_launch_chunk, the default of the f64 kernels -- counts every launch: the figure is what `rocprofv3
+ * --kernel-trace --stats` reports per kernel; x launches = the time of the batches). */
 int fhs_kernel_timing(fhs_ctx *ctx, int reset, double *blind_rotate_ms, double *keyswitch_ms,
                       uint64_t *n_blind_rotate, uint64_t *n_keyswitch, uint64_t *pbs_in_launches);
 /* Per kernel class: kind 0 = blind rotation on the exact-NTT kernel or the 2-wavefront FFT kernel (fhs_kernel_timing

@@ -32,6 +32,19 @@ if [ $PART = 3 ]; then
   run chunk_l2miss rocprofv3 --kernel-trace --output-format csv --pmc TCC_MISS_sum -d $O/chunk_l2miss -- $BB --launch-chunk 1024
   grep -h "B= 3968\|B=3968" $O/wide_*.log; for f in $O/bench_plain_*.log $O/bench_chunk_*.log; do echo $f; python3 -c "import json,sys; l=json.loads(open('$f').read().strip().splitlines()[-1]); print(l['value'], l['ms_per_step'], l['roofline']['avg_launch_ms'], l['roofline']['launches'])"; done
 fi
+# PART=4: the default bench command on the FINAL tree (one-round launches by default): kernel stats the roofline's per-launch
+# average must agree with, and its fabric traffic
+if [ $PART = 4 ]; then
+  O=gpurun_out/profile_r5final; mkdir -p $O
+  BB="python3 bench.py --steps 20 --warmup 3 --cpu-pbs 0 --skip-single-op --skip-secondary --skip-extras --repeats 0"
+  run bench_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- $BB
+  run bench_fetch rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/bench_fetch -- $BB
+  run bench_write rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/bench_write -- $BB
+  run bench_plain $BB
+  find $O -name "*kernel_trace.csv" -size +1M -delete; find $O -name "*agent_info.csv" -delete
+  cat $O/status.txt; tail -1 $O/bench_stats.log | cut -c1-600; find $O/bench_stats -name "*kernel_stats.csv" | xargs head -5
+  exit 0
+fi
 for A in $ARITHS; do          # f64 FFT (headline), exact NTT, two-bit f64, two-bit exact
   W=3968; [ $A = 2 ] && W=4096        # the two-bit f64 kernel is launched in chunks of 1024 rows: 4 whole launches
   PB="python3 tools/time_mb2.py --profile --arith=$A $W"

@@ -38,10 +38,13 @@ for arith in (ARITHS or ((2,) if PROFILE else (1, 2))):
         kt = ctx.kernel_timing(reset=True)
         # a batch of at most 512 rows goes to the 4-wavefront kernel (kind 2): its time is in fft4_ms and
         # blind_rotate_ms is 0 (this line used to divide by it)
-        br, kern = (kt["blind_rotate_ms"], "blind_rotate") if kt["n_blind_rotate"] else (kt["fft4_ms"], "blind_rotate_fft4")
+        # the timer reports the average per KERNEL launch (a batch may be cut into one-round launches): per batch = x launches / 3
+        br, kern = (kt["blind_rotate_ms"] * kt["n_blind_rotate"] / 3.0, "blind_rotate (%d launches per batch)" % (kt["n_blind_rotate"] // 3)) \
+            if kt["n_blind_rotate"] else (kt["fft4_ms"] * kt["n_fft4"] / 3.0, "blind_rotate_fft4")
         if br <= 0:
             print("   B=%5d  no blind-rotation launch was timed" % B, flush=True)
             continue
+        ks = kt["keyswitch_ms"] * kt["n_keyswitch"] / 3.0
         print("   B=%5d  %s %.2f ms  keyswitch %.3f ms -> %.0f PBS/s (blind rotation only %.0f)" % (
-            B, kern, br, kt["keyswitch_ms"], B / ((br + kt["keyswitch_ms"]) * 1e-3), B / (br * 1e-3)), flush=True)
+            B, kern, br, ks, B / ((br + ks) * 1e-3), B / (br * 1e-3)), flush=True)
     sk.close()
