@@ -1136,6 +1136,25 @@ def _main(safety, args):
                                   "pbs_per_s": best[1]["pbs_executed"] / best[0], "pattern_len": w.m}
             del keep, w
         contains_sweep["find_encrypted_pattern"] = find_sweep
+        # ... and find with a CLEAR pattern (find_clear, mod.rs:1075-1087): its nibble tests share rotations like contains'
+        find_clear_sweep = {}
+        for n in (64, 128, 256):
+            w = Workload(args, ck, sks[:1], [None], 0, 1, op="find_enc", chars=n, strings=1)
+            s_in = w.inputs[0]["shards"][0][0]
+            keep = sks[0].find_clear(s_in, w.pattern); sks[0].flush(); sync()
+            best = None
+            for _ in range(3):
+                sks[0].stats(reset=True)
+                t0 = time.perf_counter()
+                keep = sks[0].find_clear(s_in, w.pattern); sks[0].flush(); sync()
+                d = time.perf_counter() - t0
+                if best is None or d < best[0]:
+                    best = (d, sks[0].stats())
+            assert ck.decrypt_char(keep) == w.plain[0].find(w.pattern)
+            find_clear_sweep[str(n)] = {"ms_per_op": best[0] * 1e3, "pbs": best[1]["pbs_executed"],
+                                        "extracted": best[1]["pbs_extracted"], "levels": best[1]["levels"], "pattern_len": w.m}
+            del keep, w, s_in
+        contains_sweep["find_clear_pattern"] = find_clear_sweep
         contains_sweep["note"] = ("one contains_clear (m = 4, hit) alone on the GPU, best of 3; find / find_clear stop at "
                                   "254 + m characters: the reference panics beyond a u8 index (mod.rs:1025-1027), so "
                                   "find has no 1024 / 4096 rows")

@@ -144,6 +144,8 @@ def test_bench_json_line_contract(tmp_path):
     assert [k for k in sw if k[0].isdigit()] == ["64", "256", "1024", "4096"] and "254 + m" in sw["note"]
     fs = sw["find_encrypted_pattern"]
     assert list(fs) == ["64", "128", "256"] and fs["64"]["pbs"] < fs["128"]["pbs"] < fs["256"]["pbs"]
+    fc = sw["find_clear_pattern"]                            # a clear pattern shares rotations: fewer of them, faster
+    assert fc["256"]["pbs"] < 0.5 * fs["256"]["pbs"] and fc["256"]["extracted"] > 1000 and fc["256"]["ms_per_op"] < fs["256"]["ms_per_op"]
     assert sw["64"]["pbs"] < sw["256"]["pbs"] < sw["1024"]["pbs"] < sw["4096"]["pbs"]
     assert sw["64"]["ms_per_op"] < sw["4096"]["ms_per_op"] and sw["4096"]["pbs_per_s"] > 3 * sw["64"]["pbs_per_s"]
     assert all(sw[k]["levels"] <= 12 and sw[k]["found"] == 1 for k in ("64", "256", "1024", "4096"))
