@@ -104,6 +104,8 @@ def _declare(L):
     L.fhs_upload.restype = h
     L.fhs_upload_string.argtypes = [vp, vp, sz, vp]
     L.fhs_upload_string.restype = i
+    L.fhs_download_string.argtypes = [vp, vp, sz, vp]
+    L.fhs_download_string.restype = i
     L.fhs_import_device.argtypes = [vp, vp]
     L.fhs_import_device.restype = h
     for name in ("eq", "ne", "le", "lt", "ge", "gt", "bitand", "bitor", "sub", "add"):

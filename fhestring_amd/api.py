@@ -367,9 +367,13 @@ class FheString:
         return self.chars[i]
 
     def download(self):
+        """[n][4][2049] words: the whole string with one gather + one copy per 2048 blocks (fhs_download_string)."""
         if not self.chars:
             return np.zeros((0, 4, BIG_CT), np.uint64)
-        return np.stack([c.download() for c in self.chars])
+        sk = self.chars[0].sk
+        out = np.empty((len(self.chars), 4, BIG_CT), np.uint64)
+        sk.ctx._check(sk.ctx._L.fhs_download_string(sk.ctx._h, _harr(self.chars), len(self.chars), _ptr(out)))
+        return out
 
 
 class FheSplit:

@@ -167,6 +167,16 @@ int fhs_download(fhs_ctx *c, fhs_char_t a, uint64_t *blocks) {
     }
     return FHS_OK;
 }
+int fhs_download_string(fhs_ctx *c, const fhs_char_t *chars, size_t n, uint64_t *blocks) {
+    if (!c || (n && (!chars || !blocks))) return bad(c);
+    std::vector<Bid> b(4 * n);
+    for (size_t i = 0; i < n; i++) {
+        if (!c->eng.valid_char(chars[i])) return bad(c);
+        const Bid *cb = c->eng.char_blocks(chars[i]);
+        for (int k = 0; k < 4; k++) b[4 * i + k] = cb[k];
+    }
+    return c->eng.read_many(b.data(), b.size(), blocks);
+}
 int fhs_export_device(fhs_ctx *c, fhs_char_t a, uint64_t *d_blocks) {
     if (!ok(c, a) || !d_blocks) return bad(c);
     const Bid *b = c->eng.char_blocks(a);

@@ -144,6 +144,29 @@ Bid Engine::from_host(const uint64_t *ct) {
     return id;
 }
 
+// pinned host buffer + device mirror for `n_blocks` rows and their pointer table (uploads and downloads of whole strings)
+bool Engine::ensure_staging(size_t n_blocks) {
+    const size_t words = n_blocks * BIG_CT + n_blocks;
+    if (upload_words_ < words) {
+        if (upload_done_) (void)hipEventSynchronize(upload_done_);
+        if (upload_pin_) (void)hipHostFree(upload_pin_);
+        if (upload_dev_) { (void)hipStreamSynchronize(ctx.stream); (void)hipFree(upload_dev_); }
+        upload_pin_ = upload_dev_ = nullptr;
+        upload_words_ = 0;
+        const size_t want = std::max<size_t>(n_blocks, 260) * (BIG_CT + 1);
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, want * 8, hipHostMallocDefault) == hipSuccess && hipMalloc(&dp, want * 8) == hipSuccess) {
+            upload_pin_ = static_cast<uint64_t *>(hp);
+            upload_dev_ = static_cast<uint64_t *>(dp);
+            upload_words_ = want;
+        } else {
+            if (hp) (void)hipHostFree(hp);
+            if (dp) (void)hipFree(dp);
+        }
+    }
+    return upload_pin_ && (upload_done_ || hipEventCreateWithFlags(&upload_done_, hipEventDisableTiming) == hipSuccess);
+}
+
 int Engine::from_host_many(const uint64_t *cts, size_t count, Bid *out) {
     for (size_t i = 0; i < count; i++) out[i] = 0;
     auto undo = [&](size_t n) {
@@ -164,25 +187,7 @@ int Engine::from_host_many(const uint64_t *cts, size_t count, Bid *out) {
     for (size_t done = 0; done < count;) {
         const size_t n = std::min(MAX_BATCH, count - done);
         const size_t words = n * BIG_CT + n;
-        if (upload_words_ < words) {
-            if (upload_done_) (void)hipEventSynchronize(upload_done_);
-            if (upload_pin_) (void)hipHostFree(upload_pin_);
-            if (upload_dev_) { (void)hipStreamSynchronize(ctx.stream); (void)hipFree(upload_dev_); }
-            upload_pin_ = upload_dev_ = nullptr;
-            upload_words_ = 0;
-            const size_t want = std::max<size_t>(n, 260) * (BIG_CT + 1);
-            void *hp = nullptr, *dp = nullptr;
-            if (hipHostMalloc(&hp, want * 8, hipHostMallocDefault) == hipSuccess && hipMalloc(&dp, want * 8) == hipSuccess) {
-                upload_pin_ = static_cast<uint64_t *>(hp);
-                upload_dev_ = static_cast<uint64_t *>(dp);
-                upload_words_ = want;
-            } else {
-                if (hp) (void)hipHostFree(hp);
-                if (dp) (void)hipFree(dp);
-            }
-        }
-        if (!upload_pin_ || (!upload_done_ && hipEventCreateWithFlags(&upload_done_, hipEventDisableTiming) != hipSuccess))
-            return one_by_one(done);                 // no staging memory: block by block
+        if (!ensure_staging(n)) return one_by_one(done);             // no staging memory: block by block
         (void)hipEventSynchronize(upload_done_);     // the previous copy has left the pinned buffer (no-op before the first)
         {
             // pageable -> pinned: one thread copies ~10 GB/s, which for the 537 MB of two 4097-character strings is as long
@@ -1273,6 +1278,59 @@ int Engine::read_block(Bid b, uint64_t *host_out) {
     hipError_t e = hipMemcpyAsync(host_out, nodes_[b].dev, BIG_CT * 8, hipMemcpyDeviceToHost, ctx.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx.stream);
     if (e != hipSuccess) return ctx.hip_fail(e, "download");
+    return 0;
+}
+
+int Engine::read_many(const Bid *b, size_t count, uint64_t *host_out) {
+    if (planner) return ctx.fail(-3, "planner context: nothing is computed, there is nothing to download");
+    if (count == 0) return 0;
+    (void)hipSetDevice(ctx.device);
+    if (int rc = flush()) return rc;
+    for (size_t i = 0; i < count; i++)                               // linear combinations become blocks of their own first
+        if (nodes_[b[i]].kind == BlockNode::LIN)
+            if (int rc = materialize_lin(b[i])) return rc;
+    constexpr size_t MAX_BATCH = 2048;
+    for (size_t done = 0; done < count;) {
+        const size_t n = std::min(MAX_BATCH, count - done);
+        if (count < 4 || !ensure_staging(n)) {
+            // too few blocks to matter, or no staging memory: block by block
+            for (size_t i = done; i < done + n; i++)
+                if (int rc = read_block(b[i], host_out + i * BIG_CT)) return rc;
+            done += n;
+            continue;
+        }
+        if (upload_done_) (void)hipEventSynchronize(upload_done_);   // the staging buffer is shared with the uploads
+        size_t n_dev = 0;
+        for (size_t k = 0; k < n; k++) {
+            const BlockNode &nd = nodes_[b[done + k]];
+            if (nd.kind == BlockNode::TRIV) { upload_pin_[n * BIG_CT + k] = 0; continue; }
+            if (nd.kind != BlockNode::MAT) return ctx.fail(-3, "internal: block not materialised");
+            upload_pin_[n * BIG_CT + k] = (uint64_t)(uintptr_t)nd.dev;
+            n_dev++;
+        }
+        // trivial blocks have no device row: point them at the first real block (their rows are overwritten on the host)
+        uint64_t any = 0;
+        for (size_t k = 0; k < n && !any; k++) any = upload_pin_[n * BIG_CT + k];
+        if (n_dev) {
+            for (size_t k = 0; k < n; k++)
+                if (!upload_pin_[n * BIG_CT + k]) upload_pin_[n * BIG_CT + k] = any;
+            hipError_t e = hipMemcpyAsync(upload_dev_ + n * BIG_CT, upload_pin_ + n * BIG_CT, n * 8, hipMemcpyHostToDevice, ctx.stream);
+            if (e == hipSuccess)
+                e = launch_gather_rows(reinterpret_cast<const uint64_t *const *>(upload_dev_ + n * BIG_CT), upload_dev_, (int)n, ctx.stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(upload_pin_, upload_dev_, n * BIG_CT * 8, hipMemcpyDeviceToHost, ctx.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx.stream);
+            if (e != hipSuccess) return ctx.hip_fail(e, "download");
+            std::memcpy(host_out + done * BIG_CT, upload_pin_, n * BIG_CT * 8);
+        }
+        for (size_t k = 0; k < n; k++) {
+            const BlockNode &nd = nodes_[b[done + k]];
+            if (nd.kind != BlockNode::TRIV) continue;
+            uint64_t *row = host_out + (done + k) * BIG_CT;
+            std::memset(row, 0, BIG_CT * 8);
+            row[BIG_N] = (uint64_t)nd.triv << DELTA_LOG;
+        }
+        done += n;
+    }
     return 0;
 }
 

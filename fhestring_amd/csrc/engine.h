@@ -132,6 +132,9 @@ class Engine {
     int exec_level(size_t k, size_t lo, size_t hi, uint64_t *dense_out);
     int commit_level(size_t k, const uint64_t *d_all);
     int read_block(Bid b, uint64_t *host_out);        // flushes if needed
+    // `count` blocks into consecutive 2049-word rows on the host: one gather launch and one copy through the pinned staging
+    // buffer per 2048 blocks instead of one synchronous copy per block (the twin of from_host_many)
+    int read_many(const Bid *b, size_t count, uint64_t *host_out);
     // flushes if needed (do_flush = false: the caller has made sure the block's tick is enqueued); wait=false: enqueue only
     int copy_block_to_device(Bid b, uint64_t *d_out, bool wait = true, bool do_flush = true);
     uint64_t blocks_live() const { return live_dev_blocks_; }
@@ -167,6 +170,7 @@ class Engine {
     std::vector<uint64_t *> free_blocks_;
     uint64_t live_dev_blocks_ = 0;
     uint64_t planner_tokens_ = 0;
+    bool ensure_staging(size_t n_blocks);
     uint64_t *alloc_block();
     void free_block(uint64_t *p);
 

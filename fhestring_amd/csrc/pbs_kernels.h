@@ -134,6 +134,7 @@ hipError_t launch_modswitch(const uint64_t *d_ks, uint32_t *d_ms /*[B][743]*/, i
 hipError_t launch_lincomb(const LinDesc *d_desc, const LinTerm *d_terms, uint64_t *d_out /*[n][2049]*/,
                           int n, hipStream_t s);
 hipError_t launch_scatter_blocks(const uint64_t *d_in, uint64_t *const *d_dst, int n, hipStream_t s);
+hipError_t launch_gather_rows(const uint64_t *const *d_src, uint64_t *d_out, int n, hipStream_t s);   // util_kernels.hip
 // Rotation sharing: one more sample extraction of a finished blind rotation.  `lead` = the output LWE of that rotation
 // (its mask IS the accumulator's mask polynomial in extract-at-0 order), `body` = the accumulator's body polynomial
 // (body_ptrs of the blind-rotation kernels), K in [0, 4096) = negacyclic coefficient index to extract: out = what a

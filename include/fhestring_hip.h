@@ -197,6 +197,10 @@ int fhs_set_tick_balance(fhs_ctx *ctx, size_t slots);
 int fhs_resident_slots(const fhs_ctx *ctx);
 int fhs_download(fhs_ctx *ctx, fhs_char_t a, uint64_t *blocks /*[4][2049]*/);
 /* device-to-device import/export of one char (multi-GPU gather of partial results) */
+/* n characters at once into [n][4][2049] words (what MyClientKey::decrypt, src/client_key.rs:89-106, walks): one gather
+ * launch and one copy per 2048 blocks instead of a synchronous 16 KB copy per block (a 1025-character replace result:
+ * ~10 ms instead of ~120 ms). */
+int fhs_download_string(fhs_ctx *ctx, const fhs_char_t *chars, size_t n, uint64_t *blocks);
 int fhs_export_device(fhs_ctx *ctx, fhs_char_t a, uint64_t *d_blocks /*[4][2049] device*/);
 /* Stream-ordered variant: flushes asynchronously and enqueues the copies on the context's stream, no host wait.
  * fhs_stream_handle returns that hipStream_t so a caller can order its own work (e.g. an RCCL all-gather issued

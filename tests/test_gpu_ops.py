@@ -361,3 +361,24 @@ def test_round4_noise_fixes_keep_the_results(product):
     back = sk.upload_char(raw).set_noise(c2)
     assert ck.decrypt_char(back.eq(sk.trivial(150))) == 1 and ck.decrypt_char(back.add(ck.encrypt_char(7, sk))) == 157
     assert sk.stats()["max_input_sum_c2"] <= 64
+
+
+def test_download_string_equals_block_by_block_downloads(product):
+    """fhs_download_string (one gather launch + one copy per 2048 blocks) returns the words fhs_download returns block by
+    block: encrypted characters, trivially encrypted ones, a result that is still a pending DAG, a handle whose blocks are
+    linear combinations (find's index digits), across the 2048-block batch boundary."""
+    import numpy as np
+    from fhestring_amd.api import FheString
+    ck, sk = product
+    sk.set_mode(1)
+    text = "".join(chr(0x20 + (11 * i) % 95) for i in range(600))          # 601 chars = 2404 blocks: two batches
+    s = ck.encrypt(text, 1, None, sk)
+    up = sk.to_upper(s)                                                     # pending when the download starts
+    idx = sk.find_clear(FheString(s.chars[:200]), text[37:41])              # blocks that are linear combinations
+    mixed = FheString(list(up.chars[:5]) + [sk.trivial(0x41), idx, sk.trivial(0)] + list(s.chars[590:]))
+    whole = mixed.download()
+    one_by_one = np.stack([c.download() for c in mixed.chars])
+    assert whole.shape == (len(mixed), 4, 2049) and np.array_equal(whole, one_by_one)
+    big = up.download()
+    assert np.array_equal(big[::97], np.stack([c.download() for c in up.chars[::97]]))
+    assert ck.decrypt(up) == text.upper() and ck.decrypt_char(idx) == 37
