@@ -153,12 +153,14 @@ void Context::shutdown() {
     if (d_work_counter) (void)hipFree(d_work_counter);
     d_work_counter = nullptr;
     if (d_bsk_fft) (void)hipFree(d_bsk_fft);
+    if (d_bsk_std) (void)hipFree(d_bsk_std);
     if (d_bsk_mb) (void)hipFree(d_bsk_mb);
     d_bsk_mb = nullptr;
     if (d_bsk_ntt_mb) (void)hipFree(d_bsk_ntt_mb);
     d_bsk_ntt_mb = nullptr;
     if (d_fft_tables) (void)hipFree(d_fft_tables);
     d_bsk_fft = nullptr;
+    d_bsk_std = nullptr;
     d_fft_tables = nullptr;
     d_bsk_ntt = nullptr;
     d_tables = nullptr;
@@ -216,38 +218,52 @@ int Context::load_server_key(const uint64_t *bsk, const uint64_t *ksk) {
         if (fu != ht.fwd_uni || iu != ht.inv_uni || c != ht.crt_c)
             return fail(-3, "ntt_consts.inc does not match the derived twiddle tables (regenerate it)");
     }
-    if (arith == 1 || arith == 2) {
-        HostFftTables ft;
-        build_fft_tables(ft);
-        {   // the kernel's literal twiddles must equal the libm-derived ones
-            double wr[16], wi[16], ur[3], ui[3];
-            fft_uniform_consts(wr, wi, ur, ui);
-            bool ok = true;
-            for (int k = 1; k < 16; k++) ok = ok && wr[k] == ft.w_re[k] && wi[k] == ft.w_im[k];
-            for (int k = 0; k < 3; k++) ok = ok && ur[k] == ft.u_re[k] && ui[k] == ft.u_im[k];
-            if (!ok) return fail(-3, "fft_consts.inc does not match the libm-derived twiddles (regenerate it)");
-        }
-        std::vector<double> flat(ft.lanetab);
-        flat.insert(flat.end(), ft.weff.begin(), ft.weff.end());
-        flat.insert(flat.end(), ft.mono.begin(), ft.mono.end());
-        flat.insert(flat.end(), ft.r16.begin(), ft.r16.end());
-        if (!d_fft_tables) HIP_TRY(hipMalloc(&d_fft_tables, flat.size() * sizeof(double)), "hipMalloc fft tables");
-        HIP_TRY(hipMemcpy(d_fft_tables, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice),
-                "copy fft tables");
-        const size_t n = (size_t)LWE_N * 4 * POLY_N;   // 1024 complex (2048 doubles) per polynomial
-        if (!d_bsk_fft) HIP_TRY(hipMalloc(&d_bsk_fft, n * sizeof(double)), "hipMalloc bsk fft");
-        uint64_t *d_std = nullptr;
-        HIP_TRY(hipMalloc(&d_std, n * sizeof(uint64_t)), "hipMalloc bsk staging");
-        hipError_t e = hipMemcpy(d_std, bsk, n * sizeof(uint64_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = launch_bsk_to_fft(d_std, d_bsk_fft, d_fft_tables, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        (void)hipFree(d_std);
-        HIP_TRY(e, "bsk -> Fourier domain");
-    } else if (d_bsk_fft) {   // a key loaded in exact mode invalidates an older Fourier-domain key
+    {   // the standard-domain key stays on the device (48.6 MB of 288 GB): the Fourier-domain key is built from it with the
+        // device's own forward transform -- now if the f64 arithmetic is selected, otherwise the first time it is
+        const size_t n = (size_t)LWE_N * 4 * POLY_N;
+        if (!d_bsk_std) HIP_TRY(hipMalloc(&d_bsk_std, n * sizeof(uint64_t)), "hipMalloc bsk (standard domain)");
+        HIP_TRY(hipMemcpy(d_bsk_std, bsk, n * sizeof(uint64_t), hipMemcpyHostToDevice), "copy bsk (standard domain)");
+    }
+    if (d_bsk_fft) {          // a new key invalidates the Fourier-domain form of the old one
         (void)hipFree(d_bsk_fft);
         d_bsk_fft = nullptr;
     }
+    if (arith == 1 || arith == 2)
+        if (int rc = build_fft_key()) return rc;
     key_loaded = true;
+    return 0;
+}
+
+// Fourier-domain bootstrapping key of the f64 arithmetics from the retained standard-domain key (load_server_key, or the
+// first fhs_set_arithmetic(FHS_ARITH_F64_FFT) after a key was loaded under the exact arithmetic: either order works).
+int Context::build_fft_key() {
+    if (!d_bsk_std) return fail(-3, "server key not loaded");
+    HIP_TRY(hipSetDevice(device), "hipSetDevice");
+    HostFftTables ft;
+    build_fft_tables(ft);
+    {   // the kernel's literal twiddles must equal the libm-derived ones
+        double wr[16], wi[16], ur[3], ui[3];
+        fft_uniform_consts(wr, wi, ur, ui);
+        bool ok = true;
+        for (int k = 1; k < 16; k++) ok = ok && wr[k] == ft.w_re[k] && wi[k] == ft.w_im[k];
+        for (int k = 0; k < 3; k++) ok = ok && ur[k] == ft.u_re[k] && ui[k] == ft.u_im[k];
+        if (!ok) return fail(-3, "fft_consts.inc does not match the libm-derived twiddles (regenerate it)");
+    }
+    std::vector<double> flat(ft.lanetab);
+    flat.insert(flat.end(), ft.weff.begin(), ft.weff.end());
+    flat.insert(flat.end(), ft.mono.begin(), ft.mono.end());
+    flat.insert(flat.end(), ft.r16.begin(), ft.r16.end());
+    if (!d_fft_tables) HIP_TRY(hipMalloc(&d_fft_tables, flat.size() * sizeof(double)), "hipMalloc fft tables");
+    HIP_TRY(hipMemcpy(d_fft_tables, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice), "copy fft tables");
+    const size_t n = (size_t)LWE_N * 4 * POLY_N;   // 1024 complex (2048 doubles) per polynomial
+    if (!d_bsk_fft) HIP_TRY(hipMalloc(&d_bsk_fft, n * sizeof(double)), "hipMalloc bsk fft");
+    hipError_t e = launch_bsk_to_fft(d_bsk_std, d_bsk_fft, d_fft_tables, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        (void)hipFree(d_bsk_fft);
+        d_bsk_fft = nullptr;
+    }
+    HIP_TRY(e, "bsk -> Fourier domain");
     return 0;
 }
 
@@ -266,8 +282,8 @@ int Context::keyswitch(const uint64_t *d_in, size_t B, hipStream_t s) {
 
 int Context::set_arithmetic(int mode) {
     if (mode < 0 || mode > 3) return fail(-1, "unknown arithmetic mode");
-    if ((mode == 1 || mode == 2) && key_loaded && !d_bsk_fft)
-        return fail(-3, "select the f64-FFT arithmetic before loading the server key");
+    if ((mode == 1 || mode == 2) && key_loaded && !d_bsk_fft)      // the key was loaded under the exact arithmetic: build
+        if (int rc = build_fft_key()) return rc;                   // its Fourier-domain form now (either order works)
     if (mode == 2 && key_loaded && !d_bsk_mb)
         return fail(-3, "the two-bits-per-product arithmetic needs the pair key in the Fourier domain: call "
                         "fhs_load_multibit_key while arithmetic 1 (f64 FFT) is selected, then fhs_set_arithmetic 2");

@@ -60,6 +60,7 @@ class Context {
     // Select before load_server_key: the Fourier-domain key is only built when the mode asks for it.
     int arith = 0;
     double *d_bsk_fft = nullptr;
+    uint64_t *d_bsk_std = nullptr;   // standard-domain key, kept for a later conversion to the Fourier domain (build_fft_key)
     double *d_fft_tables = nullptr;   // lanetab[12][64] | weff[1024][2] | mono[4096][2] | r16[16][2]
     uint32_t *d_work_counter = nullptr;   // persistent-workgroup ciphertext counter of the 2-wavefront FFT kernel
     int wg_slots = 1024;                  // 4 workgroups per CU
@@ -92,6 +93,7 @@ class Context {
     int hip_fail(hipError_t e, const char *what);
 
     int load_server_key(const uint64_t *bsk, const uint64_t *ksk);
+    int build_fft_key();
     // all device pointers; enqueues KS+MS then blind rotation on `s`
     int pbs_batch_device(const uint64_t *d_in, const uint32_t *d_lut_idx, const uint64_t *d_luts,
                          uint64_t *d_out, size_t B, hipStream_t s);

@@ -64,9 +64,11 @@ int fhs_load_server_key(fhs_ctx *ctx, const uint64_t *bsk, const uint64_t *ksk);
 /* Arithmetic of the negacyclic products inside blind rotation.  EXACT_NTT (default): exact integer
  * arithmetic over two 47-bit NTT primes.  F64_FFT: folded f64 complex FFT, the algorithm class of the
  * reference's CPU engine (tfhe 0.5.2 + concrete-fft 0.4.0, Cargo.lock:168-179) - ~3x faster, approximate
- * at the 2^-53 relative level (far below the scheme's noise) and deterministic.  Select F64_FFT BEFORE
- * loading the key (the Fourier-domain key is only built then); switching back to EXACT_NTT is always
- * allowed. */
+ * at the 2^-53 relative level (far below the scheme's noise) and deterministic.  fhs_set_arithmetic and
+ * fhs_load_server_key may come in either order: the standard-domain key stays on the device (48.6 MB) and its
+ * Fourier-domain form is built at the key load when F64_FFT is already selected, otherwise the first time it is
+ * selected (round 5; before that a key loaded first left a drop-in host on the 3.7x slower exact path).  Switching
+ * back and forth is always allowed. */
 #define FHS_ARITH_EXACT_NTT 0
 #define FHS_ARITH_F64_FFT 1
 /* F64_FFT_MB2: the f64 FFT arithmetic with TWO LWE key bits per GGSW x GLWE external product (371 products per bootstrap

@@ -313,3 +313,32 @@ def test_fft_needs_key_built_for_it(oracle_keys):
     with pytest.raises(fhestring_amd.FhsError):
         ctx.set_arithmetic(ctx.ARITH_F64_FFT)
     ctx.close()
+
+
+def test_arithmetic_can_be_selected_after_the_key_load(oracle_keys):
+    """A drop-in host that calls fhs_ctx_create + fhs_load_server_key and only then fhs_set_arithmetic(F64_FFT) gets the
+    same kernel and the same bits as one that selected it first (the default left such a host on the
+    3.7x slower exact path; the standard-domain key now stays on the device and is converted when first needed), a
+    second key load replaces both forms."""
+    import fhestring_amd
+    from oracle import radix
+    luts = np.stack([radix.lut_poly(n) for n in ("msg", "eq_biv")])
+    cts = np.stack([oracle_keys.encrypt_block(m) for m in (0, 5, 9, 15, 22, 31, 3)])
+    idx = (np.arange(7) % 2).astype(np.uint32)
+    first = fhestring_amd.Context(0)
+    first.set_arithmetic(first.ARITH_F64_FFT)
+    first.load_server_key(oracle_keys.bsk, oracle_keys.ksk)
+    want = first.pbs_batch(cts, idx, luts)
+    late = fhestring_amd.Context(0)
+    late.load_server_key(oracle_keys.bsk, oracle_keys.ksk)             # exact arithmetic (the default) at load time
+    exact = late.pbs_batch(cts, idx, luts)
+    late.set_arithmetic(late.ARITH_F64_FFT)                             # builds the Fourier-domain key now
+    got = late.pbs_batch(cts, idx, luts)
+    assert np.array_equal(got, want) and not np.array_equal(got, exact)
+    late.set_arithmetic(late.ARITH_EXACT_NTT)
+    assert np.array_equal(late.pbs_batch(cts, idx, luts), exact)
+    late.set_arithmetic(late.ARITH_F64_FFT)
+    late.load_server_key(oracle_keys.bsk, oracle_keys.ksk)             # reload under the f64 arithmetic: converted at once
+    assert np.array_equal(late.pbs_batch(cts, idx, luts), want)
+    first.close()
+    late.close()
