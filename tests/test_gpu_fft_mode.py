@@ -306,12 +306,16 @@ def test_server_and_pair_key_files(tmp_path):
     ck.close()
 
 
-def test_fft_needs_key_built_for_it(oracle_keys):
+def test_two_bit_arithmetic_still_needs_its_pair_key(oracle_keys):
+    """The classic f64 arithmetic can be selected at any time (next test); the two-bit ones need key material the server
+    key does not contain, and say so."""
     import fhestring_amd
     ctx = fhestring_amd.Context(0)
     ctx.load_server_key(oracle_keys.bsk, oracle_keys.ksk)
     with pytest.raises(fhestring_amd.FhsError):
-        ctx.set_arithmetic(ctx.ARITH_F64_FFT)
+        ctx.set_arithmetic(ctx.ARITH_F64_FFT_MB2)
+    with pytest.raises(fhestring_amd.FhsError):
+        ctx.set_arithmetic(ctx.ARITH_EXACT_NTT_MB2)
     ctx.close()
 
 
