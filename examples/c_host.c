@@ -50,7 +50,7 @@ static char *decrypt_str(const fhs_char_t *h, size_t n) {
     char *out = calloc(n + 1, 1);
     size_t len = 0;
     if (!raw || !out) die("malloc", -1);
-    for (size_t i = 0; i < n; i++) TRY(fhs_download(ctx, h[i], raw + i * CHAR_WORDS));
+    TRY(fhs_download_string(ctx, h, n, raw));                 /* one gather + one copy for the whole string */
     TRY(fhs_client_decrypt_str(ck, raw, n, out, &len));
     out[len] = 0;
     free(raw);
@@ -75,7 +75,7 @@ int main(int argc, char **argv) {
 
     TRY(fhs_client_create_insecure_seeded(0xF5E57121ull, &ck));   /* reproducible demo keys; fhs_client_create for real ones */
     TRY(fhs_ctx_create(0, &ctx));
-    TRY(fhs_set_arithmetic(ctx, FHS_ARITH_F64_FFT));               /* before the key: the Fourier-domain key is built at load */
+    TRY(fhs_set_arithmetic(ctx, FHS_ARITH_F64_FFT));               /* before or after the key load: either order works */
     TRY(fhs_load_server_key(ctx, fhs_client_bsk(ck), fhs_client_ksk(ck)));
     TRY(fhs_set_mode(ctx, FHS_MODE_FUSED));
 
