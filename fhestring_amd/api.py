@@ -242,9 +242,10 @@ class MyClientKey:
         self._L.fhs_client_encrypt_char(self._h, int(v) & 255, _ptr(out))
         return out
 
-    def encrypt_str_raw(self, text, padding):
+    def encrypt_str_raw(self, text, padding, out=None):
         data = text.encode("ascii") if isinstance(text, str) else bytes(text)
-        out = np.empty((len(data) + padding, 4, BIG_CT), np.uint64)      # every word is written by the call
+        if out is None:
+            out = np.empty((len(data) + padding, 4, BIG_CT), np.uint64)  # every word is written by the call
         rc = self._L.fhs_client_encrypt_str(self._h, data, len(data), int(padding), _ptr(out))
         if rc != 0:
             raise AssertionError("The input string must only contain ascii letters and not include null characters")
@@ -265,7 +266,12 @@ class MyClientKey:
 
     # reference-shaped API (server key needed to place ciphertexts on the device)
     def encrypt(self, string, padding, public_parameters=None, server_key=None):   # :45-65
-        return server_key.upload_string(self.encrypt_str_raw(string, padding))
+        # the ciphertext only lives until fhs_upload_string has staged it: one scratch buffer per client, grown on demand
+        # (a fresh 268 MB array per 4097-character string is 65 000 page faults before the first byte is encrypted)
+        n = len(string) + padding
+        if getattr(self, "_scratch", None) is None or self._scratch.shape[0] < n:
+            self._scratch = np.empty((max(n, 64), 4, BIG_CT), np.uint64)
+        return server_key.upload_string(self.encrypt_str_raw(string, padding, out=self._scratch[:n]))
 
     def encrypt_no_padding(self, string, server_key=None):                         # :67-79
         return server_key.upload_string(self.encrypt_str_raw(string, 0)).chars
