@@ -1317,7 +1317,7 @@ def _main(safety, args):
             "pbs_per_op": pbs_total / args.steps / wl.n_strings,
             # rotation sharing: results that are a further sample extraction of another row's blind rotation (same table,
             # same ciphertext up to a trivial constant: the nibble tests of a clear pattern); NOT counted in `value`
-            "extractions_per_op": st.get("pbs_extracted", 0) / args.steps / wl.n_strings,
+            "extractions_per_op": st.get("pbs_extracted", 0) * world / args.steps / wl.n_strings,   # (rank 0's count x ranks)
             "levels_per_op": st["levels"] / args.steps,
             "max_level_width": st["max_level_width"],
             "max_input_sum_c2": st.get("max_input_sum_c2"),
