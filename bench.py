@@ -385,6 +385,27 @@ def roofline_for(kernel, pbs_per_launch, launch_ms, n_launches, counters, traffi
 
 LINE_LIMIT = 8000            # hard cap of the contract line in bytes (target <= 4 KB); tests/test_gpu_bench_contract.py
 OUT_LOCK = __import__("threading").Lock()    # stdout carries exactly ONE line: whoever prints it holds this lock
+CONTRACT_FD = [1]            # the fd the ONE line goes to; isolate_contract_fd() moves it away from fd 1
+
+
+def isolate_contract_fd():
+    """Before torch / the library / gloo / RCCL are loaded: keep the process's original stdout as a private fd for the
+    contract line and point fd 1 at stderr, so that no native library that prints to stdout (libgloo's "[Gloo] Rank ..."
+    banners today, NCCL_DEBUG tomorrow) can share the pipe the driver parses (VERDICT r5 weak 1).  Every rank does it;
+    only rank 0 ever writes to the saved fd."""
+    if CONTRACT_FD[0] != 1:
+        return
+    sys.stdout.flush()
+    CONTRACT_FD[0] = os.dup(1)
+    os.set_inheritable(CONTRACT_FD[0], False)
+    os.dup2(2, 1)
+
+
+def write_contract_line(text):
+    """the ONE line, in one write(2) call on the private fd (callers hold OUT_LOCK)"""
+    data = (text + "\n").encode()
+    while data:
+        data = data[os.write(CONTRACT_FD[0], data):]
 
 
 def _r(x, sig=6):
@@ -486,8 +507,7 @@ def emit(full, args, safety):
     sys.stderr.flush()
     text = compact_line(full, os.path.relpath(paths[0], ROOT) if paths else None)
     with OUT_LOCK:
-        sys.stdout.write(text + "\n")
-        sys.stdout.flush()
+        write_contract_line(text)
         safety["line_out"] = True
 
 
@@ -499,6 +519,7 @@ def main():
     rc = launch_ranks_if_needed(args)
     if rc is not None:
         sys.exit(rc)
+    isolate_contract_fd()                    # from here on fd 1 is stderr for everything but the contract line
     safety = {}
     try:
         _main(safety, args)
@@ -554,10 +575,13 @@ def launch_ranks_if_needed(args):
             pass
     old_handlers = {sig: signal.signal(sig, forward) for sig in (signal.SIGTERM, signal.SIGINT)}
     n_json = 0
-    for line in child.stdout:                    # relay as it comes; stderr goes straight through
-        sys.stdout.write(line)
-        sys.stdout.flush()
-        n_json += line.lstrip().startswith("{")
+    for line in child.stdout:                    # relay ONLY the contract line; anything else a rank or a library managed
+        if line.lstrip().startswith("{"):        # to put on the launcher's stdout goes to stderr
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            n_json += 1
+        else:
+            sys.stderr.write(line)
     try:
         rc = child.wait(timeout=30 if stopped else None)
     except subprocess.TimeoutExpired:
@@ -780,8 +804,7 @@ def _main(safety, args):
                     if rank == 0 and not safety.get("line_out"):
                         short = dict(head, roofline=_roofline_compact(head.get("roofline")),
                                      incomplete="%s [%s]" % (reason, where), incomplete_stage=stage[0])
-                        sys.stdout.write(json.dumps(_r(short), allow_nan=False, separators=(",", ":")) + "\n")
-                        sys.stdout.flush()
+                        write_contract_line(json.dumps(_r(short), allow_nan=False, separators=(",", ":")))
                         safety["line_out"] = True
                 sys.stderr.write("bench.py %s: leaving after the timed measurement: %s\n" % (where, reason))
                 sys.stderr.flush()

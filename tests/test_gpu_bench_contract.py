@@ -6,6 +6,8 @@ import sys
 
 import pytest
 
+from conftest import free_port
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -18,13 +20,10 @@ def _reject_constant(name):
 
 
 def _parse_line(stdout, gloo_noise=False):
-    """exactly one stdout line, strict JSON (no NaN / Infinity), far below the driver's 8 KB.  (The gloo rehearsals with
-    several ranks on one GPU: libgloo itself prints "[Gloo] Rank ..." lines to stdout; the nccl run has none.)"""
-    lines = [l for l in stdout.splitlines() if l.strip()]
-    if gloo_noise:                       # (the ranks' "[Gloo]" lines interleave: keep what looks like the JSON line)
-        noise = [l for l in lines if not l.lstrip().startswith("{")]
-        assert all("Gloo" in l or "peer ranks" in l for l in noise), noise
-        lines = [l for l in lines if l.lstrip().startswith("{")]
+    """exactly one JSON line on stdout, strict JSON (no NaN / Infinity), far below the driver's 8 KB.  bench.py keeps
+    fd 1 for that line alone (isolate_contract_fd), so nothing else should be there; what a foreign library might still
+    print is not this test's business -- the driver, too, looks for the '{' line only."""
+    lines = [l for l in stdout.splitlines() if l.lstrip().startswith("{")]
     assert len(lines) == 1, lines
     assert len(lines[0].encode()) < LINE_CAP, len(lines[0])
     return json.loads(lines[0], parse_constant=_reject_constant)
@@ -168,17 +167,15 @@ def test_bench_other_ops(op):
     assert op.split("_")[0] in d["config"]["workload"]
 
 
-@pytest.mark.parametrize("extra", [[], ["--pipelines", "3"], ["--op", "find_enc"], ["--op", "replace", "--chars", "96"],
-                                   ["--op", "le", "--chars", "256"], ["--arith", "mb2"]],
-                         ids=["contains_skewed", "contains_pipelines", "find_enc", "replace_level_parallel", "le",
-                              "contains_skewed_two_key_bits_per_product"])
+@pytest.mark.parametrize("extra", [[], ["--op", "find_enc"], ["--op", "replace", "--chars", "96"]],
+                         ids=["contains_skewed", "find_enc", "replace_level_parallel"])
 def test_bench_two_ranks_on_one_gpu(extra):
     """The N > 1 path of bench.py as the driver launches it (torch.distributed.run, one rank per process), rehearsed
     with two ranks sharing this GPU: FHS_BENCH_BACKEND=gloo makes the library carry its all-gathers through the host
     transport (RCCL refuses two ranks on one device); everything else is the code the 8-GPU run executes."""
     env = dict(os.environ, FHS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--master-port", free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
            "--cpu-pbs", "0", "--skip-secondary", "--skip-extras", "--repeats", "0"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -188,7 +185,7 @@ def test_bench_two_ranks_on_one_gpu(extra):
     assert ex["transport"] == "host" and ex["allgather_calls_per_step"] > 0 and ex["bytes_sent_per_rank_per_step"] > 0
 
 
-@pytest.mark.parametrize("extra", [[], ["--op", "find_enc"]], ids=["contains_skewed", "find_enc"])
+@pytest.mark.parametrize("extra", [["--op", "find_enc"]], ids=["find_enc"])
 def test_bench_four_ranks_on_one_gpu(extra):
     """Rank counts beyond 2: four ranks share this GPU.  This pool lets ONE job hold a card from at
     most 6 processes at once (the test runner itself is one of them; a 6-rank attempt was killed by the process guard),
@@ -198,7 +195,7 @@ def test_bench_four_ranks_on_one_gpu(extra):
     along; find: 256 characters, 254 windows over four ranks (64, 64, 63, 63), ONE all-gather of 64 flags per rank."""
     env = dict(os.environ, FHS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
-           "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "6", "--warmup", "2",
+           "--master-port", free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "6", "--warmup", "2",
            "--cpu-pbs", "0", "--skip-secondary", "--skip-extras", "--repeats", "0"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -237,8 +234,8 @@ def test_bench_keeps_the_headline_when_a_later_leg_fails_on_one_rank(fault):
     leaves NON-ZERO (a GPU process that failed or hung must not look like a clean run to the launcher)."""
     env = dict(os.environ, FHS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29573", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--cpu-pbs", "0", "--skip-secondary", "--skip-extras", "--repeats", "1", "--watchdog", "12",
+           "--master-port", free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--cpu-pbs", "0", "--skip-secondary", "--skip-extras", "--repeats", "1", "--watchdog", "6",
            "--inject-fault", fault]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode != 0, out.stdout[-2000:]

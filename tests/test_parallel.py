@@ -9,6 +9,8 @@ import os
 import subprocess
 import sys
 
+from conftest import free_port
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -122,7 +124,7 @@ sys.exit(0 if ok else 3)
 def test_sharded_design_world2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, FHS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    env = dict(os.environ, FHS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
     rcs = [p.wait(timeout=240) for p in procs]
     assert rcs == [0, 0]
@@ -193,7 +195,7 @@ def test_level_parallel_slices_world2_gloo(tmp_path):
     level-exec / commit protocol over the replace DAG; the slices of every level cover it exactly once."""
     script = tmp_path / "level_worker.py"
     script.write_text(LEVEL_WORKER)
-    env = dict(os.environ, FHS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    env = dict(os.environ, FHS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(2)]
     rcs = [p.wait(timeout=240) for p in procs]
     assert rcs == [0, 0]
