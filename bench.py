@@ -238,6 +238,34 @@ class Workload:
                 got, want = ck.decrypt_char(o), int(self.plain[i][0] <= self.plain[i][1])
             assert got == want, ("bench result mismatch", op, i, got, want)
 
+    def decrypt(self, o):
+        return self.ck.decrypt(o) if self.op == "replace" else self.ck.decrypt_char(o)
+
+    def single_gpu_twin(self, n=1):
+        """The same op on the first `n` strings of this workload, UNSHARDED, on this rank's GPU alone: what an N > 1 run
+        compares its sharded result with before anything is timed -> decrypted results."""
+        sk, ck, op, D = self.sks[0], self.ck, self.op, self.dists[0]
+        if op == "replace" and D is not None:
+            D.level_parallel(False)
+        try:
+            outs = []
+            for item in self.plain[:n]:
+                if op == "contains":
+                    outs.append(sk.contains_clear(ck.encrypt(item, 1, None, sk), self.pattern))
+                elif op == "find_enc":
+                    outs.append(sk.find(ck.encrypt(item, 1, None, sk), ck.encrypt_no_padding(self.pattern, sk)))
+                elif op == "replace":
+                    outs.append(sk.replace(ck.encrypt(item, 1, None, sk), ck.encrypt_no_padding(self.frm, sk),
+                                           ck.encrypt_no_padding(self.to, sk)))
+                else:
+                    a, b = ck.encrypt(item[0], 1, None, sk), ck.encrypt(item[1], 1, None, sk)
+                    outs.append(sk.eq_ignore_case(a, b) if op == "eq_ignore_case" else sk.le(a, b))
+            sk.flush()
+            return [self.decrypt(o) for o in outs]
+        finally:
+            if op == "replace" and D is not None:
+                D.level_parallel(True)
+
     def describe(self):
         names = {"contains": "contains_clear", "find_enc": "find (encrypted pattern)", "replace": "replace (encrypted from/to, 5 -> 5)",
                  "eq_ignore_case": "eq_ignore_case", "le": "le (<=)"}
@@ -452,6 +480,8 @@ def compact_line(full, extras_path):
     cfg = full["config"]
     c["config"] = {"workload": cfg["workload"], "parallelism": cfg.get("parallelism"), "transport": cfg.get("transport"),
                    "pipelines": cfg.get("pipelines")}
+    if cfg.get("precheck"):
+        c["config"]["precheck"] = cfg["precheck"]
     ex = cfg.get("exchange")
     if ex:
         c["config"]["exchange"] = {k: ex[k] for k in ("transport", "allgather_calls_per_step", "bytes_sent_per_rank_per_step")}
@@ -760,6 +790,20 @@ def _main(safety, args):
 
     for _ in range(args.warmup):
         step()
+    precheck = None
+    if world > 1:
+        # validate before timing: one sharded step, drained, decrypted -- against python AND against the same op run
+        # unsharded on this rank's GPU alone; a mismatch on any rank stops the run before a number exists
+        stage[0] = "pre-check of the sharded path against its single-GPU twin"
+        step()
+        sync()
+        wl.check(last_outs[0])
+        twin = wl.single_gpu_twin(1)
+        got = [wl.decrypt(o) for o in last_outs[0][:1]]
+        if got != twin:
+            raise SystemExit("bench.py rank %d: the sharded %s differs from the same op on one GPU (%r vs %r)" % (rank, wl.op, got, twin))
+        sync()
+        precheck = "sharded %s == single-GPU twin == python on every rank, before the timed region" % wl.op
     ex0 = [D.stats() for D in dists if D is not None]
     dt, outs, st, kt = timed(args.steps)
     ex1 = [D.stats() for D in dists if D is not None]
@@ -1329,7 +1373,7 @@ def _main(safety, args):
                                       "%d independent context(s), step k on context k mod %d" % (P, P)),
                        "parallelism": wl.parallelism(),
                        "transport": dists[0].transport if dists and dists[0] is not None else "single GPU",
-                       "exchange": exchange},
+                       "exchange": exchange, "precheck": precheck},
             "ms_per_op": dt / args.steps / wl.n_strings * 1e3,
             "median_ms_per_step": statistics.median(rep_ms) if rep_ms else None,
             # the SURVEY 8(d) protocol's figure: median of >= 5 repeats of `repeat_steps` (= K) steps each, the same region

@@ -181,6 +181,7 @@ def test_bench_two_ranks_on_one_gpu(extra):
     assert out.returncode == 0, out.stderr[-3000:]
     d = _parse_line(out.stdout, gloo_noise=True)
     assert d["n_gpus"] == 2 and d["value"] > 1000 and "GPU(s)" in d["config"]["parallelism"]
+    assert "single-GPU twin" in d["config"]["precheck"]      # the sharded op was validated before it was timed
     ex = d["config"]["exchange"]                            # fhs_dist_stats over the timed region (host transport here)
     assert ex["transport"] == "host" and ex["allgather_calls_per_step"] > 0 and ex["bytes_sent_per_rank_per_step"] > 0
 

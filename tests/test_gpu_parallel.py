@@ -26,12 +26,20 @@ from fhestring_amd.api import MyClientKey, MyServerKey
 from fhestring_amd.parallel import Dist
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", rank=rank, world_size=world)
+backend = os.environ.get("FHS_TEST_BACKEND", "gloo")
+dev = rank if backend == "nccl" else 0       # nccl: one rank per GPU (the real thing); gloo: the ranks share GPU 0
+if backend == "nccl":
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
 ck = MyClientKey(0xF5E57121)                 # same seed -> same keys on every rank
-sk = MyServerKey.from_client_key(ck, 0, arith=1)
+sk = MyServerKey.from_client_key(ck, dev, arith=1)
 sk.set_mode(1)
-D = Dist.from_torch(sk, dist, torch)         # gloo backend -> host transport through the library's callback
-ok = True
+D = Dist.from_torch(sk, dist, torch)         # gloo -> host transport through the library's callback; nccl -> the
+ok = True                                    # library's own RCCL communicator (ncclAllGather on the context's stream)
+if backend == "nccl":
+    ok &= D.transport == "rccl" and D.stats()["transport"] == "rccl"
 for s, p in [("the quick brown fox jumps over", "n fo"), ("the quick brown fox jumps over", "zama"),
              ("abcabcabcabd", "cabd"), ("ab", "abc")]:
     shard, w0, total = D.window_shard(ck, s, len(p))
@@ -66,7 +74,7 @@ ok &= [ck.decrypt_char(o) for o in D.contains_batch(shards, "n fo")] == [int("n 
 ea, eb = ck.encrypt("sharded", 1, None, sk), ck.encrypt("shardee" if rank else "sharded", 1, None, sk)
 verdict, index = sk.le(ea, eb), sk.find(ea, ck.encrypt_no_padding("rd" if rank else "ha", sk))
 flags = D.allgather_flags([verdict])
-ok &= [ck.decrypt_char(flags[r][0]) for r in range(world)] == [1, 1]
+ok &= [ck.decrypt_char(flags[r][0]) for r in range(world)] == [1] * world
 chars = D.allgather_chars([index])
 ok &= [ck.decrypt_char(chars[r][0]) for r in range(world)] == [1, 3]
 ok &= all(chars[r][0].sum_c2() == 1 for r in range(world))
@@ -96,9 +104,15 @@ sys.path.insert(0, os.environ["FHS_ROOT"])
 from fhestring_amd.api import MyClientKey, MyServerKey
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", rank=rank, world_size=world)
+backend = os.environ.get("FHS_TEST_BACKEND", "gloo")
+dev = rank if backend == "nccl" else 0
+if backend == "nccl":
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
 ck = MyClientKey(0xF5E57121)                 # same seed and call order -> identical ciphertexts on every rank
-sk = MyServerKey.from_client_key(ck, 0, arith=1)
+sk = MyServerKey.from_client_key(ck, dev, arith=1)
 sk.set_mode(1)
 sk.enable_level_parallel(rank, world, dist, torch)      # fhs_dist_level_parallel: fhs_flush splits every level
 s = ck.encrypt("hello abc abc test", 1, None, sk)
@@ -113,7 +127,9 @@ mine = torch.tensor([float(st["pbs_executed"])])
 tot = [torch.zeros(1) for _ in range(world)]
 dist.all_gather(tot, mine)
 share = st["pbs_executed"] / sum(float(t) for t in tot)
-ok &= 0.35 < share < 0.65                    # each rank ran about half of every level
+ok &= 0.7 / world < share < 1.3 / world      # each rank ran about 1/world of every level
+if backend == "nccl":
+    ok &= sk.dist.stats()["transport"] == "rccl" and sk.dist.stats()["allgather_calls"] > 0
 dist.barrier()
 sk.dist.shutdown()
 dist.destroy_process_group()
@@ -211,3 +227,32 @@ def test_stream_ordered_rccl_exchange_one_rank(tmp_path):
     env = dict(os.environ, FHS_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.Popen([sys.executable, str(script)], env=env)
     assert p.wait(timeout=500) == 0
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 MI355X in one node: skipped on this pool's 1-GPU boxes, runs by "
+                                          "itself wherever the suite meets more (VERDICT r5 item 2)")
+@pytest.mark.parametrize("worker", ["sharded", "level_parallel"])
+def test_rccl_n_ranks(tmp_path, worker):
+    """REAL RCCL over xGMI, one rank per GPU (up to 4): the same workers as the two-ranks-on-one-GPU rehearsals above,
+    with backend nccl -- Dist.from_torch brings up the library's own communicator (dist.cpp: ncclCommInitRank on the
+    context's device; every exchange one ncclAllGather on the context's stream), `transport` must say "rccl", and the
+    sharded contains / find / eq / eq_ignore_case / comparisons + the level-parallel replace / find / le / to_upper
+    must decrypt like python str (which is what the single-GPU results are checked against, too)."""
+    world = min(_n_gpus(), 4)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER if worker == "sharded" else LEVEL_WORKER)
+    env = dict(os.environ, FHS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), WORLD_SIZE=str(world),
+               FHS_TEST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(world)]
+    try:
+        rcs = [p.wait(timeout=600) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert rcs == [0] * world
