@@ -243,6 +243,8 @@ def _declare(L):
     L.fhs_dist_str_compare.restype = i
     L.fhs_debug_capture_pbs_inputs.argtypes = [vp, C.c_size_t]
     L.fhs_debug_capture_pbs_inputs.restype = i
+    L.fhs_debug_capture_live.argtypes = [vp, i]
+    L.fhs_debug_capture_live.restype = i
     L.fhs_debug_capture_read.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.fhs_debug_capture_read.restype = i
     L.fhs_set_launch_chunk.argtypes = [vp, i, sz]

@@ -172,7 +172,9 @@ class MyClientKey:
     (fhs_client_create_insecure_seeded): reproducible keys, identical on every rank, never for real data."""
 
     def __init__(self, seed=None, _handle=None):
+        import threading
         self._L = lib()
+        self._scratch, self._scratch_lock = None, threading.Lock()
         if _handle is not None:
             self._h = _handle
             return
@@ -268,10 +270,19 @@ class MyClientKey:
     def encrypt(self, string, padding, public_parameters=None, server_key=None):   # :45-65
         # the ciphertext only lives until fhs_upload_string has staged it: one scratch buffer per client, grown on demand
         # (a fresh 268 MB array per 4097-character string is 65 000 page faults before the first byte is encrypted)
+        # ctypes releases the GIL inside fhs_client_encrypt_str / fhs_upload_string (the C side is thread-safe, per-call
+        # streams): the scratch buffer is therefore guarded by a per-client lock -- two threads encrypting with one client
+        # key take turns -- and a buffer that grew beyond 320 MB (more than BASELINE's largest string, 4097
+        # characters = 268 MB) is dropped after use instead of staying pinned for the client's lifetime
         n = len(string) + padding
-        if getattr(self, "_scratch", None) is None or self._scratch.shape[0] < n:
-            self._scratch = np.empty((max(n, 64), 4, BIG_CT), np.uint64)
-        return server_key.upload_string(self.encrypt_str_raw(string, padding, out=self._scratch[:n]))
+        with self._scratch_lock:
+            if self._scratch is None or self._scratch.shape[0] < n:
+                self._scratch = np.empty((max(n, 64), 4, BIG_CT), np.uint64)
+            try:
+                return server_key.upload_string(self.encrypt_str_raw(string, padding, out=self._scratch[:n]))
+            finally:
+                if self._scratch.nbytes > (320 << 20):
+                    self._scratch = None
 
     def encrypt_no_padding(self, string, server_key=None):                         # :67-79
         return server_key.upload_string(self.encrypt_str_raw(string, 0)).chars
@@ -547,8 +558,10 @@ class MyServerKey:
                                                             len(any_diff), int(tie), C.byref(out)))
         return FheAsciiChar(self, out.value)
 
-    def capture_pbs_inputs(self, max_rows_per_level):
-        """fhs_debug_capture_pbs_inputs: sample the PBS inputs of every executed level (0 = off)."""
+    def capture_pbs_inputs(self, max_rows_per_level, live=False):
+        """fhs_debug_capture_pbs_inputs: sample the PBS inputs of every executed level (0 = off).  live: inside the
+        ordinary execution path (rotation sharing and scheduling as in production: fhs_debug_capture_live)."""
+        self.ctx._check(self.ctx._L.fhs_debug_capture_live(self.ctx._h, int(bool(live))))
         self.ctx._check(self.ctx._L.fhs_debug_capture_pbs_inputs(self.ctx._h, int(max_rows_per_level)))
 
     def read_capture(self):

@@ -149,6 +149,13 @@ int fhs_debug_capture_pbs_inputs(fhs_ctx *ctx, size_t max_rows_per_level) {
     }
     return FHS_OK;
 }
+int fhs_debug_capture_live(fhs_ctx *ctx, int on) {
+    if (!ctx) return FHS_ERR_ARG;
+    if (int rc = ctx->eng.flush()) return rc;
+    ctx->eng.capture_live = on != 0;
+    return FHS_OK;
+}
+
 int fhs_debug_capture_read(fhs_ctx *ctx, uint64_t *rows, fhs_capture_rec *recs, size_t cap, size_t *n) {
     if (!ctx || !n) return FHS_ERR_ARG;
     auto &e = ctx->eng;

@@ -295,8 +295,10 @@ int64_t Engine::lin_c2(const std::vector<Term> &terms) const {
     // Measured on the MI355X (profiles/r05_rotation_sharing_rho.txt, tools/rho_profile.py): rho falls linearly with the
     // constant difference dt from +0.45 (dt -> 0) through 0 (dt = 8) to -0.45 (dt = 15) -- the decomposition-rounding error
     // reaches every coefficient through the negacyclic product with the binary GLWE key -- and is exactly -1 at dt = 16
-    // (the same coefficient negated: such rows never share).  |rho| <= ROT_CORR = 1/2 whatever the signs:
-    //     group cost = sum c^2 + 1/2 ((sum |c|)^2 - sum c^2).
+    // (the same coefficient negated: such rows never share).  The measurement is per key and per sample (max |rho| 0.48
+    // +- 0.03 on one key, profiles/r06_margins.json repeats it on three), so the bookkeeping does not rest on it: a group
+    // is charged as FULLY correlated, |rho| <= 1, which Cauchy-Schwarz proves whatever the key and the signs:
+    //     group cost = (sum |c|)^2   (>= sum c^2 + 2 sum_{i<j} rho_ij c_i c_j for every |rho_ij| <= 1).
     int64_t c2 = 0;
     struct Grp { uint32_t rot; int64_t sum_abs, sum_c2, var; };
     Grp grp[8];
@@ -316,7 +318,7 @@ int64_t Engine::lin_c2(const std::vector<Term> &terms) const {
         grp[g].var = std::max(grp[g].var, var);
     }
     for (int g = 0; g < ng; g++)
-        c2 += (grp[g].sum_c2 + (grp[g].sum_abs * grp[g].sum_abs - grp[g].sum_c2 + 1) / 2) * grp[g].var;
+        c2 += grp[g].sum_abs * grp[g].sum_abs * grp[g].var;
     return c2;
 }
 
@@ -436,7 +438,8 @@ int Engine::flush() {
     if (dist_world > 1 && !pending_.empty())
         return ctx.fail(-3, "distributed context: pending PBS must be run with fhs_flush_plan/level_exec/level_commit");
     manual_jobs_ = false;                                     // every scheduled tick is in the stream: automatic partial flushes may resume
-    if (!capture_max_rows && balance_slots) {
+    const bool plan_capture = capture_max_rows && !capture_live;   // the all-at-once plan keeps the records (no sharing)
+    if (!plan_capture && balance_slots) {
         // round-aligned launch groups inside ONE operation as well: the levels go through the tick scheduler at row
         // granularity (plan_job), every tick is enqueued as soon as it is complete
         if (int rc = plan_job(false, false, true)) return rc;
@@ -444,7 +447,7 @@ int Engine::flush() {
             if (int rc = pump(1)) return rc;
         return 0;
     }
-    if (!capture_max_rows) return plan_job(true);             // level by level: planning overlaps execution
+    if (!plan_capture) return plan_job(true);                 // level by level: planning overlaps execution
     int rc = plan_flush();                                    // capture mode: the all-at-once plan keeps the records
     if (rc) return rc;
     for (size_t k = 0; k < plan_.levels.size(); k++)
@@ -557,8 +560,9 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                     key_terms(nodes_[ln.src], ln.src, tb, kb);
                     if (ln.lut != n.lut || ta != tb) continue;
                     // a constant difference of 16 is the SAME coefficient of the accumulator, negated (X^2048 = -1): its
-                    // error is exactly minus the other's, which no |rho| <= 1/2 bound covers -- no two members of a group
-                    // may be 16 apart (such a row joins another group of the same key, or starts one)
+                    // error is exactly minus the other's (rho = -1; the full-correlation charge of lin_c2 covers it, but a
+                    // sum a - b of the two would DOUBLE the error for no information) -- no two members of a group may be
+                    // 16 apart (such a row joins another group of the same key, or starts one)
                     const uint32_t t = (uint32_t)(((ka - kb) % 32 + 32) % 32);
                     if (used[pos] & (1u << ((t + 16) & 31))) continue;
                     used[pos] |= 1u << t;
@@ -574,8 +578,8 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                 }
             }
             if (!fol.empty()) {
-                // Sharing must not push a CONSUMER over the noise budget: extractions of one rotation are positively
-                // correlated (lin_c2), so a later bootstrap whose input sums several members of one group with the same
+                // Sharing must not push a CONSUMER over the noise budget: extractions of one rotation are
+                // correlated (lin_c2 charges them as fully correlated), so a later bootstrap whose input sums several members of one group with the same
                 // sign is charged cross terms the string layer did not see when it built that sum.  Every pending consumer
                 // is known here (deeper levels of this plan; in a partial peel the nodes still pending) -- consumers recorded
                 // later see the groups through sum_c2().  A follower whose group would take a consumer from within the
@@ -608,7 +612,7 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                     }
                     if (!multi) return;
                     int64_t plain = lin_c2(src.terms), extra = 0;      // (members are still pending: counted as independent)
-                    for (int k = 0; k < ng; k++) extra += (g[k].sum_abs * g[k].sum_abs - g[k].sum_c2 + 1) / 2;   // as lin_c2 will
+                    for (int k = 0; k < ng; k++) extra += g[k].sum_abs * g[k].sum_abs - g[k].sum_c2;   // as lin_c2 will
                     if (plain + extra <= FHS_NOISE_BUDGET_SUM_C2 || extra == 0) return;
                     for (const Term &t : src.terms)                    // the followers among this sum's terms leave their groups
                         for (size_t i = 0; i < fol.size(); i++)
@@ -678,6 +682,9 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
             }
             tl.descs.push_back(d);
             tl.lut.push_back(n.lut);
+            if (capture_max_rows && capture_live)             // level: filled in when the row runs (run_tick)
+                tl.recs.push_back(CaptureRec{0, (uint32_t)li, n.lut, d.n_terms, c2, s.kind == BlockNode::LIN ? s.konst : 0,
+                                             (uint32_t)R});
             uint64_t *o = alloc_block();
             if (!o) return ctx.fail(-2, "device block pool exhausted (hipMalloc failed)");
             tl.out.push_back(o);
@@ -803,6 +810,7 @@ int Engine::plan_job(bool run_now, bool first_level_only, bool stream_pump) {
                 dst->descs.push_back(d);
                 dst->lut.push_back(tl.lut[k]);
                 dst->out.push_back(tl.out[k]);
+                if (tl.recs.size() == tl.descs.size()) dst->recs.push_back(tl.recs[k]);
             }
             for (const ShareRow &f : tl.ext)                       // followers travel with their leader's tick
                 if (row_need[f.lead_row] == tk) dst->ext.push_back({moved[f.lead_row], f.K, f.out});
@@ -940,6 +948,30 @@ int Engine::run_tick(std::vector<TickLevel> &levels, bool sharded) {
     if (!sharded) {
         e = launch_lincomb(d_desc, d_terms, batch_in_.as<uint64_t>(), (int)width, ctx.stream);
         if (e != hipSuccess) return ctx.hip_fail(e, "lincomb launch");
+        if (capture_max_rows && capture_live) {
+            // debug only: a strided sample of every job level's PBS inputs in this launch group goes to the host
+            // (synchronous copies); the rows are the ones the production path bootstraps, shared rotations included
+            size_t row0 = 0, lvl = stats.levels - levels.size();
+            for (auto &l : levels) {
+                const size_t cnt_l = l.descs.size();
+                if (l.recs.size() == cnt_l) {
+                    const size_t stride = (cnt_l + capture_max_rows - 1) / capture_max_rows;
+                    for (size_t i = 0; i < cnt_l; i += stride) {
+                        const size_t at = capture_rows.size();
+                        capture_rows.resize(at + BIG_CT);
+                        e = hipMemcpyAsync(capture_rows.data() + at, batch_in_.as<uint64_t>() + (row0 + i) * BIG_CT, BIG_CT * 8,
+                                           hipMemcpyDeviceToHost, ctx.stream);
+                        if (e == hipSuccess) e = hipStreamSynchronize(ctx.stream);
+                        if (e != hipSuccess) return ctx.hip_fail(e, "capture download");
+                        CaptureRec r = l.recs[i];
+                        r.level = (uint32_t)lvl;
+                        capture_recs.push_back(r);
+                    }
+                }
+                row0 += cnt_l;
+                lvl++;
+            }
+        }
         if (int rc = ctx.keyswitch(batch_in_.as<uint64_t>(), width, ctx.stream)) return rc;
         uint64_t *const *d_body = n_ext ? reinterpret_cast<uint64_t *const *>(dp + off_body) : nullptr;
         if (int rc = ctx.blind_rotate(ctx.ks_buf.as<uint64_t>(), d_lut, d_luts_, nullptr, d_out, width, ctx.stream, d_body)) return rc;
@@ -1001,12 +1033,34 @@ int Engine::gather_blocks(const Bid *local, size_t n, std::vector<Bid> &out) {
     else
         while (!rc && !sched_.empty() && sched_.begin()->first <= need) rc = pump(1);
     if (rc) return rc;
+    // Extractions of ONE shared rotation are correlated (lin_c2); a gathered block comes back as a fresh node on every
+    // rank, so that relation would be lost in the exchange.  The sharded operations never send two members of one group
+    // (their partials are AND / OR results over different inputs); a caller-supplied set that does is refused rather than
+    // under-charged.  The rank's OWN blocks keep their bookkeeping across the exchange (below).
+    for (size_t k = 0; k < n; k++) {
+        const BlockNode &a = nodes_[local[k]];
+        if (a.kind != BlockNode::MAT || !a.rot) continue;
+        for (size_t q = 0; q < k; q++)
+            if (nodes_[local[q]].kind == BlockNode::MAT && nodes_[local[q]].rot == a.rot)
+                return ctx.fail(-3, "all-gather of two extractions of one shared blind rotation: their noise correlation would "
+                                    "be lost on the receivers (refresh one of them, or fhs_set_rotation_sharing(ctx, 0))");
+    }
+    auto keep_own = [&](std::vector<Bid> &got) {             // own slice: the figures this rank already tracks
+        const size_t r0 = (size_t)ctx.dist.rank * n;
+        for (size_t k = 0; k < n && r0 + k < got.size(); k++) {
+            const BlockNode &a = nodes_[local[k]];
+            if (a.kind != BlockNode::MAT) continue;
+            nodes_[got[r0 + k]].var = std::max(nodes_[got[r0 + k]].var, a.var);
+            nodes_[got[r0 + k]].rot = a.rot;
+        }
+    };
     if (planner) {
         // a planner context exchanges nothing: count the all-gather like Dist::all_gather does and hand back world * n
         // fresh single-output blocks, so that the combine DAG can be recorded and levelised (multi-GPU projections)
         ctx.dist.n_gathers++;
         ctx.dist.bytes_sent += n * row;
         for (size_t i = 0; i < world * n; i++) out.push_back(from_device(nullptr));
+        keep_own(out);
         return 0;
     }
     if (hipSetDevice(ctx.device) != hipSuccess) return ctx.fail(-2, "hipSetDevice failed");
@@ -1029,6 +1083,7 @@ int Engine::gather_blocks(const Bid *local, size_t n, std::vector<Bid> &out) {
         }
         out.push_back(b);
     }
+    keep_own(out);
     return 0;
 }
 

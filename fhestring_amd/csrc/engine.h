@@ -144,6 +144,9 @@ class Engine {
     // key; nothing here sees a secret.  capture_max_rows == 0: off.
     struct CaptureRec { uint32_t level, index, lut, n_terms; int64_t sum_c2; int32_t konst; uint32_t width; };
     size_t capture_max_rows = 0;
+    // capture_live: sample inside the ordinary execution path (plan_job / run_tick: rotation sharing, round alignment and
+    // tick scheduling as in production) instead of the all-at-once plan of plan_flush (which never shares rotations)
+    bool capture_live = false;
     std::vector<uint64_t> capture_rows;      // [n][2049]
     std::vector<CaptureRec> capture_recs;
 
@@ -197,6 +200,7 @@ class Engine {
         std::vector<uint64_t *> out;
         std::vector<uint64_t *> body;     // empty, or per rotation row: where the accumulator's body polynomial goes (leaders)
         std::vector<ShareRow> ext;        // followers of this level's leaders
+        std::vector<CaptureRec> recs;     // per row, only while capturing live (capture_live)
         uint64_t job = 0;                 // rows of one job that land on the same tick share one TickLevel
     };
     std::map<uint64_t, std::vector<TickLevel>> sched_;            // tick -> job levels to run in that launch group

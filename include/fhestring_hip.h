@@ -355,6 +355,10 @@ typedef struct {
     uint32_t width;            /* PBS in this level */
 } fhs_capture_rec;
 int fhs_debug_capture_pbs_inputs(fhs_ctx *ctx, size_t max_rows_per_level);
+/* on != 0: sample inside the ordinary execution path -- rotation sharing, round alignment and tick scheduling exactly as
+ * in production (tests/test_gpu_margins.py); 0 (default): through an all-at-once plan without rotation sharing.  `level`
+ * of a record then counts the job levels executed since the last fhs_reset_stats. */
+int fhs_debug_capture_live(fhs_ctx *ctx, int on);
 /* Copies up to `cap` captured rows ([2049] u64 each) and records, returns the number in *n and clears the capture;
  * rows == NULL only reports the count (nothing is cleared). */
 int fhs_debug_capture_read(fhs_ctx *ctx, uint64_t *rows, fhs_capture_rec *recs, size_t cap, size_t *n);
