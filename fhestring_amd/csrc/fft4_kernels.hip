@@ -53,8 +53,10 @@ template <bool INV, int TAU> __device__ __forceinline__ void stage8(cplx (&z)[8]
         }
     }
 }
-// the three wave-uniform stages of layout A' (every group has its own explicit twiddle, no rotation)
-template <bool INV> __device__ __forceinline__ void stagesA(cplx (&z)[8], tw_t w2, const tw_t (&w4)[2], const tw_t (&w8)[4]) {
+// the three wave-uniform stages of layout A' (every group has its own explicit twiddle, no rotation), in two parts: the
+// step next to the exchange or the transpose (forward: the LAST one, t = 64; inverse: the LAST one, t = 256) is run by the
+// caller through pipeline4 together with its stores
+template <bool INV> __device__ __forceinline__ void stagesA_head(cplx (&z)[8], tw_t w2, const tw_t (&w4)[2], const tw_t (&w8)[4]) {
     if (!INV) {
 #pragma unroll
         for (int r = 0; r < 4; r++) bf_fwd<false>(z[r], z[r + 4], w2.r, w2.i);
@@ -62,8 +64,6 @@ template <bool INV> __device__ __forceinline__ void stagesA(cplx (&z)[8], tw_t w
         for (int g = 0; g < 2; g++)
 #pragma unroll
             for (int r = 4 * g; r < 4 * g + 2; r++) bf_fwd<false>(z[r], z[r + 2], w4[g].r, w4[g].i);
-#pragma unroll
-        for (int g = 0; g < 4; g++) bf_fwd<false>(z[2 * g], z[2 * g + 1], w8[g].r, w8[g].i);
     } else {
 #pragma unroll
         for (int g = 0; g < 4; g++) bf_inv<false>(z[2 * g], z[2 * g + 1], w8[g].r, w8[g].i);
@@ -71,8 +71,89 @@ template <bool INV> __device__ __forceinline__ void stagesA(cplx (&z)[8], tw_t w
         for (int g = 0; g < 2; g++)
 #pragma unroll
             for (int r = 4 * g; r < 4 * g + 2; r++) bf_inv<false>(z[r], z[r + 2], w4[g].r, w4[g].i);
-#pragma unroll
-        for (int r = 0; r < 4; r++) bf_inv<false>(z[r], z[r + 4], w2.r, w2.i);
+    }
+}
+
+// Round 6 (profiles/r06_fft4_timeline_before.txt): a lone ciphertext overlaps nothing -- its FP64 issue (4.5 k cycles per
+// iteration), its LDS traffic (4.5 k: ds_write_b128 moves 79 B/clk per CU, the four wavefronts store in the same phases),
+// the tail of the key loads (1.4 k) and the write -> barrier -> read exposures (2.7 k) simply add up.  Two remedies, both
+// pure instruction ORDER (same butterflies on the same values: the same CPU mirror, bit for bit):
+//   FFT4_OVERLAP  the stores of every exchange / transpose are issued from inside the stage that produces their data:
+//                 the two registers a butterfly finishes are stored while the next butterfly computes (pipeline4), and
+//                 the forward exchange is written while the imaginary digits are still being decomposed;
+//   FFT4_HB_WIDE  the one-workgroup-per-CU kernel requests ALL key rows of the iteration (8 chunks per row) before the
+//                 forward transform instead of keeping 2 in flight inside the pointwise product (one wave per SIMD may
+//                 use the whole 512-register file).
+#ifndef FFT4_OVERLAP
+#define FFT4_OVERLAP 2       // 2: one butterfly per step (measured best, 2.94 ms per 64-row level); 1: two; 0: off
+#endif
+#ifndef FFT4_HB_WIDE
+#define FFT4_HB_WIDE 8
+#endif
+//   FFT4_KEY_SPREAD  (with FFT4_HB_WIDE 8) the 16 key loads of a wavefront-iteration are requested two at a time at eight
+//                 points of the forward transform instead of back to back: a vector-memory instruction holds its
+//                 wavefront while the texture-address unit takes its 64 addresses, and the four wavefronts of the
+//                 workgroup issue in the same phase (nokey ablation: 0.44 ms per level; requesting all 16 at once, however
+//                 early, gave none of it back)
+#ifndef FFT4_KEY_SPREAD
+#define FFT4_KEY_SPREAD 1
+#endif
+// FFT4_TIMELINE (tools/fft4_timeline.py, timing experiments only; off in the product): every wavefront stamps the shader
+// clock (s_memtime) at twelve points of iterations 300..331 into a device array
+#ifdef FFT4_TIMELINE
+#define FFT4_TL_ITER0 300
+#define FFT4_TL_ITERS 32
+#define FFT4_TL_STAMPS 12
+#define FFT4_TL_MAXB 256
+__device__ unsigned long long g_fft4_tl[FFT4_TL_MAXB * 4 * FFT4_TL_ITERS * FFT4_TL_STAMPS];
+extern "C" int fhs_exp_fft4_timeline(unsigned long long *out, size_t n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fft4_tl), n * 8);
+}
+#define FFT4_TL_TOP() const bool tl_on = i >= FFT4_TL_ITER0 && i < FFT4_TL_ITER0 + FFT4_TL_ITERS && blockIdx.x < FFT4_TL_MAXB; \
+    unsigned long long *tlp = g_fft4_tl + (((size_t)blockIdx.x * 4 + w) * FFT4_TL_ITERS + (tl_on ? i - FFT4_TL_ITER0 : 0)) * FFT4_TL_STAMPS; \
+    FFT4_TL(0)
+#define FFT4_TL(k) do { __builtin_amdgcn_sched_barrier(0); if (tl_on) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+    if (lane == 0) tlp[k] = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FFT4_TL_TOP() do {} while (0)
+#define FFT4_TL(k) do {} while (0)
+#endif
+// the four butterflies bf(0..3) of a stage and the stores st(k) of the two registers butterfly k finishes
+// (OV = false, the kernel with two workgroups per CU: plain order -- a second wavefront per SIMD already fills the gaps, and
+// pinning cost 1 % there)
+template <bool OV, class BF, class ST> __device__ __forceinline__ void pipeline4(BF bf, ST st) {
+    if (OV && FFT4_OVERLAP == 2) {                            // one butterfly per step, two stores at the tail
+        bf(0);
+        __builtin_amdgcn_sched_barrier(0);
+        st(0); bf(1);
+        __builtin_amdgcn_sched_barrier(0);
+        st(1); bf(2);
+        __builtin_amdgcn_sched_barrier(0);
+        st(2); bf(3);
+        __builtin_amdgcn_sched_barrier(0);
+        st(3);
+    } else if (OV) {                                          // (FFT4_OVERLAP 1: 3.02 ms)
+        bf(0); bf(1);
+        __builtin_amdgcn_sched_barrier(0);
+        st(0); bf(2);
+        __builtin_amdgcn_sched_barrier(0);
+        st(1); bf(3);
+        __builtin_amdgcn_sched_barrier(0);
+        st(2); st(3);
+    } else {
+        bf(0); bf(1); bf(2); bf(3);
+        st(0); st(1); st(2); st(3);
+    }
+}
+// butterfly k of the last in-lane stage of a layout: TAU = 1 pairs registers (2k, 2k + 1) with twiddle a, i a, b, i b
+// (stage8<INV, 1>), TAU = 4 pairs (k, k + 4) with twiddle a (stage8<INV, 4>)
+template <bool INV, int TAU> __device__ __forceinline__ void last_bf(cplx (&z)[8], int k, tw_t a, tw_t b) {
+    if (TAU == 1) {
+        const tw_t w = k < 2 ? a : b;
+        if (k & 1) { if (INV) bf_inv<true>(z[2 * k], z[2 * k + 1], w.r, w.i); else bf_fwd<true>(z[2 * k], z[2 * k + 1], w.r, w.i); }
+        else       { if (INV) bf_inv<false>(z[2 * k], z[2 * k + 1], w.r, w.i); else bf_fwd<false>(z[2 * k], z[2 * k + 1], w.r, w.i); }
+    } else {
+        if (INV) bf_inv<false>(z[k], z[k + 4], a.r, a.i); else bf_fwd<false>(z[k], z[k + 4], a.r, a.i);
     }
 }
 
@@ -89,6 +170,8 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = w >> 1, h = w & 1;
     constexpr int AREA = 4 * F4_WAVE_BYTES;
+    constexpr bool OVERLAP = WIDE && FFT4_OVERLAP;
+    constexpr bool EARLY_X = OVERLAP;
     char *const xbase = smem + (WIDE ? AREA : 0), *const mbase = smem + (WIDE ? 2 * AREA : 0), *const pbase = smem + (WIDE ? 3 * AREA : 0);
     cplx *mine = reinterpret_cast<cplx *>(mbase + w * F4_WAVE_BYTES);                      // private transposes
     cplx *xmine = reinterpret_cast<cplx *>(xbase + w * F4_WAVE_BYTES);                     // cross-half exchange, own half
@@ -152,8 +235,10 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         const uint32_t s = a & (POLY_N - 1);
         const bool neg = a >= POLY_N;
 
+        FFT4_TL_TOP();
         // ---- rotate, subtract, decompose: z[r] = digit(k(r)) + i digit(k(r) + 1024) -------------------------------
         __syncthreads();                              // staged accumulator of both halves visible
+        FFT4_TL(1);
         cplx z[8];
         // as in fft_kernels.hip: lane rotation by s mod 64 (per-lane base), row rotation by s div 64 (scalar offset per
         // register; this wave's register r is row 8 h + (r & 7) + 16 (r >> 3)), borrowing lanes one row lower
@@ -187,8 +272,12 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
             const uint32_t nhi = rot_sub_hi_compl(v, acc[r], wrapmask ^ keep_unless_wrapped);
             const int32_t dig = (int32_t)(0xFFu - nhi) >> 9;
             if (r < 8) z[r].r = (double)dig; else z[r - 8].i = (double)dig;
+            // WIDE: the exchange area is this wavefront's own, so point r - 8 goes out as soon as its imaginary digit exists
+            // (the partner's last read of it was before barrier 4 of the previous iteration)
+            if (EARLY_X && r >= 8) xmine[pslot(lane + 64 * (r - 8))] = z[r - 8];
             __builtin_amdgcn_sched_barrier(0);
         }
+        FFT4_TL(2);
         if (!WIDE) __syncthreads();                   // all rotated reads done before the area is reused
 
         // key rows of this iteration: own transform first (row j), then the partner polynomial's (row 1-j), column j;
@@ -197,17 +286,27 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         const size_t koff = (size_t)(8 * (lane & 1)) * 64 + 32 * h + (lane >> 1);
         const double2_t *b_own = reinterpret_cast<const double2_t *>(P.bsk_fft) + ((((size_t)i * 2 + j) * 2 + j)) * FM + koff;
         const double2_t *b_par = reinterpret_cast<const double2_t *>(P.bsk_fft) + ((((size_t)i * 2 + (1 - j)) * 2 + j)) * FM + koff;
-        constexpr int HB = 2;
+        constexpr int HB = WIDE ? FFT4_HB_WIDE : 2;
         double2_t bo[HB], bp[HB];
+        constexpr bool SPREAD = WIDE && FFT4_KEY_SPREAD && HB == 8;
+        // SPREAD: chunk k is requested at point k of the forward transform, pinned there
+#define FFT4_LDK(k) do { if (SPREAD) { __builtin_amdgcn_sched_barrier(0); bo[k] = b_own[(k) * 64]; bp[k] = b_par[(k) * 64]; \
+                                        __builtin_amdgcn_sched_barrier(0); } } while (0)
+        if (!SPREAD) {
 #pragma unroll
-        for (int k = 0; k < HB; k++) { bo[k] = b_own[k * 64]; bp[k] = b_par[k * 64]; }
+            for (int k = 0; k < HB; k++) { bo[k] = b_own[k * 64]; bp[k] = b_par[k * 64]; }
+        }
+        FFT4_LDK(0);
 
         // ---- forward transform -------------------------------------------------------------------------------
         __builtin_amdgcn_s_setprio(1);
         {   // stage t = 512 across the two halves: (a, b) = (lower, upper) point, this half keeps its own output
+            if (!EARLY_X) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) xmine[pslot(lane + 64 * r)] = z[r];
+                for (int r = 0; r < 8; r++) xmine[pslot(lane + 64 * r)] = z[r];
+            }
             __syncthreads();
+            FFT4_TL(3);
             // all 8 partner points requested first, ONE wave-uniform branch around the butterflies (a branch and a
             // serialized LDS round trip per point before)
             cplx o[8];
@@ -222,9 +321,12 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
             }
             if (!WIDE) __syncthreads();               // the partner has read this half's points
         }
-        stagesA<false>(z, w2, w4, w8);
-#pragma unroll
-        for (int r = 0; r < 8; r++) mine[pslot(lane + 64 * r)] = z[r];
+        FFT4_TL(4);
+        FFT4_LDK(1);
+        stagesA_head<false>(z, w2, w4, w8);
+        FFT4_LDK(2);
+        pipeline4<OVERLAP>([&](int k) { bf_fwd<false>(z[2 * k], z[2 * k + 1], w8[k].r, w8[k].i); },
+                  [&](int k) { mine[pslot(lane + 64 * (2 * k))] = z[2 * k]; mine[pslot(lane + 64 * (2 * k + 1))] = z[2 * k + 1]; });
         __builtin_amdgcn_wave_barrier();
         {
             const cplx *rd = mine + pslot(64 * (lane >> 3)) + (lane & 7);     // pslot(64 a + 8 r + b) = 72 a + 9 r + b
@@ -232,15 +334,15 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
             for (int r = 0; r < 8; r++) z[r] = rd[9 * r];
         }
         __builtin_amdgcn_wave_barrier();
+        FFT4_LDK(3);
         {
             stage8<false, 4>(z, t32, t32);
+            FFT4_LDK(4);
             stage8<false, 2>(z, t16, t16);
-            stage8<false, 1>(z, t8a, t8b);
-        }
-        {
+            FFT4_LDK(5);
             cplx *wr = mine + pslot(64 * (lane >> 3)) + (lane & 7);
-#pragma unroll
-            for (int r = 0; r < 8; r++) wr[9 * r] = z[r];
+            pipeline4<OVERLAP>([&](int k) { last_bf<false, 1>(z, k, t8a, t8b); },
+                      [&](int k) { wr[9 * (2 * k)] = z[2 * k]; wr[9 * (2 * k + 1)] = z[2 * k + 1]; });
         }
         __builtin_amdgcn_wave_barrier();
         {
@@ -249,21 +351,27 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
             for (int c = 0; c < 8; c++) z[c] = rd[c];
         }
         __builtin_amdgcn_wave_barrier();
+        FFT4_LDK(6);
+        FFT4_TL(5);                                   // (before the last three in-wave stages: layout C')
+        // ---- last forward stage + publish, pointwise multiply-accumulate with GGSW_i ---------------------------------
         {
             stage8<false, 4>(z, t4, t4);
+            FFT4_LDK(7);
             stage8<false, 2>(z, t2, t2);
-            stage8<false, 1>(z, t1a, t1b);
+            pipeline4<OVERLAP>([&](int k) { last_bf<false, 1>(z, k, t1a, t1b); },
+                      [&](int k) { pmine[(2 * k) * 64 + lane] = z[2 * k]; pmine[(2 * k + 1) * 64 + lane] = z[2 * k + 1]; });
         }
-
-        // ---- publish, pointwise multiply-accumulate with GGSW_i -------------------------------------------------
-#pragma unroll
-        for (int c = 0; c < 8; c++) pmine[c * 64 + lane] = z[c];
         __syncthreads();
+        FFT4_TL(6);
         __builtin_amdgcn_s_setprio(2);
+        cplx og[8];                                   // the partner's 8 points, all requested before the first product
+#pragma unroll
+        for (int c = 0; c < 8; c++) og[c] = other[c * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             const int k = c % HB;
-            const cplx g = other[c * 64 + lane];
+            const cplx g = og[c];
             const double fr = z[c].r, fi = z[c].i;
             double rr = fr * bo[k].x; rr = __builtin_fma(-fi, bo[k].y, rr);
             rr = __builtin_fma(g.r, bp[k].x, rr); rr = __builtin_fma(-g.i, bp[k].y, rr);
@@ -272,19 +380,18 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
             z[c].r = rr; z[c].i = ii;
             if (c + HB < 8) { bo[k] = b_own[(c + HB) * 64]; bp[k] = b_par[(c + HB) * 64]; }
         }
+#undef FFT4_LDK
         if (!WIDE) __syncthreads();                   // the other polynomial has read this wave's transform
         __builtin_amdgcn_s_setprio(0);
 
+        FFT4_TL(7);
         // ---- inverse transform -------------------------------------------------------------------------------
         {
             stage8<true, 1>(z, t1a, t1b);
             stage8<true, 2>(z, t2, t2);
-            stage8<true, 4>(z, t4, t4);
-        }
-        {
             cplx *wr = mine + 9 * lane;
-#pragma unroll
-            for (int c = 0; c < 8; c++) wr[c] = z[c];
+            pipeline4<OVERLAP>([&](int k) { last_bf<true, 4>(z, k, t4, t4); },
+                      [&](int k) { wr[k] = z[k]; wr[k + 4] = z[k + 4]; });
         }
         __builtin_amdgcn_wave_barrier();
         {
@@ -296,22 +403,21 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         {
             stage8<true, 1>(z, t8a, t8b);
             stage8<true, 2>(z, t16, t16);
-            stage8<true, 4>(z, t32, t32);
-        }
-        {
             cplx *wr = mine + pslot(64 * (lane >> 3)) + (lane & 7);
-#pragma unroll
-            for (int r = 0; r < 8; r++) wr[9 * r] = z[r];
+            pipeline4<OVERLAP>([&](int k) { last_bf<true, 4>(z, k, t32, t32); },
+                      [&](int k) { wr[9 * k] = z[k]; wr[9 * (k + 4)] = z[k + 4]; });
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 8; r++) z[r] = mine[pslot(lane + 64 * r)];
         __builtin_amdgcn_wave_barrier();
-        stagesA<true>(z, w2, w4, w8);
-        {   // stage t = 512 across the two halves
-#pragma unroll
-            for (int r = 0; r < 8; r++) xmine[pslot(lane + 64 * r)] = z[r];
+        FFT4_TL(8);                                   // (before the last three in-wave stages: layout A')
+        stagesA_head<true>(z, w2, w4, w8);
+        {   // last in-wave stage (t = 256) + stage t = 512 across the two halves
+            pipeline4<OVERLAP>([&](int k) { bf_inv<false>(z[k], z[k + 4], w2.r, w2.i); },
+                      [&](int k) { xmine[pslot(lane + 64 * k)] = z[k]; xmine[pslot(lane + 64 * (k + 4))] = z[k + 4]; });
             __syncthreads();
+            FFT4_TL(9);
             cplx o[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) o[r] = pair[pslot(lane + 64 * r)];
@@ -325,6 +431,7 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
             if (!WIDE) __syncthreads();               // the partner has read this half's points
         }
 
+        FFT4_TL(10);
         // ---- back to the torus, update and restage the accumulator -------------------------------------------
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -335,6 +442,7 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
             if (r == 0 && h == 0) stage[64 + 2048 + lane] = acc[0];
             if (r == 7 && h == 1) stage[lane] = acc[15];
         }
+        FFT4_TL(11);
     }
 
     uint64_t *out = P.out_ptrs ? P.out_ptrs[ct] : P.out + (size_t)ct * BIG_CT;
@@ -363,7 +471,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     fft4_bootstrap<false>(P, smem, blockIdx.x);
 }
 // batches of at most one ciphertext per CU: four LDS areas (136 KB per workgroup), 4 instead of 8 barriers per iteration
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void blind_rotate_fft4_wide_kernel(BlindRotateFftParams P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void blind_rotate_fft4_wide_kernel(BlindRotateFftParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     fft4_bootstrap<true>(P, smem, blockIdx.x);
 }

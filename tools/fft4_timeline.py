@@ -1,7 +1,9 @@
 """Where one iteration of blind_rotate_fft4_wide_kernel (narrow dependency levels) spends its time.
 
-    python tools/fft4_timeline.py build           # here (no GPU): tools/ablate_build/libfhs_fft4_<variant>.so
+    python tools/fft4_timeline.py build           # here (no GPU, needs .git): ablations of the ROUND-5 kernel (git show R5_REV)
     python tools/fft4_timeline.py run [B ...]     # on the GPU box: default B = 64 256
+    python tools/fft4_timeline.py build_ab        # here: A/B builds of the round-6 remedies + the stamped build, current source
+    python tools/fft4_timeline.py run_ab [B ...]  # on the GPU box
 
 Two instruments on copies of csrc/fft4_kernels.hip (TIMING ONLY; the product library is never touched):
 
@@ -20,17 +22,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "fhestring_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "ablate_build")
 TL_ITER0, TL_ITERS, TL_STAMPS, TL_MAXB = 300, 32, 12, 256
-SEGMENTS = ["top -> barrier 1 passed (staged accumulator visible)",
-            "rotated reads + subtract + decompose",
-            "exchange write -> barrier 2 passed",
-            "partner read + cross-half stage t=512",
-            "9 in-wave forward stages incl. 2 private transposes",
-            "publish write -> barrier 3 passed",
-            "partner transform read + pointwise x GGSW_i (key rows)",
-            "9 in-wave inverse stages incl. 2 private transposes",
-            "exchange write -> barrier 4 passed",
-            "partner read + inverse cross-half stage",
-            "to torus, accumulate, restage"]
+R5_REV = "bd97dce"           # the kernel the ablations (and profiles/r06_fft4_timeline_before.txt) describe
+SEGMENTS_R5 = ["top -> barrier 1 passed (staged accumulator visible)",
+               "rotated reads + subtract + decompose",
+               "exchange write -> barrier 2 passed",
+               "partner read + cross-half stage t=512",
+               "9 in-wave forward stages incl. 2 private transposes",
+               "publish write -> barrier 3 passed",
+               "partner transform read + pointwise x GGSW_i (key rows)",
+               "9 in-wave inverse stages incl. 2 private transposes",
+               "exchange write -> barrier 4 passed",
+               "partner read + inverse cross-half stage",
+               "to torus, accumulate, restage"]
+SEGMENTS_R6 = ["top -> barrier 1 passed (staged accumulator visible)",
+               "rotated reads + subtract + decompose (+ exchange writes from inside the loop)",
+               "barrier 2 passed",
+               "partner read + cross-half stage t=512",
+               "forward: layouts A' and B' (6 stages, 2 private transposes, 6 of the 8 key requests)",
+               "forward: layout C' (3 stages) with the publish writes -> barrier 3 passed",
+               "partner transform read + pointwise x GGSW_i",
+               "inverse: layouts C' and B' (6 stages, 2 private transposes)",
+               "inverse: layout A' (3 stages) with the exchange writes -> barrier 4 passed",
+               "partner read + inverse cross-half stage",
+               "to torus, accumulate, restage"]
+SEGMENTS = SEGMENTS_R6 if os.environ.get("FHS_LIB_PATH", "").endswith("ab_timeline.so") else SEGMENTS_R5
 
 NOP8R = 'for (int r = 0; r < 8; r++) asm volatile("" : "+v"(z[r].r), "+v"(z[r].i));'
 NOP8C = 'for (int c = 0; c < 8; c++) asm volatile("" : "+v"(z[c].r), "+v"(z[c].i));'
@@ -102,7 +117,7 @@ V["timeline"] = [
 
 def build():
     os.makedirs(OUT, exist_ok=True)
-    text = open(os.path.join(SRC, "fft4_kernels.hip")).read()
+    text = subprocess.check_output(["git", "-C", ROOT, "show", R5_REV + ":fhestring_amd/csrc/fft4_kernels.hip"], text=True)
     objs = [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith(".o") and f != "fft4_kernels.o"]
     for name, edits in V.items():
         t = text
@@ -114,6 +129,26 @@ def build():
         obj = src.replace(".hip", ".o")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", SRC,
                                "-Wno-unused-function", "-Wno-unused-variable", "-c", src, "-o", obj])
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
+                               os.path.join(OUT, "libfhs_fft4_%s.so" % name), obj] + objs + ["-lpthread", "-ldl"])
+        os.remove(obj)
+        print("built", name, flush=True)
+
+
+AB = {"ab_neither": ["-DFFT4_OVERLAP=0", "-DFFT4_HB_WIDE=2"], "ab_keys_early": ["-DFFT4_OVERLAP=0", "-DFFT4_KEY_SPREAD=0"],
+      "ab_overlap": ["-DFFT4_OVERLAP=2", "-DFFT4_HB_WIDE=2"], "ab_overlap_keys_early": ["-DFFT4_KEY_SPREAD=0"],
+      "ab_keys_spread": ["-DFFT4_OVERLAP=0"], "ab_overlap1_keys_spread": ["-DFFT4_OVERLAP=1"], "ab_all": [],
+      "ab_timeline": ["-DFFT4_TIMELINE"]}
+
+
+def build_ab():
+    """A/B of the two round-6 remedies through their macros (csrc/fft4_kernels.hip): bit-identical results by construction"""
+    os.makedirs(OUT, exist_ok=True)
+    objs = [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith(".o") and f != "fft4_kernels.o"]
+    for name, flags in AB.items():
+        obj = os.path.join(OUT, "fft4_kernels_%s.o" % name)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", SRC,
+                               "-Wno-unused-function", "-c", os.path.join(SRC, "fft4_kernels.hip"), "-o", obj] + flags)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
                                os.path.join(OUT, "libfhs_fft4_%s.so" % name), obj] + objs + ["-lpthread", "-ldl"])
         os.remove(obj)
@@ -163,14 +198,15 @@ def worker(B):
                                                                         100.0 * np.median(s) / np.median(it), name))
         print("  %5.0f cycles  sum of the segment medians; stamp 11 -> next stamp 0: %d" % (tot, np.median(t[:, :, 1:, 0] - t[:, :, :-1, 11])))
         skew = t.max(axis=1) - t.min(axis=1)                   # spread of the 4 wavefronts of a workgroup at each stamp
-        print("  spread between the 4 wavefronts of a workgroup when they reach a barrier (median cycles): b1 %d  b2 %d  b3 %d  b4 %d" % (
+        r6 = SEGMENTS is SEGMENTS_R6                            # (stamps taken just BEFORE each barrier: 0, 2, 5 / 8, 8 / 11)
+        print("  spread between the 4 wavefronts of a workgroup at the stamp in front of each barrier (median cycles): b1 %d  b2 %d  b3/b4 (last stamps before them) %d %d" % (
             np.median(skew[..., 0]), np.median(skew[..., 2]), np.median(skew[..., 5]), np.median(skew[..., 8])))
     ctx.close()
 
 
-def run(sizes):
+def run(sizes, names=None):
     for B in sizes:
-        for name in V:
+        for name in (names or V):
             lib = os.path.join(OUT, "libfhs_fft4_%s.so" % name)
             env = dict(os.environ, FHS_LIB_PATH=lib)
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "worker", str(B)], capture_output=True, text=True,
@@ -182,6 +218,10 @@ def run(sizes):
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
+    elif sys.argv[1] == "build_ab":
+        build_ab()
+    elif sys.argv[1] == "run_ab":
+        run([int(a) for a in sys.argv[2:]] or [8, 64, 256, 300, 512], list(AB))
     elif sys.argv[1] == "worker":
         worker(int(sys.argv[2]))
     else:
