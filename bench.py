@@ -266,6 +266,13 @@ class Workload:
             if op == "replace" and D is not None:
                 D.level_parallel(True)
 
+    def amortisation(self, skew):
+        """what `ms_per_op` means: the step's wall time over its independent strings"""
+        if self.n_strings <= 1:
+            return ""
+        return "; ms_per_op is AMORTISED over %d independent strings per step%s -- one op alone = single_op_latency_ms" % (
+            self.n_strings, " (level-skewed batching)" if skew else "")
+
     def describe(self):
         names = {"contains": "contains_clear", "find_enc": "find (encrypted pattern)", "replace": "replace (encrypted from/to, 5 -> 5)",
                  "eq_ignore_case": "eq_ignore_case", "le": "le (<=)"}
@@ -349,6 +356,35 @@ def cpu_baseline(n_pbs, level_widths):
     assert K.decrypt_char(r.cts()) == 1
     out["config1_eq_hello_hello"] = {"ms": dt * 1e3, "pbs": int(eng.pbs_count), "levels": int(eng.levels),
                                      "note": "reference CLI DAG as written (src/utils.rs:691-703), CPU port, %d threads" % cores}
+    # (4) BASELINE configs[1] and configs[2] RUN TO COMPLETION on the host cores: the SAME fused DAGs the
+    # GPU executes -- recorded by the product's planner (host logic, no device), replayed launch group by launch group with
+    # the CPU port's bootstrap on real ciphertexts (oracle/plan_exec.py), decrypt-checked
+    from oracle.plan_exec import PlanRun
+    rnd = random.Random(SEED + 3)
+    enc_s = lambda t, pad: np.stack([K.encrypt_char(b) for b in t.encode() + b"\0" * pad])
+    for key, n_chars, clear in (("cfg2_contains_clear_64", 64, True), ("cfg3_find_encrypted_256", 256, False)):
+        text = list(rand_text(rnd, n_chars))
+        at = min(200, n_chars - 4)
+        text[at:at + 4] = "Qz7#"
+        text = "".join(text)
+        pr = PlanRun(S, cores, mode=best_mode if best_mode else 2)
+        try:
+            es = pr.upload_string(enc_s(text, 1))
+            ep = None if clear else pr.upload_string(enc_s("Qz7#", 0))
+            pr.run()                                      # (the uploads)
+            t0 = time.perf_counter()
+            res = pr.sk.contains_clear(es, "Qz7#") if clear else pr.sk.find(es, ep.chars)
+            pr.run()
+            dt = time.perf_counter() - t0
+            got = K.decrypt_char(pr.result_char(res))
+            assert got == (1 if clear else text.find("Qz7#")), (key, got)
+            st = pr.sk.stats()
+            out[key] = {"ms": dt * 1e3, "pbs": int(pr.pbs), "launch_groups": int(pr.groups), "bootstrap_ms": pr.pbs_seconds * 1e3,
+                        "rotations_on_gpu": int(st["pbs_executed"]), "shared_extractions_on_gpu": int(st["pbs_extracted"]),
+                        "note": "the fused DAG the GPU runs, replayed on %d host threads with the CPU port's bootstrap, result "
+                                "decrypted and checked; a shared extraction is replayed as a bootstrap of its own" % cores}
+        finally:
+            pr.close()
     return out
 
 
@@ -496,6 +532,9 @@ def compact_line(full, extras_path):
                              "sample": cb["sample_short"], "ms_per_pbs_per_thread": cb["ms_per_pbs_per_thread"]}
         if "config1_eq_hello_hello" in cb:
             c["cpu_baseline"]["config1_eq_hello_hello_ms"] = cb["config1_eq_hello_hello"]["ms"]
+        for k, short in (("cfg2_contains_clear_64", "cfg2_contains_64_ms"), ("cfg3_find_encrypted_256", "cfg3_find_256_ms")):
+            if k in cb:                                  # run to completion on the host cores, decrypt-checked
+                c["cpu_baseline"][short] = cb[k]["ms"]
     if full.get("configs"):
         c["configs"] = {name: {k: e[k] for k in ("ms_per_op", "pbs", "levels", "pbs_per_s", "end_to_end_ms",
                                                 "two_queued_ms_per_op", "streamed_ms_per_op") if e.get(k) is not None}
@@ -832,7 +871,7 @@ def _main(safety, args):
                     "ms_per_step": h_dt / args.steps * 1e3, "higher_is_better": True, "scaling": wl.scaling,
                     "vs_baseline": None, "dtype": "u64" if args.arith in ("exact", "exact_mb2") else "f64",
                     "data": "synthetic",
-                    "config": {"workload": "%s, %s DAG, %s arithmetic" % (wl.describe(), args.mode, ARITH_NAME[args.arith]),
+                    "config": {"workload": "%s, %s DAG, %s arithmetic%s" % (wl.describe(), args.mode, ARITH_NAME[args.arith], wl.amortisation(SKEW)),
                                "parallelism": wl.parallelism(),
                                "transport": dists[0].transport if dists and dists[0] is not None else "single GPU"},
                     "ms_per_op": h_dt / args.steps / wl.n_strings * 1e3, "roofline": roof_h}
@@ -1363,7 +1402,7 @@ def _main(safety, args):
             "vs_baseline": None,
             "dtype": "u64" if args.arith in ("exact", "exact_mb2") else "f64",
             "data": "synthetic",
-            "config": {"workload": "%s, %s DAG, %s arithmetic" % (wl.describe(), args.mode, ARITH_NAME[args.arith]),
+            "config": {"workload": "%s, %s DAG, %s arithmetic%s" % (wl.describe(), args.mode, ARITH_NAME[args.arith], wl.amortisation(SKEW)),
                        "pipelines": args.pipelines, "launch_chunk": args.launch_chunk,
                        "scheduling": (("level-skewed batching: one context, fhs_submit + fhs_pump per step, the narrow "
                                        "levels of step k ride in the wide launch of step k+1" +

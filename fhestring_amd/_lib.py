@@ -243,6 +243,14 @@ def _declare(L):
     L.fhs_dist_str_compare.restype = i
     L.fhs_debug_capture_pbs_inputs.argtypes = [vp, C.c_size_t]
     L.fhs_debug_capture_pbs_inputs.restype = i
+    L.fhs_debug_plan_trace.argtypes = [vp, i]
+    L.fhs_debug_plan_trace.restype = i
+    L.fhs_debug_plan_read.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.fhs_debug_plan_read.restype = i
+    L.fhs_debug_char_terms.argtypes = [vp, C.c_uint64, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.fhs_debug_char_terms.restype = i
+    L.fhs_debug_lut_poly.argtypes = [i, vp]
+    L.fhs_debug_lut_poly.restype = i
     L.fhs_debug_capture_live.argtypes = [vp, i]
     L.fhs_debug_capture_live.restype = i
     L.fhs_debug_capture_read.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]

@@ -3,6 +3,7 @@
 #include <new>
 
 #include "capi_internal.h"
+#include "luts.h"
 
 extern "C" {
 
@@ -153,6 +154,46 @@ int fhs_debug_capture_live(fhs_ctx *ctx, int on) {
     if (!ctx) return FHS_ERR_ARG;
     if (int rc = ctx->eng.flush()) return rc;
     ctx->eng.capture_live = on != 0;
+    return FHS_OK;
+}
+
+int fhs_debug_plan_trace(fhs_ctx *ctx, int on) {
+    if (!ctx) return FHS_ERR_ARG;
+    if (!ctx->eng.planner) return ctx->eng.ctx.fail(FHS_ERR_STATE, "fhs_debug_plan_trace: planner contexts only (fhs_ctx_create_planner)");
+    if (int rc = ctx->eng.flush()) return rc;
+    ctx->eng.trace_plan = on != 0;
+    ctx->eng.trace_.clear();
+    return FHS_OK;
+}
+
+int fhs_debug_plan_read(fhs_ctx *ctx, uint64_t *out, size_t cap, size_t *n) {
+    if (!ctx || !n) return FHS_ERR_ARG;
+    if (int rc = ctx->eng.flush()) return rc;
+    const std::vector<uint64_t> &t = ctx->eng.trace_;
+    *n = t.size();
+    if (!out) return FHS_OK;
+    if (cap < t.size()) return ctx->eng.ctx.fail(FHS_ERR_ARG, "fhs_debug_plan_read: buffer too small");
+    std::copy(t.begin(), t.end(), out);
+    ctx->eng.trace_.clear();
+    return FHS_OK;
+}
+
+int fhs_debug_char_terms(fhs_ctx *ctx, fhs_char_t h, uint64_t *out, size_t cap, size_t *n) {
+    if (!ctx || !n || !ctx->eng.valid_char(h)) return ctx ? ctx->eng.ctx.fail(FHS_ERR_ARG, "invalid character handle") : FHS_ERR_ARG;
+    if (int rc = ctx->eng.flush()) return rc;
+    std::vector<uint64_t> v;
+    const fhs::Bid *b = ctx->eng.char_blocks(h);
+    for (int k = 0; k < 4; k++) ctx->eng.describe_block(b[k], v);
+    *n = v.size();
+    if (!out) return FHS_OK;
+    if (cap < v.size()) return ctx->eng.ctx.fail(FHS_ERR_ARG, "fhs_debug_char_terms: buffer too small");
+    std::copy(v.begin(), v.end(), out);
+    return FHS_OK;
+}
+
+int fhs_debug_lut_poly(int lut_id, uint64_t *out) {
+    if (!out || lut_id < 0 || lut_id >= fhs::LUT_COUNT) return FHS_ERR_ARG;
+    fhs::make_lut_poly(lut_id, out);
     return FHS_OK;
 }
 

@@ -141,6 +141,7 @@ Bid Engine::from_host(const uint64_t *ct) {
     Bid id = new_node();
     nodes_[id].kind = BlockNode::MAT;
     nodes_[id].dev = d;
+    if (planner && trace_plan) { trace_.push_back(TR_UPLOAD); trace_.push_back((uint64_t)(uintptr_t)d); }
     return id;
 }
 
@@ -280,6 +281,19 @@ Bid Engine::lin(const Term *terms, size_t n, int konst) {
     nn.level = lvl;
     nn.terms = std::move(flat);
     return id;
+}
+
+void Engine::describe_block(Bid b, std::vector<uint64_t> &out) const {
+    const BlockNode &n = nodes_[b];
+    if (n.kind == BlockNode::TRIV) { out.insert(out.end(), {0, (uint64_t)(triv_val(b) & 31), 0}); return; }
+    if (n.kind == BlockNode::MAT) { out.insert(out.end(), {1, 0, 1, (uint64_t)(uintptr_t)n.dev, 1}); return; }
+    if (n.kind != BlockNode::LIN) { out.insert(out.end(), {3, 0, 0}); return; }
+    out.insert(out.end(), {2, (uint64_t)(n.konst & 31), (uint64_t)n.terms.size()});
+    for (const Term &t : n.terms) {
+        const BlockNode &tb = nodes_[t.blk];
+        out.push_back(tb.kind == BlockNode::MAT ? (uint64_t)(uintptr_t)tb.dev : 0);
+        out.push_back((uint64_t)t.coef);
+    }
 }
 
 int64_t Engine::sum_c2(Bid b) const {
@@ -888,6 +902,30 @@ int Engine::run_tick(std::vector<TickLevel> &levels, bool sharded) {
     if (n_ext && sharded) return ctx.fail(-3, "internal: rotation sharing in a level-parallel launch group");
     stats.pbs_extracted += n_ext;
     if (stats.group_rows.size() < (1u << 20)) stats.group_rows.push_back((uint32_t)cnt);
+    if (planner && trace_plan) {
+        for (auto &l : levels) {
+            for (size_t k = 0; k < l.descs.size(); k++) {
+                const LinDesc &d = l.descs[k];
+                trace_.push_back(TR_ROW);
+                trace_.push_back((uint64_t)(uintptr_t)l.out[k]);
+                trace_.push_back(l.lut[k]);
+                trace_.push_back(d.konst_body >> DELTA_LOG);
+                trace_.push_back(d.n_terms);
+                for (uint32_t t = 0; t < d.n_terms; t++) {
+                    trace_.push_back((uint64_t)(uintptr_t)l.terms[d.first_term + t].src);
+                    trace_.push_back((uint64_t)l.terms[d.first_term + t].coef);
+                }
+            }
+            for (const ShareRow &f : l.ext) {
+                trace_.push_back(TR_EXT);
+                trace_.push_back((uint64_t)(uintptr_t)l.out[f.lead_row]);
+                trace_.push_back((uint64_t)(uintptr_t)f.out);
+                trace_.push_back(f.K);
+            }
+        }
+        trace_.push_back(TR_GROUP_END);
+        trace_.push_back(width);
+    }
     if (planner) {
         // nothing runs, but the exchange of a level-parallel launch group is accounted for like Dist::all_gather does
         if (sharded) { ctx.dist.n_gathers++; ctx.dist.bytes_sent += cap * BIG_CT * 8; }

@@ -150,6 +150,17 @@ class Engine {
     std::vector<uint64_t> capture_rows;      // [n][2049]
     std::vector<CaptureRec> capture_recs;
 
+    // ---- debug: plan trace (planner contexts; tests and bench.py's CPU-baseline leg) ----
+    // While on, a planner context writes what it WOULD run as a flat list of 64-bit words (block tokens are the planner's
+    // unique fake pointers): uploads in order, every launch group row by row (output token, LUT id, constant, terms), the
+    // shared extractions, a group end.  A host executor replays it with any PBS implementation -- the CPU oracle runs the
+    // product's fused DAGs that way (the checker's plan_exec.py); nothing in the product reads it back.
+    enum : uint64_t { TR_UPLOAD = 1, TR_ROW = 2, TR_EXT = 3, TR_GROUP_END = 4 };
+    bool trace_plan = false;
+    std::vector<uint64_t> trace_;
+    // [kind 0 TRIV / 1 MAT / 2 LIN / 3 pending, value or constant, n_terms, (token, coef)...] of one block
+    void describe_block(Bid b, std::vector<uint64_t> &out) const;
+
     // ---- char handles (fhs_char_t) ----
     struct CharRec { Bid b[4]; bool used; };
     uint64_t new_char(const Bid b[4]);   // takes over the 4 references

@@ -363,6 +363,23 @@ int fhs_debug_capture_live(fhs_ctx *ctx, int on);
  * rows == NULL only reports the count (nothing is cleared). */
 int fhs_debug_capture_read(fhs_ctx *ctx, uint64_t *rows, fhs_capture_rec *recs, size_t cap, size_t *n);
 
+/* ---- debug: plan trace of a planner context (tests/test_plan_exec.py; bench.py's CPU-baseline leg) --------------
+ * While on, a planner context (fhs_ctx_create_planner: no device) writes what it WOULD run as 64-bit words; block tokens
+ * are the planner's unique fake pointers:
+ *   1 token                                    an uploaded block, in upload order
+ *   2 out lut konst n (token coef) x n         one bootstrap: LUT `lut` of sum coef * block + konst * 2^59 -> block `out`
+ *   3 leader_out out K                         a shared extraction: coefficient K of the accumulator of `leader_out`'s row
+ *                                              (= that row's bootstrap with konst + K / 128)
+ *   4 width                                    end of a launch group (its rows are independent of one another)
+ * A host executor replays the list with any bootstrap implementation: the CPU oracle runs the product's fused DAGs on
+ * real ciphertexts this way (oracle/plan_exec.py).  fhs_debug_char_terms describes a result handle after the flush, per
+ * block: kind (0 plaintext, 1 block, 2 linear combination), value or konst, n, (token coef) x n.  fhs_debug_lut_poly:
+ * the catalogue's body polynomial [2048] of a LUT id (csrc/luts.h). */
+int fhs_debug_plan_trace(fhs_ctx *ctx, int on);
+int fhs_debug_plan_read(fhs_ctx *ctx, uint64_t *out, size_t cap, size_t *n);
+int fhs_debug_char_terms(fhs_ctx *ctx, fhs_char_t h, uint64_t *out, size_t cap, size_t *n);
+int fhs_debug_lut_poly(int lut_id, uint64_t *out);
+
 /* ---- statistics ----------------------------------------------------------------
  * fhs_stats grows at its END when a counter is added (round 5: pbs_extracted): a host must be compiled against the
  * header of the library it loads -- fhs_get_stats writes sizeof(fhs_stats) bytes of THAT build.  (build() recompiles

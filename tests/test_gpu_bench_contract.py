@@ -84,6 +84,10 @@ def test_bench_json_line_contract(tmp_path):
     lc = line["cpu_baseline"]
     assert set(lc) >= {"value", "unit", "cores", "kind", "sample"} and lc["kind"] == "port" and lc["value"] > 0
     assert len(lc["sample"]) < 200
+    # configs 1-3 run to completion on the CPU port, decrypt-checked inside bench.py (oracle/plan_exec.py
+    # replays the product's own fused DAG): far slower than the same op on the GPU
+    assert lc["cfg3_find_256_ms"] > 20 * line["configs"]["cfg3_find_encrypted_256"]["ms_per_op"] > 0
+    assert lc["cfg2_contains_64_ms"] > 20 * line["single_op_latency_ms"] > 0 and lc["config1_eq_hello_hello_ms"] > 0
     for k in ("cfg3_find_encrypted_256", "cfg4_replace_1024", "cfg5_eq_ignore_case_4096", "cfg5_le_4096"):
         e = line["configs"][k]
         assert e["ms_per_op"] > 0 and e["pbs"] > 1000 and e["levels"] > 0
@@ -104,6 +108,8 @@ def test_bench_json_line_contract(tmp_path):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
     assert c["config1_eq_hello_hello"]["ms"] > 0 and c["config1_eq_hello_hello"]["pbs"] > 100
+    assert c["cfg3_find_encrypted_256"]["pbs"] == d["configs"]["cfg3_find_encrypted_256"]["pbs"] == 2574     # the SAME DAG
+    assert c["cfg2_contains_clear_64"]["pbs"] == c["cfg2_contains_clear_64"]["rotations_on_gpu"] + c["cfg2_contains_clear_64"]["shared_extractions_on_gpu"]
     # SURVEY 8(d) timing protocol
     assert len(d["repeat_ms_per_step"]) == 5 and d["median_ms_per_step"] > 0
     assert d["end_to_end_ms"] > d["single_op_latency_ms"] > 0
