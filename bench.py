@@ -392,7 +392,7 @@ def load_counters():
     """Hardware-counted figures of the committed kernels (rocprofv3 --pmc passes of THIS bench command, profiles/README.md):
     round 3's for the kernels re-profiled this round, round 2's for the others."""
     out = {}
-    for name in ("r02_counters.json", "r03_counters.json", "r04_counters.json", "r05_counters.json"):
+    for name in ("r02_counters.json", "r03_counters.json", "r04_counters.json", "r05_counters.json", "r06_counters.json"):
         try:
             out.update(json.load(open(os.path.join(ROOT, "profiles", name))))
         except Exception:
