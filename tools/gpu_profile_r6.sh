@@ -21,6 +21,9 @@ BB="python3 bench.py --steps 20 --warmup 3 --cpu-pbs 0 --skip-single-op --skip-s
 run bench_stats rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- $BB
 run bench_fetch rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/bench_fetch -- $BB
 run bench_write rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/bench_write -- $BB
-find $O -name "*kernel_trace.csv" -size +1M -delete
+
 find $O -name "*agent_info.csv" -delete
 cat $O/status.txt; tail -1 $O/bench_stats.log | cut -c1-700; find $O/bench_stats $O/n64_stats -name "*kernel_stats.csv" | xargs head -6
+run single_trace rocprofv3 --kernel-trace --output-format csv -d $O/single_trace -- python3 tools/single_op_trace.py
+python3 tools/single_op_trace.py gaps $O/single_trace > $O/single_op_gaps.txt 2>&1; cat $O/single_trace.log $O/single_op_gaps.txt
+find $O -name "*kernel_trace.csv" -size +1M -delete; find $O -name "*agent_info.csv" -delete
