@@ -98,6 +98,57 @@ template <bool INV> __device__ __forceinline__ void stagesA_head(cplx (&z)[8], t
 #ifndef FFT4_KEY_SPREAD
 #define FFT4_KEY_SPREAD 1
 #endif
+//   FFT4_REG_T1 / FFT4_REG_T2  (experiments, OFF: measured and not adopted, profiles/r06_fft4_ab_timeline.txt) the private
+//                 transposes inside the register file instead of through LDS: v_permlane32_swap / v_permlane16_swap exchange
+//                 lane bit 5 / 4 with a register bit, row_ror:8 / row_shr:4 / row_shl:4 moves under bank masks do it for lane
+//                 bits 3 / 2, quad_perm moves + selects for bits 1 / 0.  The results are layouts B' / C' exactly (same digest),
+//                 but 80-160 cross-lane VALU instructions per transpose take as long as its LDS round trip: A' <-> B' in
+//                 registers 2.914 vs 2.923 ms per level, both transposes 3.11 ms.
+#ifndef FFT4_REG_T1
+#define FFT4_REG_T1 0
+#endif
+#ifndef FFT4_REG_T2
+#define FFT4_REG_T2 0
+#endif
+// exchanges register-index bit DST (4, 2, 1) of the 8 points with lane bit log2(W): element (register bit 1, lane bit 0)
+// <-> (register bit 0, lane bit 1).  An involution: the same call undoes it.
+template <int W, int DST> __device__ __forceinline__ void reg_lane_swap(cplx (&z)[8]) {
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        if (p & DST) continue;
+        double *a[2] = {&z[p].r, &z[p].i}, *b[2] = {&z[p + DST].r, &z[p + DST].i};
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const uint64_t x = __builtin_bit_cast(uint64_t, *a[hh]), y = __builtin_bit_cast(uint64_t, *b[hh]);
+            uint32_t xw[2] = {(uint32_t)x, (uint32_t)(x >> 32)}, yw[2] = {(uint32_t)y, (uint32_t)(y >> 32)};
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                uint32_t nx, ny;
+                if (W == 32) {          // lanes 32..63 of x <-> lanes 0..31 of y
+                    auto l = __builtin_amdgcn_permlane32_swap(xw[q], yw[q], false, false); nx = l[0]; ny = l[1];
+                } else if (W == 16) {   // odd rows of x <-> even rows of y
+                    auto l = __builtin_amdgcn_permlane16_swap(xw[q], yw[q], false, false); nx = l[0]; ny = l[1];
+                } else if (W == 8) {    // row_ror:8 = lane ^ 8; banks 2, 3 = lanes with bit 3 set
+                    nx = (uint32_t)__builtin_amdgcn_update_dpp((int)xw[q], (int)yw[q], 0x128, 0xF, 0xC, false);
+                    ny = (uint32_t)__builtin_amdgcn_update_dpp((int)yw[q], (int)xw[q], 0x128, 0xF, 0x3, false);
+                } else if (W == 4) {    // row_shr:4 into banks 1, 3 (lane bit 2 set), row_shl:4 into banks 0, 2
+                    nx = (uint32_t)__builtin_amdgcn_update_dpp((int)xw[q], (int)yw[q], 0x114, 0xF, 0xA, false);
+                    ny = (uint32_t)__builtin_amdgcn_update_dpp((int)yw[q], (int)xw[q], 0x104, 0xF, 0x5, false);
+                } else {                // W = 2 / 1: quad_perm [2,3,0,1] / [1,0,3,2] = lane ^ 2 / lane ^ 1, merged by lane mask
+                    const int ctrl = W == 2 ? 0x4E : 0xB1;
+                    const uint32_t py = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)yw[q], ctrl, 0xF, 0xF, true);
+                    const uint32_t px = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xw[q], ctrl, 0xF, 0xF, true);
+                    const bool hi = (threadIdx.x & W) != 0;                         // this lane has the bit set
+                    nx = hi ? py : xw[q];
+                    ny = hi ? yw[q] : px;
+                }
+                xw[q] = nx; yw[q] = ny;
+            }
+            *a[hh] = __builtin_bit_cast(double, ((uint64_t)xw[1] << 32) | xw[0]);
+            *b[hh] = __builtin_bit_cast(double, ((uint64_t)yw[1] << 32) | yw[0]);
+        }
+    }
+}
 // FFT4_TIMELINE (tools/fft4_timeline.py, timing experiments only; off in the product): every wavefront stamps the shader
 // clock (s_memtime) at twelve points of iterations 300..331 into a device array
 #ifdef FFT4_TIMELINE
@@ -172,6 +223,8 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
     constexpr int AREA = 4 * F4_WAVE_BYTES;
     constexpr bool OVERLAP = WIDE && FFT4_OVERLAP;
     constexpr bool EARLY_X = OVERLAP;
+    constexpr bool REG_T1 = WIDE && FFT4_REG_T1;
+    constexpr bool REG_T2 = WIDE && FFT4_REG_T2;
     char *const xbase = smem + (WIDE ? AREA : 0), *const mbase = smem + (WIDE ? 2 * AREA : 0), *const pbase = smem + (WIDE ? 3 * AREA : 0);
     cplx *mine = reinterpret_cast<cplx *>(mbase + w * F4_WAVE_BYTES);                      // private transposes
     cplx *xmine = reinterpret_cast<cplx *>(xbase + w * F4_WAVE_BYTES);                     // cross-half exchange, own half
@@ -325,32 +378,49 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         FFT4_LDK(1);
         stagesA_head<false>(z, w2, w4, w8);
         FFT4_LDK(2);
-        pipeline4<OVERLAP>([&](int k) { bf_fwd<false>(z[2 * k], z[2 * k + 1], w8[k].r, w8[k].i); },
-                  [&](int k) { mine[pslot(lane + 64 * (2 * k))] = z[2 * k]; mine[pslot(lane + 64 * (2 * k + 1))] = z[2 * k + 1]; });
-        __builtin_amdgcn_wave_barrier();
-        {
-            const cplx *rd = mine + pslot(64 * (lane >> 3)) + (lane & 7);     // pslot(64 a + 8 r + b) = 72 a + 9 r + b
+        if (REG_T1) {                                 // A' -> B' inside the register file
 #pragma unroll
-            for (int r = 0; r < 8; r++) z[r] = rd[9 * r];
+            for (int k = 0; k < 4; k++) bf_fwd<false>(z[2 * k], z[2 * k + 1], w8[k].r, w8[k].i);
+            reg_lane_swap<32, 4>(z);
+            reg_lane_swap<16, 2>(z);
+            reg_lane_swap<8, 1>(z);
+        } else {
+            pipeline4<OVERLAP>([&](int k) { bf_fwd<false>(z[2 * k], z[2 * k + 1], w8[k].r, w8[k].i); },
+                      [&](int k) { mine[pslot(lane + 64 * (2 * k))] = z[2 * k]; mine[pslot(lane + 64 * (2 * k + 1))] = z[2 * k + 1]; });
+            __builtin_amdgcn_wave_barrier();
+            {
+                const cplx *rd = mine + pslot(64 * (lane >> 3)) + (lane & 7);     // pslot(64 a + 8 r + b) = 72 a + 9 r + b
+#pragma unroll
+                for (int r = 0; r < 8; r++) z[r] = rd[9 * r];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
         FFT4_LDK(3);
         {
             stage8<false, 4>(z, t32, t32);
             FFT4_LDK(4);
             stage8<false, 2>(z, t16, t16);
             FFT4_LDK(5);
-            cplx *wr = mine + pslot(64 * (lane >> 3)) + (lane & 7);
-            pipeline4<OVERLAP>([&](int k) { last_bf<false, 1>(z, k, t8a, t8b); },
-                      [&](int k) { wr[9 * (2 * k)] = z[2 * k]; wr[9 * (2 * k + 1)] = z[2 * k + 1]; });
+            if (REG_T2) {                             // B' -> C' inside the register file
+                stage8<false, 1>(z, t8a, t8b);
+                reg_lane_swap<4, 4>(z);
+                reg_lane_swap<2, 2>(z);
+                reg_lane_swap<1, 1>(z);
+            } else {
+                cplx *wr = mine + pslot(64 * (lane >> 3)) + (lane & 7);
+                pipeline4<OVERLAP>([&](int k) { last_bf<false, 1>(z, k, t8a, t8b); },
+                          [&](int k) { wr[9 * (2 * k)] = z[2 * k]; wr[9 * (2 * k + 1)] = z[2 * k + 1]; });
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        {
-            const cplx *rd = mine + 9 * lane;                                 // pslot(8 lane + c) = 9 lane + c
+        if (!REG_T2) {
+            __builtin_amdgcn_wave_barrier();
+            {
+                const cplx *rd = mine + 9 * lane;                             // pslot(8 lane + c) = 9 lane + c
 #pragma unroll
-            for (int c = 0; c < 8; c++) z[c] = rd[c];
+                for (int c = 0; c < 8; c++) z[c] = rd[c];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
         FFT4_LDK(6);
         FFT4_TL(5);                                   // (before the last three in-wave stages: layout C')
         // ---- last forward stage + publish, pointwise multiply-accumulate with GGSW_i ---------------------------------
@@ -389,28 +459,46 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         {
             stage8<true, 1>(z, t1a, t1b);
             stage8<true, 2>(z, t2, t2);
-            cplx *wr = mine + 9 * lane;
-            pipeline4<OVERLAP>([&](int k) { last_bf<true, 4>(z, k, t4, t4); },
-                      [&](int k) { wr[k] = z[k]; wr[k + 4] = z[k + 4]; });
+            if (REG_T2) {                             // C' -> B' inside the register file
+                stage8<true, 4>(z, t4, t4);
+                reg_lane_swap<1, 1>(z);
+                reg_lane_swap<2, 2>(z);
+                reg_lane_swap<4, 4>(z);
+            } else {
+                cplx *wr = mine + 9 * lane;
+                pipeline4<OVERLAP>([&](int k) { last_bf<true, 4>(z, k, t4, t4); },
+                          [&](int k) { wr[k] = z[k]; wr[k + 4] = z[k + 4]; });
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        {
-            const cplx *rd = mine + pslot(64 * (lane >> 3)) + (lane & 7);
+        if (!REG_T2) {
+            __builtin_amdgcn_wave_barrier();
+            {
+                const cplx *rd = mine + pslot(64 * (lane >> 3)) + (lane & 7);
 #pragma unroll
-            for (int r = 0; r < 8; r++) z[r] = rd[9 * r];
+                for (int r = 0; r < 8; r++) z[r] = rd[9 * r];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
         {
             stage8<true, 1>(z, t8a, t8b);
             stage8<true, 2>(z, t16, t16);
-            cplx *wr = mine + pslot(64 * (lane >> 3)) + (lane & 7);
-            pipeline4<OVERLAP>([&](int k) { last_bf<true, 4>(z, k, t32, t32); },
-                      [&](int k) { wr[9 * k] = z[k]; wr[9 * (k + 4)] = z[k + 4]; });
+            if (REG_T1) {                             // B' -> A' inside the register file
+                stage8<true, 4>(z, t32, t32);
+                reg_lane_swap<8, 1>(z);
+                reg_lane_swap<16, 2>(z);
+                reg_lane_swap<32, 4>(z);
+            } else {
+                cplx *wr = mine + pslot(64 * (lane >> 3)) + (lane & 7);
+                pipeline4<OVERLAP>([&](int k) { last_bf<true, 4>(z, k, t32, t32); },
+                          [&](int k) { wr[9 * k] = z[k]; wr[9 * (k + 4)] = z[k + 4]; });
+            }
         }
-        __builtin_amdgcn_wave_barrier();
+        if (!REG_T1) {
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 8; r++) z[r] = mine[pslot(lane + 64 * r)];
-        __builtin_amdgcn_wave_barrier();
+            for (int r = 0; r < 8; r++) z[r] = mine[pslot(lane + 64 * r)];
+            __builtin_amdgcn_wave_barrier();
+        }
         FFT4_TL(8);                                   // (before the last three in-wave stages: layout A')
         stagesA_head<true>(z, w2, w4, w8);
         {   // last in-wave stage (t = 256) + stage t = 512 across the two halves
