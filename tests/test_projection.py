@@ -2,7 +2,7 @@
 transport attached records the library's REAL sharded entry points for any (rank, world) -- what each rank would launch
 and exchange is exact, only the times of tools/project_multi_gpu.py are a model.  Pinned here: PBS per rank, launch
 groups, ncclAllGather calls and bytes for BASELINE configs 3-5 and the 4096-character contains, the committed projection
-(profiles/r05_multi_gpu_projection.json) being what the tool computes today, and the model's N = 1 column within 10 % of
+(profiles/r06_multi_gpu_projection.json) being what the tool computes today, and the model's N = 1 column within 10 % of
 the single-GPU times measured on the MI355X."""
 import json
 import os
@@ -73,7 +73,7 @@ def test_level_parallel_replace_counts():
 
 
 def test_committed_projection_is_current_and_labelled():
-    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_multi_gpu_projection.json")))
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r06_multi_gpu_projection.json")))
     assert rec["label"].startswith("PROJECTED") and "ASSUMED" in rec["label"]
     assert rec["model"] == pm.MODEL
     now = pm.project("cfg3_find_encrypted_256", pm.op_find(256))

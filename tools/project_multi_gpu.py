@@ -10,13 +10,13 @@ established without hardware is exactly what every rank would launch and exchang
     ncclAllGather calls and bytes (fhs_dist_stats).  These COUNTS are exact and pinned by tests/test_projection.py.
 
 The TIMES are a model, labelled `projected` everywhere, built from three figures measured on ONE MI355X (profiles/r04_*,
-r05_*): a round of <= 1024 rows of blind_rotate_fft_kernel (7.6 ms), a narrow launch of blind_rotate_fft4_kernel (3.55 ms
+r05_*): a round of <= 1024 rows of blind_rotate_fft_kernel (7.6 ms), a narrow launch of blind_rotate_fft4_kernel (2.95 ms
 up to 256 rows, 6.1 ms at 512), keyswitch + lincomb (0.08 ms per 1024 rows) -- plus an ASSUMED RCCL all-gather cost over
 xGMI (latency 40 us; ring bandwidth 48 GB/s per link, MI355X_MICROARCH.md: 7 links x ~153 GB/s bidirectional peak per
 GPU, ~64 GB/s unidirectional per link, 75 % achieved).  The N = 1 column is compared with the measured single-GPU times,
 which bounds the model error of the compute part; the exchange part is an assumption until the driver's 8-GPU run.
 
-    python tools/project_multi_gpu.py [--out profiles/r05_multi_gpu_projection.json]
+    python tools/project_multi_gpu.py [--out profiles/r06_multi_gpu_projection.json]
 """
 import argparse
 import json
@@ -29,15 +29,15 @@ sys.path.insert(0, ROOT)
 
 MODEL = {
     "round_rows": 1024, "round_ms": 7.6,                      # blind_rotate_fft_kernel, 4 workgroups per CU resident
-    "narrow_ms": 3.55, "narrow_rows": 256, "narrow_max_rows": 512, "narrow_ms_at_max": 6.1,   # blind_rotate_fft4_kernel
+    "narrow_ms": 2.95, "narrow_rows": 256, "narrow_max_rows": 512, "narrow_ms_at_max": 5.0,   # blind_rotate_fft4_kernel
     "ks_ms_per_1024_rows": 0.08, "group_overhead_ms": 0.05,   # keyswitch (MFMA) + lincomb; launch gaps
     "allgather_latency_ms": 0.04, "xgmi_link_gbs": 48.0,      # ASSUMED (never measured here)
-    "source": "profiles/r04_fft_3968_kernel_stats.csv (30.36 ms per 3968 rows), profiles/r04_fft4_64_kernel_stats.csv, "
+    "source": "profiles/r04_fft_3968_kernel_stats.csv (30.36 ms per 3968 rows), profiles/r06_fft4_64_kernel_stats.csv, "
               "DESIGN.md section 4; exchange figures assumed",
 }
-MEASURED_1GPU_MS = {          # profiles/r05_bench_default.json (one MI355X, one op alone, inputs resident)
-    "cfg2_contains_64": 16.84, "cfg3_find_encrypted_256": 35.70, "cfg4_replace_1024": 1031.9,
-    "cfg5_eq_ignore_case_4096": 199.6, "cfg5_le_4096": 119.0,
+MEASURED_1GPU_MS = {          # profiles/r06_bench_default.json (one MI355X, one op alone, inputs resident)
+    "cfg2_contains_64": 12.70, "cfg3_find_encrypted_256": 32.09, "cfg4_replace_1024": 1006.4,
+    "cfg5_eq_ignore_case_4096": 199.7, "cfg5_le_4096": 116.1,
 }
 
 
@@ -258,7 +258,7 @@ def cases():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_multi_gpu_projection.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_multi_gpu_projection.json"))
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     res = {"label": "PROJECTED -- counts from planner contexts (exact), times from a three-figure kernel model measured on "
@@ -286,7 +286,7 @@ def main():
         b = {str(N): bench_default_weak(N) for N in (1, 2, 4, 8)}
         for N in ("1", "2", "4", "8"):
             b[N]["projected_weak_scaling_efficiency"] = b[N]["projected_value_pbs_per_s"] / (int(N) * b["1"]["projected_value_pbs_per_s"])
-        b["measured_1gpu_value_pbs_per_s"] = 133922.0        # profiles/r05_bench_default.json (random pattern: 445 PBS per op)
+        b["measured_1gpu_value_pbs_per_s"] = 134374.0        # BENCH_r05.json (the driver's run of round 5; this round's builder runs: 136-140 k)
         res["bench_default_weak"] = b
         sys.stderr.write("bench default (weak)               " + "  ".join(
             "N=%s %.0f PBS/s (%.2f ms/step, eff %.2f)" % (N, b[N]["projected_value_pbs_per_s"], b[N]["projected_ms_per_step"],
