@@ -98,6 +98,12 @@ template <bool INV> __device__ __forceinline__ void stagesA_head(cplx (&z)[8], t
 #ifndef FFT4_KEY_SPREAD
 #define FFT4_KEY_SPREAD 1
 #endif
+// the two-workgroups-per-CU kernel (257..512 rows) has 256 registers per wavefront: a window of 2 chunks as in round 5.
+// (4 chunks, spread the same way, measured 4.95 vs 4.76 ms at 300 rows and 5.13 vs 5.22 ms at 512: inside the noise, not
+// adopted -- its second wavefront per SIMD already fills what a held wavefront leaves.)
+#ifndef FFT4_HB_NARROW
+#define FFT4_HB_NARROW 2
+#endif
 //   FFT4_REG_T1 / FFT4_REG_T2  (experiments, OFF: measured and not adopted, profiles/r06_fft4_ab_timeline.txt) the private
 //                 transposes inside the register file instead of through LDS: v_permlane32_swap / v_permlane16_swap exchange
 //                 lane bit 5 / 4 with a register bit, row_ror:8 / row_shr:4 / row_shl:4 moves under bank masks do it for lane
@@ -339,11 +345,12 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         const size_t koff = (size_t)(8 * (lane & 1)) * 64 + 32 * h + (lane >> 1);
         const double2_t *b_own = reinterpret_cast<const double2_t *>(P.bsk_fft) + ((((size_t)i * 2 + j) * 2 + j)) * FM + koff;
         const double2_t *b_par = reinterpret_cast<const double2_t *>(P.bsk_fft) + ((((size_t)i * 2 + (1 - j)) * 2 + j)) * FM + koff;
-        constexpr int HB = WIDE ? FFT4_HB_WIDE : 2;
+        constexpr int HB = WIDE ? FFT4_HB_WIDE : FFT4_HB_NARROW;
         double2_t bo[HB], bp[HB];
-        constexpr bool SPREAD = WIDE && FFT4_KEY_SPREAD && HB == 8;
-        // SPREAD: chunk k is requested at point k of the forward transform, pinned there
-#define FFT4_LDK(k) do { if (SPREAD) { __builtin_amdgcn_sched_barrier(0); bo[k] = b_own[(k) * 64]; bp[k] = b_par[(k) * 64]; \
+        constexpr bool SPREAD = FFT4_KEY_SPREAD && (WIDE ? HB == 8 : HB == 4);
+        constexpr int LDK_STRIDE = 8 / HB;           // HB = 8: chunk k at point k; HB = 4: chunk k at point 2 k, 4..7 in the product
+        // SPREAD: the first HB chunks are requested at points of the forward transform, pinned there
+#define FFT4_LDK(pt) do { if (SPREAD && (pt) % LDK_STRIDE == 0) { constexpr int k = (pt) / LDK_STRIDE; __builtin_amdgcn_sched_barrier(0); bo[k] = b_own[k * 64]; bp[k] = b_par[k * 64]; \
                                         __builtin_amdgcn_sched_barrier(0); } } while (0)
         if (!SPREAD) {
 #pragma unroll
