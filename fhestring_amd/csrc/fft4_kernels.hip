@@ -98,6 +98,12 @@ template <bool INV> __device__ __forceinline__ void stagesA_head(cplx (&z)[8], t
 #ifndef FFT4_KEY_SPREAD
 #define FFT4_KEY_SPREAD 1
 #endif
+//   FFT4_XCHG_I32  (one workgroup per CU) the FORWARD cross-half exchange carries the digits as two 32-bit integers per point
+//                 (8 B: ds_write_b64 / ds_read_b64) instead of two doubles (16 B); the partner converts them -- the same
+//                 exact values, half the bytes through the LDS store path.
+#ifndef FFT4_XCHG_I32
+#define FFT4_XCHG_I32 1
+#endif
 // the two-workgroups-per-CU kernel (257..512 rows) has 256 registers per wavefront: a window of 2 chunks as in round 5.
 // (4 chunks, spread the same way, measured 4.95 vs 4.76 ms at 300 rows and 5.13 vs 5.22 ms at 512: inside the noise, not
 // adopted -- its second wavefront per SIMD already fills what a held wavefront leaves.)
@@ -229,12 +235,16 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
     constexpr int AREA = 4 * F4_WAVE_BYTES;
     constexpr bool OVERLAP = WIDE && FFT4_OVERLAP;
     constexpr bool EARLY_X = OVERLAP;
+    constexpr bool XI32 = EARLY_X && FFT4_XCHG_I32;
     constexpr bool REG_T1 = WIDE && FFT4_REG_T1;
     constexpr bool REG_T2 = WIDE && FFT4_REG_T2;
     char *const xbase = smem + (WIDE ? AREA : 0), *const mbase = smem + (WIDE ? 2 * AREA : 0), *const pbase = smem + (WIDE ? 3 * AREA : 0);
     cplx *mine = reinterpret_cast<cplx *>(mbase + w * F4_WAVE_BYTES);                      // private transposes
     cplx *xmine = reinterpret_cast<cplx *>(xbase + w * F4_WAVE_BYTES);                     // cross-half exchange, own half
     const cplx *pair = reinterpret_cast<const cplx *>(xbase + (w ^ 1) * F4_WAVE_BYTES);    // other half, same polynomial
+    typedef int32_t __attribute__((ext_vector_type(2))) int2_t;
+    int2_t *xmine_i = reinterpret_cast<int2_t *>(xbase + w * F4_WAVE_BYTES);               // (XI32) point n at slot n, 8 B each
+    const int2_t *pair_i = reinterpret_cast<const int2_t *>(xbase + (w ^ 1) * F4_WAVE_BYTES);
     cplx *pmine = reinterpret_cast<cplx *>(pbase + w * F4_WAVE_BYTES);                     // published transform
     const cplx *other = reinterpret_cast<const cplx *>(pbase + (w ^ 2) * F4_WAVE_BYTES);   // same half, other polynomial
     uint64_t *stage = reinterpret_cast<uint64_t *>(smem + j * 2 * F4_WAVE_BYTES);          // 2048 words of polynomial j
@@ -299,6 +309,7 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
         __syncthreads();                              // staged accumulator of both halves visible
         FFT4_TL(1);
         cplx z[8];
+        int32_t dre[8];                               // (XI32) the real digits, kept as integers until their point goes out
         // as in fft_kernels.hip: lane rotation by s mod 64 (per-lane base), row rotation by s div 64 (scalar offset per
         // register; this wave's register r is row 8 h + (r & 7) + 16 (r >> 3)), borrowing lanes one row lower
         const uint32_t sl = s & 63, sh = s >> 6;
@@ -331,9 +342,11 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
             const uint32_t nhi = rot_sub_hi_compl(v, acc[r], wrapmask ^ keep_unless_wrapped);
             const int32_t dig = (int32_t)(0xFFu - nhi) >> 9;
             if (r < 8) z[r].r = (double)dig; else z[r - 8].i = (double)dig;
+            if (XI32 && r < 8) dre[r] = dig;
             // WIDE: the exchange area is this wavefront's own, so point r - 8 goes out as soon as its imaginary digit exists
             // (the partner's last read of it was before barrier 4 of the previous iteration)
-            if (EARLY_X && r >= 8) xmine[pslot(lane + 64 * (r - 8))] = z[r - 8];
+            if (XI32 && r >= 8) { int2_t d2; d2.x = dre[r - 8]; d2.y = dig; xmine_i[lane + 64 * (r - 8)] = d2; }
+            else if (EARLY_X && r >= 8) xmine[pslot(lane + 64 * (r - 8))] = z[r - 8];
             __builtin_amdgcn_sched_barrier(0);
         }
         FFT4_TL(2);
@@ -370,8 +383,16 @@ __device__ __forceinline__ void fft4_bootstrap(const BlindRotateFftParams &P, ch
             // all 8 partner points requested first, ONE wave-uniform branch around the butterflies (a branch and a
             // serialized LDS round trip per point before)
             cplx o[8];
+            if (XI32) {
+                int2_t oi[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) o[r] = pair[pslot(lane + 64 * r)];
+                for (int r = 0; r < 8; r++) oi[r] = pair_i[lane + 64 * r];
+#pragma unroll
+                for (int r = 0; r < 8; r++) { o[r].r = (double)oi[r].x; o[r].i = (double)oi[r].y; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; r++) o[r] = pair[pslot(lane + 64 * r)];
+            }
             if (h == 0) {
 #pragma unroll
                 for (int r = 0; r < 8; r++) bf_fwd<false>(z[r], o[r], w1.r, w1.i);

@@ -137,7 +137,7 @@ def build():
 
 AB = {"ab_neither": ["-DFFT4_OVERLAP=0", "-DFFT4_HB_WIDE=2"], "ab_keys_early": ["-DFFT4_OVERLAP=0", "-DFFT4_KEY_SPREAD=0"],
       "ab_overlap": ["-DFFT4_OVERLAP=2", "-DFFT4_HB_WIDE=2"], "ab_overlap_keys_early": ["-DFFT4_KEY_SPREAD=0"],
-      "ab_keys_spread": ["-DFFT4_OVERLAP=0"], "ab_overlap1_keys_spread": ["-DFFT4_OVERLAP=1"], "ab_reg_t1": ["-DFFT4_REG_T1=1"], "ab_narrow_hb4": ["-DFFT4_HB_NARROW=4"],
+      "ab_keys_spread": ["-DFFT4_OVERLAP=0"], "ab_overlap1_keys_spread": ["-DFFT4_OVERLAP=1"], "ab_reg_t1": ["-DFFT4_REG_T1=1"], "ab_xchg_f64": ["-DFFT4_XCHG_I32=0"],
       "ab_reg_t1_t2": ["-DFFT4_REG_T1=1", "-DFFT4_REG_T2=1"], "ab_all": [],
       "ab_timeline": ["-DFFT4_TIMELINE"]}
 

@@ -41,14 +41,18 @@ sk.set_mode(1)
 sk.set_tick_balance()
 import random  # noqa: E402
 rnd = random.Random(1)
-s = "".join(chr(rnd.randint(0x20, 0x7E)) for _ in range(64))
+OP = os.environ.get("FHS_TRACE_OP", "contains")          # contains (64 chars, clear pattern) | find (256 chars, encrypted pattern)
+n = 64 if OP == "contains" else 256
+s = "".join(chr(rnd.randint(0x20, 0x7E)) for _ in range(n))
 es = ck.encrypt(s, 1, None, sk)
+ep = ck.encrypt_no_padding(s[200:204], sk) if OP == "find" else None
 sk.flush()
 for k in range(6):
     time.sleep(0.01)
     t0 = time.perf_counter()
-    r = sk.contains_clear(es, s[20:24])
+    r = sk.contains_clear(es, s[20:24]) if OP == "contains" else sk.find(es, ep)
+    t1 = time.perf_counter()
     sk.flush()
     dt = time.perf_counter() - t0
-    print("op %d: %.3f ms, found %d" % (k, dt * 1e3, ck.decrypt_char(r)), flush=True)
+    print("op %d: %.3f ms (recording the DAG %.3f ms), result %d" % (k, dt * 1e3, (t1 - t0) * 1e3, ck.decrypt_char(r)), flush=True)
 sk.close()
