@@ -63,7 +63,7 @@ def test_roofline_counters_are_tied_to_the_kernel_sources():
         assert set(counters[kernel]["source_blobs"]) == set(ks.KERNEL_SOURCES[kernel])
         moved = ks.stale_sources(kernel, counters[kernel]["source_blobs"])
         if moved:        # not a failure on the CPU (a kernel under development): bench.py withholds the figures, and the
-            warnings.warn("%s changed after its counters were taken (%s): re-run tools/gpu_profile_r5.sh + tools/build_counters.py before the "
+            warnings.warn("%s changed after its counters were taken (%s): re-run tools/gpu_profile_r6.sh + tools/build_counters.py --round r06 before the "
                           "round ends -- tests/test_gpu_bench_contract.py refuses a stale headline" % (kernel, moved))
     rec = dict(counters["blind_rotate_fft_kernel"]["source_blobs"])
     rec["fft_transform.h"] = "0" * 40
